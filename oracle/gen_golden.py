@@ -1,0 +1,315 @@
+"""ORACLE -- golden-vector generator (run in the BUILD CONTAINER only; needs /root/reference).
+
+    python -m oracle.gen_golden            # writes tests/golden/<case>.npz
+
+For every case in ``oracle/cases.py`` this script
+
+1. puts the stand-ins of ``oracle/standins/`` (``distribution_extension``, ``torchrl``, ``cnn``,
+   ``lightning`` -- all absent from this image) on ``sys.path`` and registers *empty* package
+   objects for ``multimodal_rssm[.models[...]]`` so that the reference's own hot-path files are
+   imported from ``/root/reference/src`` WITHOUT executing its package ``__init__`` files (those pull
+   wandb / gdown / torchvision, which are absent and off the path);
+2. builds the reference ``MoPoE_MRSSM`` / ``MoPoE_MMTRSSM`` from its own ``Representation`` /
+   ``Transition`` / ``MTRNN`` classes, loads the oracle's seeded weights BY STATE-DICT NAME
+   (``strict=True`` -- pins SURVEY.md section 8b's names);
+3. runs the reference ``shared_step`` + ``backward``, ``rollout_representation``,
+   ``State.__getitem__`` and ``rollout_transition`` on the injected-noise tape in the reference's
+   own draw order;
+4. asserts the restatement in ``oracle/ref_model.py`` reproduces every value (losses, per-step
+   deter / logits / one-hot samples, gradients);
+5. freezes inputs, noise, per-parameter weight checksums and outputs in ``tests/golden/<case>.npz``.
+
+Nothing from the reference is copied: fixtures hold data only.  The third-party arithmetic under
+both runs is the build-defined restatement (parity unpinned there).
+"""
+
+from __future__ import annotations
+
+import importlib
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+import torch
+from torch import nn
+
+ROOT = Path(__file__).resolve().parents[1]
+REF_SRC = Path("/root/reference/src")
+GOLDEN = ROOT / "tests" / "golden"
+
+sys.path.insert(0, str(ROOT))
+
+from oracle import ref_dists  # noqa: E402
+from oracle.cases import CASES, MARGIN, Case, build_batch, build_model, build_noise, min_margin  # noqa: E402
+
+
+def _mount_reference() -> None:
+    sys.path.insert(0, str(ROOT / "oracle" / "standins"))
+    for pkg in (
+        "multimodal_rssm", "multimodal_rssm.models", "multimodal_rssm.models.mrssm",
+        "multimodal_rssm.models.mrssm.mopoe_mrssm", "multimodal_rssm.models.mmtrssm",
+        "multimodal_rssm.models.mmtrssm.mopoe_mmtrssm",
+    ):
+        mod = types.ModuleType(pkg)
+        mod.__path__ = [str(REF_SRC / pkg.replace(".", "/"))]
+        sys.modules[pkg] = mod
+
+
+def _ref_classes() -> dict[str, type]:
+    net = importlib.import_module("multimodal_rssm.models.networks")
+    mr = importlib.import_module("multimodal_rssm.models.mrssm.mopoe_mrssm.core")
+    mt = importlib.import_module("multimodal_rssm.models.mmtrssm.mopoe_mmtrssm.core")
+    st = importlib.import_module("multimodal_rssm.models.state")
+    mst = importlib.import_module("multimodal_rssm.models.mmtrssm.state")
+    return {
+        "Representation": net.Representation, "Transition": net.Transition, "MoPoE_MRSSM": mr.MoPoE_MRSSM,
+        "MoPoE_MMTRSSM": mt.MoPoE_MMTRSSM, "State": st.State, "cat_states": st.cat_states,
+        "MTState": mst.MTState, "cat_mtstates": mst.cat_mtstates,
+    }
+
+
+def _build_reference(case: Case, cls: dict[str, type]) -> nn.Module:
+    import cnn  # stand-in
+    from distribution_extension import MultiOneHotFactory  # stand-in
+    from torchrl.modules import MLP  # stand-in
+
+    d = case.dims
+    if case.kind == "mrssm":
+        rep = {"deterministic_size": d.deter, "hidden_size": d.hidden, "obs_embed_size": d.embed,
+               "distribution_config": [d.classes, d.cats], "activation_name": d.activation}
+        return cls["MoPoE_MRSSM"](
+            audio_representation=cls["Representation"](**rep),
+            vision_representation=cls["Representation"](**rep),
+            transition=cls["Transition"](deterministic_size=d.deter, hidden_size=d.hidden, action_size=d.action,
+                                         distribution_config=[d.classes, d.cats], activation_name=d.activation),
+            audio_encoder=cnn.Encoder(d.enc_audio), vision_encoder=cnn.Encoder(d.enc_vision),
+            audio_decoder=cnn.Decoder(d.dec_audio), vision_decoder=cnn.Decoder(d.dec_vision),
+            init_proj=MLP(in_features=d.embed, out_features=d.deter, num_cells=d.init_cells, depth=1),
+            kl_coeff=d.kl_coeff, use_kl_balancing=d.use_kl_balancing,
+        )
+    rep = {"deterministic_size": d.ld, "hidden_size": d.hidden, "obs_embed_size": d.embed,
+           "distribution_config": [d.ls_classes, d.ls_cats], "activation_name": d.activation}
+    act = getattr(nn, d.activation)
+    return cls["MoPoE_MMTRSSM"](
+        audio_representation=cls["Representation"](**rep), vision_representation=cls["Representation"](**rep),
+        audio_encoder=cnn.Encoder(d.enc_audio), vision_encoder=cnn.Encoder(d.enc_vision),
+        audio_decoder=cnn.Decoder(d.dec_audio), vision_decoder=cnn.Decoder(d.dec_vision),
+        init_proj=MLP(in_features=d.embed, out_features=d.hd + d.ld, num_cells=d.init_cells, depth=1),
+        kl_coeff=d.kl_coeff, use_kl_balancing=d.use_kl_balancing,
+        action_size=d.action, hd_dim=d.hd, hs_dim=d.hs, ld_dim=d.ld, ls_dim=d.ls, l_tau=d.l_tau, h_tau=d.h_tau,
+        l_prior=MLP(in_features=d.ld, out_features=d.ls, num_cells=d.hidden, depth=1, activation_class=act),
+        l_posterior=MLP(in_features=d.ld + d.embed, out_features=d.ls, num_cells=d.hidden, depth=1, activation_class=act),
+        h_prior=MLP(in_features=d.hd, out_features=d.hs, num_cells=d.hidden, depth=1, activation_class=act),
+        h_posterior=MLP(in_features=d.ld + d.hd, out_features=d.hs, num_cells=d.hidden, depth=1, activation_class=act),
+        l_dist=MultiOneHotFactory(class_size=d.ls_classes, category_size=d.ls_cats),
+        h_dist=MultiOneHotFactory(class_size=d.hs_classes, category_size=d.hs_cats),
+        w_kl_h=d.w_kl_h,
+    )
+
+
+def _tape_for_shared_step(case: Case, noise: dict[str, torch.Tensor], steps: int) -> list[torch.Tensor]:
+    """Uniforms in the reference's draw order (SURVEY.md section 7 "RNG contract")."""
+    tape: list[torch.Tensor] = []
+    if case.kind == "mrssm":
+        tape.append(noise["u_init"])
+        junk = torch.full_like(noise["u_init"], 0.5)
+        for t in range(steps):
+            tape += [noise["u_prior"][:, t], junk, junk, noise["u_post"][:, t]]
+    else:
+        tape += [noise["u_init_h"], noise["u_init_l"]]
+        for t in range(steps):
+            tape += [noise["u_post_l"][:, t], noise["u_post_h"][:, t], noise["u_prior_h"][:, t], noise["u_prior_l"][:, t]]
+    return tape
+
+
+def _close(name: str, a: torch.Tensor, b: torch.Tensor, rtol: float = 1e-6, atol: float = 1e-6) -> None:
+    a, b = a.detach(), b.detach()
+    if a.shape != b.shape:
+        msg = f"{name}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+        raise AssertionError(msg)
+    if not torch.allclose(a, b, rtol=rtol, atol=atol):
+        err = (a - b).abs().max().item()
+        msg = f"{name}: reference vs restatement differ, max abs err {err:.3e}"
+        raise AssertionError(msg)
+
+
+def _onehot_index(stoch: torch.Tensor, cats: int, classes: int) -> np.ndarray:
+    return stoch.detach().reshape(*stoch.shape[:-1], cats, classes).argmax(-1).to(torch.int8).numpy()
+
+
+def _run_case(case: Case, cls: dict[str, type]) -> dict[str, np.ndarray]:  # noqa: PLR0914, PLR0915
+    oracle = build_model(case)
+    batch = build_batch(case)
+    d = case.dims
+    # -- pick a noise seed whose every draw keeps the safety margin -----------------------
+    seed = case.noise_seed
+    for attempt in range(5000):
+        noise = build_noise(case, seed + attempt)
+        with torch.no_grad():
+            probe = oracle.shared_step(batch, noise)
+        if min_margin(case, probe, noise) >= MARGIN:
+            seed += attempt
+            break
+    else:
+        msg = f"{case.name}: no noise seed with margin >= {MARGIN}"
+        raise RuntimeError(msg)
+
+    oracle.zero_grad()
+    out = oracle.shared_step(batch, noise)
+    out["loss"].backward()
+    o_grads = {k: p.grad.clone() for k, p in oracle.named_parameters() if p.grad is not None}
+
+    # -- the reference's own control flow -------------------------------------------------
+    ref = _build_reference(case, cls)
+    missing = ref.load_state_dict(oracle.state_dict(), strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    ref_dists.TAPE.clear()
+    ref_dists.TAPE.extend(_tape_for_shared_step(case, noise, case.steps))
+    ref.zero_grad()
+    r_loss = ref.shared_step(batch)
+    assert len(ref_dists.TAPE) == 0, "reference drew fewer samples than the documented RNG contract"
+    r_loss["loss"].backward()
+    keys = ("loss", "recon", "recon/audio", "recon/vision", "kl") + (("kl_h",) if case.kind == "mmtrssm" else ())
+    assert set(r_loss) == set(keys), sorted(r_loss)
+    for k in keys:
+        _close(f"{case.name}:{k}", r_loss[k], out[k], rtol=2e-6)
+    r_grads = {k: p.grad for k, p in ref.named_parameters() if p.grad is not None}
+    assert set(r_grads) == set(o_grads), sorted(set(r_grads) ^ set(o_grads))
+    for k, g in r_grads.items():
+        _close(f"{case.name}:grad:{k}", g, o_grads[k], rtol=1e-4, atol=1e-6 + 1e-5 * float(o_grads[k].abs().max()))
+
+    # rollout + indexing + prior-only rollout, as mrssm/callback.py:156-189 uses them
+    ref_dists.TAPE.clear()
+    ref_dists.TAPE.extend(_tape_for_shared_step(case, noise, case.steps))
+    q = case.query
+    with torch.no_grad():
+        obs = (batch[1], batch[2])
+        state0 = ref.initial_state((batch[1][:, 0], batch[2][:, 0]))
+        post, prior = ref.rollout_representation(actions=batch[0], observations=obs, prev_state=state0)
+        start = post[:, q - 1]
+        if case.kind == "mrssm":
+            ref_dists.TAPE.extend([noise["u_trans"][:, t] for t in range(case.steps - q)])
+        else:
+            for t in range(case.steps - q):
+                ref_dists.TAPE.extend([noise["u_trans_h"][:, t], noise["u_trans_l"][:, t]])
+        trans = ref.rollout_transition(actions=batch[0][:, q:], prev_state=start)
+        joined = (cls["cat_states"] if case.kind == "mrssm" else cls["cat_mtstates"])([post[:, :q], trans], dim=1)
+        assert len(ref_dists.TAPE) == 0
+
+    fx: dict[str, np.ndarray] = {"noise_seed": np.asarray(seed), "margin": np.asarray(min_margin(case, out, noise))}
+    for i, name in enumerate(("action_in", "audio_in", "vision_in", "action_tgt", "audio_tgt", "vision_tgt")):
+        fx[f"batch/{name}"] = batch[i].numpy()
+    for k, v in noise.items():
+        fx[f"noise/{k}"] = v.numpy()
+    for k, p in oracle.state_dict().items():
+        fx[f"wsum/{k}"] = np.asarray([p.double().sum().item(), p.double().abs().sum().item()])
+    for k in keys:
+        fx[f"loss/{k}"] = np.asarray(float(r_loss[k].detach()), dtype=np.float64)
+
+    if case.kind == "mrssm":
+        _close("deter", post.deter, out["_deter"])
+        _close("post_logits", post.distribution.logits.flatten(-2), torch.log_softmax(
+            out["_post_logits"].reshape(*out["_post_logits"].shape[:-1], d.cats, d.classes), -1).flatten(-2))
+        _close("prior_probs", prior.distribution.probs.flatten(-2), torch.softmax(
+            out["_prior_logits"].reshape(*out["_prior_logits"].shape[:-1], d.cats, d.classes), -1).flatten(-2))
+        _close("post_stoch", post.stoch, out["_post_stoch"], atol=0)
+        _close("prior_stoch", prior.stoch, out["_prior_stoch"], atol=0)
+        _close("feature", post.feature, torch.cat([out["_deter"], out["_post_stoch"]], -1))
+        with torch.no_grad():
+            o_trans = oracle.rollout_transition(
+                batch[0][:, q:], {"deter": out["_deter"][:, q - 1], "stoch": out["_post_stoch"][:, q - 1]}, noise["u_trans"])
+        _close("trans_deter", trans.deter, o_trans["deter"])
+        _close("trans_stoch", trans.stoch, o_trans["prior_stoch"], atol=0)
+        assert joined.deter.shape[1] == case.steps
+        for k in ("deter", "prior_logits", "audio_logits", "vision_logits", "post_logits"):
+            fx[f"out/{k}"] = out[f"_{k}"].detach().numpy()
+        fx["out/post_probs"] = post.distribution.probs.numpy()
+        fx["out/prior_probs"] = prior.distribution.probs.numpy()
+        fx["out/post_index"] = _onehot_index(post.stoch, d.cats, d.classes)
+        fx["out/prior_index"] = _onehot_index(prior.stoch, d.cats, d.classes)
+        fx["out/deter0"] = state0.deter.numpy()
+        fx["out/stoch0_index"] = _onehot_index(state0.stoch, d.cats, d.classes)
+        fx["out/audio_embed"] = out["_audio_embed"].detach().numpy()
+        fx["out/vision_embed"] = out["_vision_embed"].detach().numpy()
+        fx["trans/deter"] = trans.deter.numpy()
+        fx["trans/prior_probs"] = trans.distribution.probs.numpy()
+        fx["trans/index"] = _onehot_index(trans.stoch, d.cats, d.classes)
+        grad_keys = [k for k in r_grads if k.startswith(("transition.", "representation.", "vision_representation.", "init_proj."))]
+    else:
+        _close("deter_l", post.deter_l, out["_deter_l"])
+        _close("deter_h", post.deter_h, out["_deter_h"])
+        _close("hidden_l", post.hidden_l, out["_hidden_l"])
+        _close("hidden_h", post.hidden_h, out["_hidden_h"])
+        _close("post_stoch_l", post.stoch_l, out["_post_stoch_l"], atol=0)
+        _close("post_stoch_h", post.stoch_h, out["_post_stoch_h"], atol=0)
+        _close("prior_stoch_l", prior.stoch_l, out["_prior_stoch_l"], atol=0)
+        _close("prior_stoch_h", prior.stoch_h, out["_prior_stoch_h"], atol=0)
+        _close("feature", post.feature, torch.cat(
+            [out["_deter_h"], out["_post_stoch_h"], out["_deter_l"], out["_post_stoch_l"]], -1))
+        st0 = {"deter_l": out["_deter_l"][:, q - 1], "deter_h": out["_deter_h"][:, q - 1],
+               "hidden_l": out["_hidden_l"][:, q - 1], "hidden_h": out["_hidden_h"][:, q - 1],
+               "stoch_l": out["_post_stoch_l"][:, q - 1], "stoch_h": out["_post_stoch_h"][:, q - 1]}
+        with torch.no_grad():
+            o_trans = oracle.rollout_transition(
+                batch[0][:, q:], st0, {"u_prior_h": noise["u_trans_h"], "u_prior_l": noise["u_trans_l"]})
+        _close("trans_deter_l", trans.deter_l, o_trans["deter_l"])
+        _close("trans_deter_h", trans.deter_h, o_trans["deter_h"])
+        _close("trans_stoch_l", trans.stoch_l, o_trans["prior_stoch_l"], atol=0)
+        _close("trans_stoch_h", trans.stoch_h, o_trans["prior_stoch_h"], atol=0)
+        assert joined.deter_l.shape[1] == case.steps
+        for k in ("deter_l", "deter_h", "hidden_l", "hidden_h", "prior_logits_l", "prior_logits_h", "audio_logits",
+                  "vision_logits", "post_logits_l", "post_logits_h"):
+            fx[f"out/{k}"] = out[f"_{k}"].detach().numpy()
+        fx["out/post_probs_l"] = post.distribution_l.probs.numpy()
+        fx["out/post_probs_h"] = post.distribution_h.probs.numpy()
+        fx["out/prior_probs_l"] = prior.distribution_l.probs.numpy()
+        fx["out/prior_probs_h"] = prior.distribution_h.probs.numpy()
+        fx["out/post_index_l"] = _onehot_index(post.stoch_l, d.ls_cats, d.ls_classes)
+        fx["out/post_index_h"] = _onehot_index(post.stoch_h, d.hs_cats, d.hs_classes)
+        fx["out/prior_index_l"] = _onehot_index(prior.stoch_l, d.ls_cats, d.ls_classes)
+        fx["out/prior_index_h"] = _onehot_index(prior.stoch_h, d.hs_cats, d.hs_classes)
+        fx["out/init_deter_h"] = state0.deter_h.numpy()
+        fx["out/init_deter_l"] = state0.deter_l.numpy()
+        fx["out/init_index_h"] = _onehot_index(state0.stoch_h, d.hs_cats, d.hs_classes)
+        fx["out/init_index_l"] = _onehot_index(state0.stoch_l, d.ls_cats, d.ls_classes)
+        fx["out/audio_embed"] = out["_audio_embed"].detach().numpy()
+        fx["out/vision_embed"] = out["_vision_embed"].detach().numpy()
+        fx["trans/deter_l"] = trans.deter_l.numpy()
+        fx["trans/deter_h"] = trans.deter_h.numpy()
+        fx["trans/index_l"] = _onehot_index(trans.stoch_l, d.ls_cats, d.ls_classes)
+        fx["trans/index_h"] = _onehot_index(trans.stoch_h, d.hs_cats, d.hs_classes)
+        grad_keys = [k for k in r_grads if k.startswith(
+            ("l_rnn.", "h_rnn.", "l_prior.", "h_prior.", "h_posterior.", "representation.", "vision_representation.", "init_proj."))]
+        fx["meta/no_grad_params"] = np.asarray(sorted(set(dict(ref.named_parameters())) - set(r_grads)))
+
+    # gradients: full tensors when small, a strided sample + norms when large
+    for k in grad_keys:
+        g = r_grads[k].detach().flatten()
+        fx[f"gradnorm/{k}"] = np.asarray([g.double().norm().item(), g.double().sum().item()])
+        stride = max(1, g.numel() // 4096)
+        fx[f"grad/{k}"] = g[::stride].numpy()
+    for k, g in r_grads.items():
+        if k not in grad_keys:
+            fx[f"gradnorm/{k}"] = np.asarray([g.double().norm().item(), g.double().sum().item()])
+    return fx
+
+
+def main() -> None:
+    if not REF_SRC.exists():
+        msg = "gen_golden needs /root/reference (build container only)"
+        raise SystemExit(msg)
+    torch.set_num_threads(1)  # fixed summation order inside every op
+    _mount_reference()
+    cls = _ref_classes()
+    GOLDEN.mkdir(parents=True, exist_ok=True)
+    for name in (sys.argv[1:] or list(CASES)):
+        fx = _run_case(CASES[name], cls)
+        path = GOLDEN / f"{name}.npz"
+        np.savez_compressed(path, **fx)
+        print(f"{name}: reference == restatement; margin {float(fx['margin']):.2e}; "
+              f"loss {float(fx['loss/loss']):.6f}; wrote {path.relative_to(ROOT)} ({path.stat().st_size / 1024:.0f} KiB)")
+
+
+if __name__ == "__main__":
+    main()
