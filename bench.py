@@ -1,0 +1,227 @@
+"""bench.py -- seq-steps/s of the MoPoE-MRSSM train step on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one full train step (encoders -> initial state -> T-step scan -> decoders -> Gaussian NLL +
+KL -> backward -> [one RCCL all-reduce] -> global-norm clip + AdamW) on one synthetic batch that is already
+resident in HBM.  Workload = BASELINE.json configs[1]: MoPoE-MRSSM B=64 per GPU, T=50, deter=200,
+stoch=30 (6 categoricals x 5 classes), action=4, vision 1x64x64 + audio 1x128x32 (128 mel bins x 32
+frames); the dims BASELINE leaves open are build-chosen and printed in ``config``.  N > 1 shards the
+sequence batch data-parallel (weak scaling: 64 sequences per GPU), one process per GPU.
+
+Rank 0 prints ONE JSON line.  ``roofline`` is for the dominant hand-written kernel of the step (HIP events
+on the launch stream inside the timed region); ``cpu_baseline`` times the oracle (``oracle/ref_model.py``,
+the op-for-op eager restatement of the reference loop) on this box's host cores on a bounded sample.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+import torch.distributed as dist
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+
+WORKLOAD = dict(batch_per_gpu=64, steps=50, deter=200, hidden=200, classes=5, cats=6, action=4, embed=256,
+                vision=(1, 64, 64), audio=(1, 128, 32))
+
+
+def build_model(device: str):  # noqa: ANN201
+    import multimodal_mtrssm_amd as mt
+    from multimodal_mtrssm_amd.factory import decoder_config, encoder_config
+
+    w = WORKLOAD
+    feat = w["deter"] + w["classes"] * w["cats"]
+    torch.manual_seed(42)  # yaml: seed_everything: 42
+    model = mt.make_mrssm(
+        deter=w["deter"], hidden=w["hidden"], classes=w["classes"], cats=w["cats"], action=w["action"], embed=w["embed"],
+        enc_audio=encoder_config(w["audio"], w["embed"]), enc_vision=encoder_config(w["vision"], w["embed"]),
+        dec_audio=decoder_config(feat, w["audio"]), dec_vision=decoder_config(feat, w["vision"]),
+    )
+    return model.to(device)
+
+
+def synthetic_batch(batch: int, device: str, seed: int) -> tuple[torch.Tensor, ...]:
+    """targets U(-1,1), inputs = targets + N(0, 0.1^2), actions N(0,1)."""
+    w = WORKLOAD
+    g = torch.Generator().manual_seed(seed)
+    t = w["steps"]
+    act_t = torch.randn(batch, t, w["action"], generator=g)
+    aud_t = torch.rand(batch, t, *w["audio"], generator=g) * 2 - 1
+    vis_t = torch.rand(batch, t, *w["vision"], generator=g) * 2 - 1
+    act_i = act_t + 0.1 * torch.randn(act_t.shape, generator=g)
+    aud_i = aud_t + 0.1 * torch.randn(aud_t.shape, generator=g)
+    vis_i = vis_t + 0.1 * torch.randn(vis_t.shape, generator=g)
+    return tuple(x.to(device) for x in (act_i, aud_i, vis_i, act_t, aud_t, vis_t))
+
+
+def cpu_baseline(seconds_budget: float = 25.0) -> dict[str, object]:
+    """The oracle's train step (fwd + bwd + clip + AdamW) on the host cores, same dims, bounded sample."""
+    from oracle.cases import decoder_config, encoder_config
+    from oracle.ref_model import MRSSMDims, OracleMRSSM
+
+    w = WORKLOAD
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    feat = w["deter"] + w["classes"] * w["cats"]
+    dims = MRSSMDims(deter=w["deter"], hidden=w["hidden"], classes=w["classes"], cats=w["cats"], action=w["action"],
+                     embed=w["embed"], enc_audio=encoder_config(w["audio"], w["embed"]),
+                     enc_vision=encoder_config(w["vision"], w["embed"]), dec_audio=decoder_config(feat, w["audio"]),
+                     dec_vision=decoder_config(feat, w["vision"]))
+    torch.manual_seed(42)
+    model = OracleMRSSM(dims)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    b = 8
+    batch = synthetic_batch(b, "cpu", 1)
+    noise = {"u_init": torch.rand(b, w["cats"]), "u_prior": torch.rand(b, w["steps"], w["cats"]),
+             "u_post": torch.rand(b, w["steps"], w["cats"])}
+
+    def step() -> None:
+        opt.zero_grad()
+        out = model.shared_step(batch, noise, wasteful=True)
+        out["loss"].backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
+        opt.step()
+
+    step()  # warm-up
+    times: list[float] = []
+    t_start = time.perf_counter()
+    while len(times) < 5 and (time.perf_counter() - t_start < seconds_budget or len(times) < 2):
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    return {"value": b * w["steps"] / med, "unit": "seq-steps/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/ref_model.py train step (fwd+bwd+clip+AdamW), B={b} T={w['steps']} same dims, "
+                      f"median of {len(times)} after 1 warm-up, {torch.get_num_threads()} torch threads"}
+
+
+def main() -> None:  # noqa: PLR0914, PLR0915
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        msg = f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
+        raise SystemExit(msg)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+
+    import multimodal_mtrssm_amd as mt
+    from multimodal_mtrssm_amd import scan
+    from multimodal_mtrssm_amd.optim import FlatParameters
+
+    w = WORKLOAD
+    model = build_model(device)
+    flat = FlatParameters(model, extra=8)
+    dp = mt.FlatDataParallel(flat)
+    dp.broadcast_parameters(0)
+    opt = mt.FlatAdamW(flat, lr=1e-3, clip_norm=10.0)
+    b = w["batch_per_gpu"]
+    batch = synthetic_batch(b, device, seed=1000 + rank)  # each rank owns its own 64 sequences (weak scaling)
+    gnoise = torch.Generator(device=device).manual_seed(7 + rank)
+
+    def train_step() -> dict[str, torch.Tensor]:
+        noise = {"u_init": torch.rand(b, w["cats"], device=device, generator=gnoise),
+                 "u_post": torch.rand(b, w["steps"], w["cats"], device=device, generator=gnoise)}
+        opt.zero_grad()
+        out = model.shared_step(batch, noise)
+        out["loss"].backward()
+        scalars = dp.sync({k: out[k] for k in ("loss", "recon", "kl")})
+        opt.step(grad_scale=dp.grad_scale)
+        return scalars
+
+    def barrier() -> None:
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        train_step()
+    scan.KERNEL_TIMERS.enable()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        scalars = train_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = scan.KERNEL_TIMERS.summary()
+    scan.KERNEL_TIMERS.disable()
+    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        seq_steps = b * world * w["steps"]
+        ms = elapsed / args.steps * 1e3
+        # dominant hand-written kernel of the step + its algorithmic HBM bytes per launch:
+        # forward scan per (b,t): reads xa,pa,pv (3H) + 2 uniform rows (K), writes deter (D), 2 logit sets + sample (3S),
+        # kl (1) and the saved activations h1,h2 (2H), gates (4D), heads (3H), audio/vision logits (2S); fp32.
+        D, H, S, K = w["deter"], w["hidden"], w["classes"] * w["cats"], w["cats"]
+        fwd_bytes = 4 * (3 * H + K + D + 3 * S + 1 + 2 * H + 4 * D + 3 * H + 2 * S) * b * w["steps"]
+        # backward scan per (b,t): reads the saved activations + deter + 2 logit sets + incoming g_deter, g_stoch, g_kl;
+        # writes d_z1, d_h2 (2H), d_gi, d_gh (6D), d_zh (3H), d_lp, d_la, d_lv (3S)
+        bwd_bytes = 4 * ((2 * H + 4 * D + 3 * H + 2 * S) + D + 2 * S + (D + S + 1) + 2 * H + 6 * D + 3 * H + 3 * S) * b * w["steps"]
+        name, dur = max(kernel_ms.items(), key=lambda kv: kv[1]) if kernel_ms else ("none", float("nan"))
+        algo = {"mtrssm_mrssm_rollout_fwd": fwd_bytes, "mtrssm_mrssm_rollout_bwd": bwd_bytes}.get(name, 0)
+        achieved = algo / (dur * 1e-3) / 1e9 if dur == dur and dur > 0 else None
+        line = {
+            "metric": "seq-steps/s (BxT) MoPoE-MRSSM train step",
+            "value": seq_steps / (elapsed / args.steps),
+            "unit": "seq-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[1]: MoPoE-MRSSM train step, B=64/GPU T=50 deter=200 stoch=30, vision 1x64x64 + audio 1x128x32 + action 4",
+                "global_batch": b * world, "seq_len": w["steps"], "parallelism": f"dp{world}",
+                "hidden": w["hidden"], "embed": w["embed"], "categoricals_x_classes": f"{w['cats']}x{w['classes']}",
+                "enc_channels": [8, 16, 32], "dec_channels": [32, 16, 1], "residual_blocks": 3, "activation": "ELU",
+                "optimizer": "AdamW lr 1e-3 + clip 10 (fused HIP)", "params": flat.numel,
+            },
+            "loss": float(scalars["loss"]),
+            "roofline": {
+                "kernel": name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                "avg_ms": dur, "algorithmic_bytes_per_launch": algo,
+                "note": "latency-bound serial scan (T dependent steps, weights re-streamed from L2); see DESIGN.md section 4",
+                "kernel_ms": kernel_ms,
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

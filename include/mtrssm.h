@@ -1,0 +1,341 @@
+/* mtrssm.h -- C-ABI of libmtrssm_hip.so: MI355X (gfx950) kernels for the MoPoE-M(MT)RSSM
+ * sequential-rollout train step.
+ *
+ * The reference (Mamo1031/Multimodal-MTRSSM) is pure Python and has no FFI of its own; its boundary
+ * for this path is the Python class API.  This header is the build-defined C
+ * boundary underneath the drop-in Python classes of `multimodal_mtrssm_amd/`: every entry point
+ * names the reference code it replaces.
+ *
+ * Conventions
+ *   - plain C: pointers and sizes only, no torch / HIP types.  `stream` is a hipStream_t passed as
+ *     void* (NULL = the null stream).  Kernels are launched asynchronously on it.
+ *   - all device buffers are caller-owned, fp32, row-major contiguous; sequence tensors are
+ *     [B, T, dim] (a row's T steps contiguous).  The library never allocates, frees or keeps
+ *     global mutable state and is re-entrant across streams.
+ *   - return 0 on success, a negative MTRSSM_E* code otherwise; mtrssm_last_error() gives the
+ *     thread-local message.  There is NO CPU fallback.
+ *   - S = K*C flat stochastic size, K = category_size (number of categoricals), C = class_size.
+ *   - a matrix-vector product with a WIDE output streams its matrix reduction-major (row r of the
+ *     buffer = all outputs for input r; threads own outputs, loads coalesce); one with a NARROW
+ *     output (the S-wide heads) streams it output-major (one wave per output row).  Hence the
+ *     forward scan takes "_t" (= W^T, [in][out]) copies of the wide layers and the PyTorch
+ *     [out][in] layout of the narrow ones, and the backward scan the opposite.
+ */
+#ifndef MTRSSM_H
+#define MTRSSM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MTRSSM_VERSION 100 /* 0.1.0 */
+
+#define MTRSSM_OK 0
+#define MTRSSM_EINVAL (-1)  /* bad dims / null pointer */
+#define MTRSSM_ELAUNCH (-2) /* HIP launch error */
+#define MTRSSM_ELDS (-3)    /* dims do not fit the 160 KiB LDS of a CU in this kernel regime */
+
+/* activation ids (torch.nn names the reference YAML uses: Identity, ReLU, ELU, Tanh) */
+#define MTRSSM_ACT_IDENTITY 0
+#define MTRSSM_ACT_RELU 1
+#define MTRSSM_ACT_ELU 2
+#define MTRSSM_ACT_TANH 3
+
+int mtrssm_version(void);
+const char* mtrssm_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * MoPoE-MRSSM scan.  Replaces the T loop of MoPoE_MRSSM.rollout_representation
+ * (mrssm/mopoe_mrssm/core.py:221-256): Transition.forward (networks.py:151-173), the two posterior
+ * heads (core.py:62-84), flat log-softmax + PoE + MoE (core.py:241-243, 112-163), State sampling
+ * (state.py:17) and the per-step KL term of BaseRSSM.shared_step (core.py:212-216).
+ * With post == 0 it is BaseRSSM.rollout_transition (core.py:170-185): prior-only.
+ *
+ * Contractions that do not depend on the recurrence are hoisted out of the loop by the caller:
+ *   xa[b,t,:] = W1[:, :A] a[b,t] + b1          (action part of action_state_projector.0)
+ *   pa[b,t,:] = Wa1[:, D:] ea[b,t] + ba1       (embedding part of audio rnn_to_post_projector.0)
+ *   pv[b,t,:] = Wv1[:, D:] ev[b,t] + bv1
+ * ------------------------------------------------------------------------------------------ */
+typedef struct MtrssmMrssmDims {
+  int32_t B, T;          /* sequences, timesteps */
+  int32_t D, H;          /* deterministic size, hidden (num_cells) */
+  int32_t K, C;          /* categoricals, classes */
+  int32_t act;           /* MTRSSM_ACT_* of the three MLPs */
+  int32_t post;          /* 1: posterior rollout; 0: prior-only rollout */
+  float kl_w_post;       /* d(loss)/d(KL) share sent to the posterior (1-alpha with balancing, else 1) */
+  float kl_w_prior;      /* share sent to the prior (alpha with balancing, else 1) */
+  int32_t rows_per_block; /* 0 = library default */
+  int32_t threads;        /* 0 = library default */
+} MtrssmMrssmDims;
+
+typedef struct MtrssmMrssmFwdWeights {
+  const float* w1s_t;  /* [S][H]   action_state_projector.0.weight[:, A:]^T */
+  const float* w2_t;   /* [H][H]   action_state_projector.2.weight^T */
+  const float* b2;     /* [H] */
+  const float* wih_t;  /* [H][3D]  rnn_cell.weight_ih^T (gate order r,z,n) */
+  const float* bih;    /* [3D] */
+  const float* whh_t;  /* [D][3D]  rnn_cell.weight_hh^T */
+  const float* bhh;    /* [3D] */
+  const float* wh1_t;  /* [D][3H]  [prior.0.weight ; audio post.0.weight[:, :D] ; vision post.0.weight[:, :D]]^T
+                                   (prior-only: [D][H]) */
+  const float* b3;     /* [H]      rnn_to_prior_projector.0.bias */
+  const float* w4;     /* [S][H]   rnn_to_prior_projector.2.weight (PyTorch layout: narrow output, one wave per row) */
+  const float* b4;     /* [S] */
+  const float* wa2;    /* [S][H]   audio rnn_to_post_projector.2.weight */
+  const float* ba2;    /* [S] */
+  const float* wv2;    /* [S][H]   vision rnn_to_post_projector.2.weight */
+  const float* bv2;    /* [S] */
+} MtrssmMrssmFwdWeights;
+
+typedef struct MtrssmMrssmFwdIO {
+  /* inputs */
+  const float* xa;      /* [B,T,H] */
+  const float* pa;      /* [B,T,H]  (post only) */
+  const float* pv;      /* [B,T,H]  (post only) */
+  const float* deter0;  /* [B,D] */
+  const float* stoch0;  /* [B,S] */
+  const float* u_post;  /* [B,T,K] uniforms for the posterior sample (post only) */
+  const float* u_prior; /* [B,T,K] uniforms for the prior sample (NULL: not sampled when post=1) */
+  /* outputs */
+  float* deter;         /* [B,T,D] */
+  float* prior_logits;  /* [B,T,S] raw prior logits */
+  float* prior_stoch;   /* [B,T,S] one-hot prior sample (NULL allowed when post=1) */
+  float* post_logits;   /* [B,T,S] mixed log-probs (post only) */
+  float* post_stoch;    /* [B,T,S] one-hot posterior sample (post only) */
+  float* kl;            /* [B,T]   sum_K KL(q_k || p_k) (post only, NULL allowed) */
+  /* activations saved for the backward scan (all NULL = inference) */
+  float* sv_h1;         /* [B,T,H]  act(MLP1 layer 0) */
+  float* sv_h2;         /* [B,T,H]  MLP1 output */
+  float* sv_gates;      /* [B,T,4D] r, z, n, (W_hn h + b_hn) */
+  float* sv_heads;      /* [B,T,3H] act of prior / audio / vision head layer 0 */
+  float* sv_la;         /* [B,T,S]  audio logits */
+  float* sv_lv;         /* [B,T,S]  vision logits */
+} MtrssmMrssmFwdIO;
+
+int mtrssm_mrssm_rollout_fwd(const MtrssmMrssmDims* dims, const MtrssmMrssmFwdWeights* w,
+                             const MtrssmMrssmFwdIO* io, void* stream);
+
+typedef struct MtrssmMrssmBwdWeights {
+  const float* w1s_t; /* [S][H]  action_state_projector.0.weight[:, A:]^T (same buffer as the forward's) */
+  const float* w2;   /* [H][H] */
+  const float* wih;  /* [3D][H] */
+  const float* whh;  /* [3D][D] */
+  const float* wh1;  /* [3H][D]  [prior.0.weight ; audio post.0.weight[:, :D] ; vision post.0.weight[:, :D]] */
+  const float* w4;   /* [S][H] */
+  const float* wa2;  /* [S][H] */
+  const float* wv2;  /* [S][H] */
+} MtrssmMrssmBwdWeights;
+
+typedef struct MtrssmMrssmBwdIO {
+  /* forward inputs / outputs / saved activations */
+  const float* deter0;       /* [B,D] */
+  const float* deter;        /* [B,T,D] */
+  const float* prior_logits; /* [B,T,S] */
+  const float* post_logits;  /* [B,T,S] */
+  const float* sv_h1;
+  const float* sv_h2;
+  const float* sv_gates;
+  const float* sv_heads;
+  const float* sv_la;
+  const float* sv_lv;
+  /* incoming gradients (any may be NULL = zero) */
+  const float* g_deter;        /* [B,T,D] */
+  const float* g_post_stoch;   /* [B,T,S] straight-through */
+  const float* g_prior_stoch;  /* [B,T,S] straight-through */
+  const float* g_post_logits;  /* [B,T,S] */
+  const float* g_prior_logits; /* [B,T,S] */
+  const float* g_kl;           /* [B,T] */
+  /* outgoing gradients */
+  float* g_deter0;  /* [B,D] */
+  float* g_stoch0;  /* [B,S] */
+  float* d_z1;      /* [B,T,H]  = d xa        (pre-activation of MLP1 layer 0) */
+  float* d_h2;      /* [B,T,H]  grad at MLP1 output */
+  float* d_gi;      /* [B,T,3D] */
+  float* d_gh;      /* [B,T,3D] */
+  float* d_zh;      /* [B,T,3H] pre-activation grads of prior / audio / vision head layer 0 (audio = d pa, vision = d pv) */
+  float* d_lp;      /* [B,T,S]  grad at prior logits */
+  float* d_la;      /* [B,T,S]  grad at audio logits */
+  float* d_lv;      /* [B,T,S]  grad at vision logits */
+} MtrssmMrssmBwdIO;
+
+/* Reverse-time scan (BPTT).  Weight gradients are NOT accumulated inside the serial loop: the
+ * kernel emits the per-step pre-activation gradients above and the caller forms every dW as one
+ * batched [out x B*T] . [B*T x in] library GEMM (rocBLAS), which is where MFMA belongs. */
+int mtrssm_mrssm_rollout_bwd(const MtrssmMrssmDims* dims, const MtrssmMrssmBwdWeights* w,
+                             const MtrssmMrssmBwdIO* io, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * MoPoE-MMTRSSM scan (two-timescale MTState variant).  Replaces the T loop of
+ * MoPoE_MMTRSSM.rollout_representation (mmtrssm/mopoe_mmtrssm/core.py:405-490): MTRNN (:59-60),
+ * _compute_lower_prior (:263-287), the two posterior heads (:241-261), inline MoPoE (:436-453),
+ * _compute_higher_prior_posterior (:289-319), MTState sampling (mmtrssm/state.py:47-49) and the
+ * per-step kl / kl_h terms of shared_step (:586-600).  post == 0: rollout_transition (:496-544).
+ * Hoisted by the caller:  xl[b,t,:] = Wx_l[:, :A] a[b,t] + bx_l + bd_l ; pa / pv as above.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct MtrssmMmtrssmDims {
+  int32_t B, T;
+  int32_t LD, HD;        /* lower / higher deterministic sizes */
+  int32_t H;             /* num_cells of l_prior, h_prior, h_posterior and the posterior heads */
+  int32_t KL, CL;        /* lower categoricals, classes  (ls = KL*CL) */
+  int32_t KH, CH;        /* higher categoricals, classes (hs = KH*CH) */
+  int32_t act;
+  int32_t post;
+  float tau_l, tau_h;    /* MTRNN time constants (> 1) */
+  float keep_l, keep_h;  /* (float)(1.0 - 1.0/tau), computed in double by the caller (core.py:59) */
+  float kl_w_post, kl_w_prior;
+  int32_t rows_per_block;
+  int32_t threads;
+} MtrssmMmtrssmDims;
+
+typedef struct MtrssmMmtrssmFwdWeights {
+  const float* wxl_s_t;  /* [LS+HS][LD]  l_rnn._input2h.weight[:, A:]^T */
+  const float* wdl_t;    /* [LD][LD]     l_rnn._d2h.weight^T (bias folded into xl) */
+  const float* wxh_t;    /* [HS][HD]     h_rnn._input2h.weight^T */
+  const float* wdh_t;    /* [HD][HD]     h_rnn._d2h.weight^T */
+  const float* bh;       /* [HD]         h_rnn._input2h.bias + h_rnn._d2h.bias */
+  const float* wl1_t;    /* [LD][4H]     [l_prior.0 ; audio post.0[:, :LD] ; vision post.0[:, :LD] ; h_posterior.0[:, :LD]]^T
+                                         (prior-only: [LD][H]) */
+  const float* bl1;      /* [H]          l_prior.0.bias */
+  const float* wh1_t;    /* [HD][2H]     [h_prior.0 ; h_posterior.0[:, LD:]]^T (prior-only: [HD][H]) */
+  const float* bh1;      /* [2H]         [h_prior.0.bias ; h_posterior.0.bias] */
+  const float* wlp2;     /* [LS][H]  l_prior.2.weight (PyTorch layout) */
+  const float* blp2;     /* [LS] */
+  const float* wa2;      /* [LS][H]  audio rnn_to_post_projector.2.weight */
+  const float* ba2;
+  const float* wv2;      /* [LS][H] */
+  const float* bv2;
+  const float* whp2;     /* [HS][H]  h_prior.2.weight */
+  const float* bhp2;
+  const float* whq2;     /* [HS][H]  h_posterior.2.weight */
+  const float* bhq2;
+} MtrssmMmtrssmFwdWeights;
+
+typedef struct MtrssmMmtrssmFwdIO {
+  const float* xl;        /* [B,T,LD] */
+  const float* pa;        /* [B,T,H] (post only) */
+  const float* pv;        /* [B,T,H] (post only) */
+  const float* deter_l0;  /* [B,LD] */
+  const float* deter_h0;  /* [B,HD] */
+  const float* hidden_l0; /* [B,LD] */
+  const float* hidden_h0; /* [B,HD] */
+  const float* stoch_l0;  /* [B,LS] */
+  const float* stoch_h0;  /* [B,HS] */
+  const float* u_post_l;  /* [B,T,KL] */
+  const float* u_post_h;  /* [B,T,KH] */
+  const float* u_prior_l; /* [B,T,KL] (NULL allowed when post=1) */
+  const float* u_prior_h; /* [B,T,KH] */
+  float* deter_l;         /* [B,T,LD] */
+  float* deter_h;         /* [B,T,HD] */
+  float* hidden_l;        /* [B,T,LD] */
+  float* hidden_h;        /* [B,T,HD] */
+  float* prior_logits_l;  /* [B,T,LS] */
+  float* prior_logits_h;  /* [B,T,HS] */
+  float* prior_stoch_l;   /* [B,T,LS] (NULL allowed when post=1) */
+  float* prior_stoch_h;   /* [B,T,HS] */
+  float* post_logits_l;   /* [B,T,LS] mixed log-probs */
+  float* post_logits_h;   /* [B,T,HS] raw h_posterior logits */
+  float* post_stoch_l;    /* [B,T,LS] */
+  float* post_stoch_h;    /* [B,T,HS] */
+  float* kl_l;            /* [B,T] */
+  float* kl_h;            /* [B,T] */
+  float* sv_l1;           /* [B,T,4H] act of l_prior.0 / audio post.0 / vision post.0 / h_posterior.0 */
+  float* sv_h1;           /* [B,T,H]  act of h_prior layer 0 */
+  float* sv_la;           /* [B,T,LS] */
+  float* sv_lv;           /* [B,T,LS] */
+} MtrssmMmtrssmFwdIO;
+
+int mtrssm_mmtrssm_rollout_fwd(const MtrssmMmtrssmDims* dims, const MtrssmMmtrssmFwdWeights* w,
+                               const MtrssmMmtrssmFwdIO* io, void* stream);
+
+typedef struct MtrssmMmtrssmBwdWeights {
+  const float* wxl_s_t; /* [LS+HS][LD] (the forward's buffer: narrow output) */
+  const float* wdl;    /* [LD][LD] */
+  const float* wxh_t;  /* [HS][HD]    (the forward's buffer: narrow output) */
+  const float* wdh;    /* [HD][HD] */
+  const float* wl1;    /* [4H][LD] */
+  const float* wh1;    /* [2H][HD] */
+  const float* wlp2;   /* [LS][H] */
+  const float* wa2;    /* [LS][H] */
+  const float* wv2;    /* [LS][H] */
+  const float* whp2;   /* [HS][H] */
+  const float* whq2;   /* [HS][H] */
+} MtrssmMmtrssmBwdWeights;
+
+typedef struct MtrssmMmtrssmBwdIO {
+  const float* deter_l0;
+  const float* deter_h0;
+  const float* deter_l;
+  const float* deter_h;
+  const float* prior_logits_l;
+  const float* prior_logits_h;
+  const float* post_logits_l;
+  const float* post_logits_h;
+  const float* sv_l1;
+  const float* sv_h1;
+  const float* sv_la;
+  const float* sv_lv;
+  /* incoming gradients (NULL = zero) */
+  const float* g_deter_l;
+  const float* g_deter_h;
+  const float* g_hidden_l;
+  const float* g_hidden_h;
+  const float* g_post_stoch_l;
+  const float* g_post_stoch_h;
+  const float* g_prior_stoch_l;
+  const float* g_prior_stoch_h;
+  const float* g_post_logits_l;
+  const float* g_post_logits_h;
+  const float* g_prior_logits_l;
+  const float* g_prior_logits_h;
+  const float* g_kl_l;
+  const float* g_kl_h;
+  /* outgoing gradients */
+  float* g_deter_l0;
+  float* g_deter_h0;
+  float* g_hidden_l0;
+  float* g_hidden_h0;
+  float* g_stoch_l0;
+  float* g_stoch_h0;
+  float* d_ul;    /* [B,T,LD] grad at the lower MTRNN pre-activation sum (already / tau_l) = d xl */
+  float* d_uh;    /* [B,T,HD] grad at the higher MTRNN pre-activation sum (already / tau_h) */
+  float* d_zl1;   /* [B,T,4H] pre-activation grads: l_prior.0, audio.0 (= d pa), vision.0 (= d pv), h_posterior.0 */
+  float* d_zh1;   /* [B,T,H]  pre-activation grad of h_prior.0 */
+  float* d_lpl;   /* [B,T,LS] grad at lower prior logits */
+  float* d_la;    /* [B,T,LS] */
+  float* d_lv;    /* [B,T,LS] */
+  float* d_lph;   /* [B,T,HS] grad at higher prior logits */
+  float* d_lqh;   /* [B,T,HS] grad at higher posterior logits */
+} MtrssmMmtrssmBwdIO;
+
+int mtrssm_mmtrssm_rollout_bwd(const MtrssmMmtrssmDims* dims, const MtrssmMmtrssmBwdWeights* w,
+                               const MtrssmMmtrssmBwdIO* io, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Gaussian NLL with unit scale, fused reduction.  Replaces objective.likelihood
+ * (objective.py:7-23) as used by compute_reconstruction_loss (mrssm/mopoe_mrssm/core.py:279-308):
+ *   nll = mean_n sum_e [ 0.5 (target - pred)^2 + 0.5 log(2 pi) ],  n = B*T frames, e = C*H*W.
+ * fwd writes partial sums to `partials` (caller-zeroed, >= 1024 floats) and the scalar to `out`;
+ * bwd writes d pred = g_out * (pred - target) / n.
+ * ------------------------------------------------------------------------------------------ */
+int mtrssm_gaussian_nll_fwd(const float* pred, const float* target, int64_t frames, int64_t event,
+                            float* out, void* stream);
+int mtrssm_gaussian_nll_bwd(const float* pred, const float* target, const float* g_out,
+                            int64_t frames, int64_t event, float* g_pred, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused AdamW over one flat fp32 parameter buffer, with global-norm gradient clipping
+ * (yaml: torch.optim.AdamW lr 1e-3; trainer.gradient_clip_val 10 -- default.yaml:103-107,119).
+ * sumsq: device scalar holding sum(grad^2) (mtrssm_sumsq writes it); clip <= 0 disables clipping.
+ * ------------------------------------------------------------------------------------------ */
+int mtrssm_sumsq(const float* x, int64_t n, float* out, void* stream);
+int mtrssm_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                      const float* sumsq, float clip_norm, float grad_scale, float lr, float beta1,
+                      float beta2, float eps, float weight_decay, int32_t step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MTRSSM_H */

@@ -1,0 +1,164 @@
+"""Conv encoder / decoder (the ``cnn.Encoder`` / ``cnn.Decoder`` the reference YAMLs instantiate).
+
+The reference takes these from the un-vendored ``cnn`` 3.1.1 package; only the YAML field names are
+in the reference tree (``mrssm/mopoe_mrssm/configs/default.yaml:31-92``), so the architecture is
+build-defined ("parity unpinned") and identical to ``oracle/ref_cnn.py``:
+
+Encoder: [+2 coordinate channels] -> (Conv k,s,p -> act) x n -> Conv3x3 to ``residual_output_size``
+         -> n_res x {x + Conv1x1(act(Conv3x3(act x)))} -> act -> flatten -> Linear(s) -> out_act
+Decoder: Linear -> act -> Linear -> reshape ``conv_in_shape`` -> n_res x {residual block} -> act
+         -> (ConvTranspose k,s,p -> act) x (n-1) -> ConvTranspose -> out_act
+
+Both take arbitrary leading batch dims (``[B,T,C,H,W]`` and ``[B,C,H,W]`` are both used upstream,
+``mrssm/mopoe_mrssm/core.py:179-180,215-216,272-273``).  Frames are folded to one ``[B*T, C, H, W]`` batch so
+every layer is a single dense launch over all B*T frames.
+
+Round-1 status: the layers below run through MIOpen / rocBLAS via torch ops (dense library
+convolutions / GEMMs); hand-written gfx950 conv kernels with a fused tanh + Gaussian-NLL epilogue are
+the next item.
+"""
+
+from __future__ import annotations
+
+from typing import Any
+
+import torch
+from torch import Tensor, nn
+
+
+def _act(name: str) -> nn.Module:
+    return getattr(nn, name)()
+
+
+def _cfg(config: Any) -> dict[str, Any]:  # noqa: ANN401
+    return dict(config) if isinstance(config, dict) else dict(vars(config))
+
+
+class ResidualBlock(nn.Module):
+    def __init__(self, channels: int, intermediate: int, activation_name: str) -> None:
+        super().__init__()
+        self.conv3 = nn.Conv2d(channels, intermediate, 3, 1, 1)
+        self.conv1 = nn.Conv2d(intermediate, channels, 1, 1, 0)
+        self.act = _act(activation_name)
+
+    def forward(self, x: Tensor) -> Tensor:
+        return x + self.conv1(self.act(self.conv3(self.act(x))))
+
+
+class Encoder(nn.Module):
+    """``Encoder(config)``; optional extra key ``input_shape: [C, H, W]`` builds the Linear eagerly."""
+
+    def __init__(self, config: Any) -> None:  # noqa: ANN401
+        super().__init__()
+        self.cfg = _cfg(config)
+        self.coord_conv = bool(self.cfg.get("coord_conv", False))
+        self.act = _act(self.cfg["activation_name"])
+        self.out_act = _act(self.cfg.get("out_activation_name", "Identity"))
+        self.convs = nn.ModuleList()
+        self.res_in: nn.Module | None = None
+        self.res = nn.ModuleList()
+        self.linears = nn.ModuleList()
+        self.input_shape: tuple[int, int, int] | None = None
+        self._coords: Tensor | None = None
+        if self.cfg.get("input_shape") is not None:
+            self.materialize(tuple(self.cfg["input_shape"]))
+
+    def materialize(self, input_shape: tuple[int, ...]) -> None:
+        cfg = self.cfg
+        c, h, w = (int(v) for v in input_shape)
+        self.input_shape = (c, h, w)
+        cin = c + (2 if self.coord_conv else 0)
+        for ch, k, s, p in zip(cfg["channels"], cfg["kernel_sizes"], cfg["strides"], cfg["paddings"], strict=True):
+            self.convs.append(nn.Conv2d(cin, ch, k, s, p))
+            h, w, cin = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1, ch
+        if cfg.get("num_residual_blocks", 0) > 0:
+            rout = cfg["residual_output_size"]
+            self.res_in = nn.Conv2d(cin, rout, 3, 1, 1)
+            for _ in range(cfg["num_residual_blocks"]):
+                self.res.append(ResidualBlock(rout, cfg["residual_intermediate_size"], cfg["activation_name"]))
+            cin = rout
+        width = cin * h * w
+        for out in cfg["linear_sizes"]:
+            self.linears.append(nn.Linear(width, out))
+            width = out
+
+    def _coord_channels(self, x: Tensor) -> Tensor:
+        h, w = x.shape[-2:]
+        if self._coords is None or self._coords.shape[-2:] != (h, w) or self._coords.device != x.device:
+            yy = torch.linspace(-1.0, 1.0, h, dtype=x.dtype, device=x.device)
+            xx = torch.linspace(-1.0, 1.0, w, dtype=x.dtype, device=x.device)
+            self._coords = torch.stack([yy[:, None].expand(h, w), xx[None, :].expand(h, w)], dim=0)
+        return self._coords
+
+    def forward(self, x: Tensor) -> Tensor:
+        if len(self.linears) == 0:
+            self.materialize(tuple(x.shape[-3:]))
+            self.to(x.device)
+        lead = x.shape[:-3]
+        x = x.reshape(-1, *x.shape[-3:])
+        if self.coord_conv:
+            x = torch.cat([x, self._coord_channels(x).unsqueeze(0).expand(x.shape[0], -1, -1, -1)], dim=1)
+        for conv in self.convs:
+            x = self.act(conv(x))
+        if self.res_in is not None:
+            x = self.res_in(x)
+            for blk in self.res:
+                x = blk(x)
+            x = self.act(x)
+        x = x.flatten(start_dim=1)
+        for i, lin in enumerate(self.linears):
+            x = lin(x)
+            if i + 1 < len(self.linears):
+                x = self.act(x)
+        return self.out_act(x).reshape(*lead, -1)
+
+
+class Decoder(nn.Module):
+    """``Decoder(config)``; optional extra key ``in_features`` builds the first Linear eagerly."""
+
+    def __init__(self, config: Any) -> None:  # noqa: ANN401
+        super().__init__()
+        cfg = self.cfg = _cfg(config)
+        self.act = _act(cfg["activation_name"])
+        self.out_act = _act(cfg.get("out_activation_name", "Identity"))
+        self.conv_in_shape = tuple(int(v) for v in cfg["conv_in_shape"])
+        self.linears = nn.ModuleList()
+        self.res = nn.ModuleList()
+        self.deconvs = nn.ModuleList()
+        cin = self.conv_in_shape[0]
+        for _ in range(cfg.get("num_residual_blocks", 0)):
+            self.res.append(ResidualBlock(cin, cfg["residual_intermediate_size"], cfg["activation_name"]))
+        n = len(cfg["channels"])
+        ops = cfg.get("output_paddings", [0] * n)
+        for ch, k, s, p, op in zip(cfg["channels"], cfg["kernel_sizes"], cfg["strides"], cfg["paddings"], ops, strict=True):
+            self.deconvs.append(nn.ConvTranspose2d(cin, ch, k, s, p, op))
+            cin = ch
+        if cfg.get("in_features") is not None:
+            self.materialize(int(cfg["in_features"]))
+
+    def materialize(self, in_features: int) -> None:
+        width = in_features
+        for out in self.cfg["linear_sizes"]:
+            self.linears.append(nn.Linear(width, out))
+            width = out
+        self.in_features = in_features
+
+    def forward(self, f: Tensor) -> Tensor:
+        if len(self.linears) == 0:
+            self.materialize(f.shape[-1])
+            self.to(f.device)
+        lead = f.shape[:-1]
+        x = f.reshape(-1, f.shape[-1])
+        for i, lin in enumerate(self.linears):
+            x = lin(x)
+            if i + 1 < len(self.linears):
+                x = self.act(x)
+        x = x.reshape(-1, *self.conv_in_shape)
+        if len(self.res) > 0:
+            for blk in self.res:
+                x = blk(x)
+            x = self.act(x)
+        for i, dc in enumerate(self.deconvs):
+            x = dc(x)
+            x = self.act(x) if i + 1 < len(self.deconvs) else self.out_act(x)
+        return x.reshape(*lead, *x.shape[-3:])

@@ -1,0 +1,61 @@
+// extern "C" boundary of libmtrssm_hip.so (declared in include/mtrssm.h).
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "scan_common.h"
+
+namespace mtrssm {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int mrssm_fwd_launch(const MtrssmMrssmDims*, const MtrssmMrssmFwdWeights*, const MtrssmMrssmFwdIO*, hipStream_t);
+int mrssm_bwd_launch(const MtrssmMrssmDims*, const MtrssmMrssmBwdWeights*, const MtrssmMrssmBwdIO*, hipStream_t);
+int mmtrssm_fwd_launch(const MtrssmMmtrssmDims*, const MtrssmMmtrssmFwdWeights*, const MtrssmMmtrssmFwdIO*, hipStream_t);
+int mmtrssm_bwd_launch(const MtrssmMmtrssmDims*, const MtrssmMmtrssmBwdWeights*, const MtrssmMmtrssmBwdIO*, hipStream_t);
+int nll_fwd_launch(const float*, const float*, int64_t, int64_t, float*, hipStream_t);
+int nll_bwd_launch(const float*, const float*, const float*, int64_t, int64_t, float*, hipStream_t);
+int sumsq_launch(const float*, int64_t, float*, hipStream_t);
+int adamw_launch(float*, const float*, float*, float*, int64_t, const float*, float, float, float, float, float, float, float, int, hipStream_t);
+
+}  // namespace mtrssm
+
+using namespace mtrssm;
+#define MTRSSM_API extern "C" __attribute__((visibility("default")))
+
+MTRSSM_API int mtrssm_version(void) { return MTRSSM_VERSION; }
+MTRSSM_API const char* mtrssm_last_error(void) { return g_err; }
+
+MTRSSM_API int mtrssm_mrssm_rollout_fwd(const MtrssmMrssmDims* d, const MtrssmMrssmFwdWeights* w, const MtrssmMrssmFwdIO* io, void* stream) {
+  return mrssm_fwd_launch(d, w, io, static_cast<hipStream_t>(stream));
+}
+MTRSSM_API int mtrssm_mrssm_rollout_bwd(const MtrssmMrssmDims* d, const MtrssmMrssmBwdWeights* w, const MtrssmMrssmBwdIO* io, void* stream) {
+  return mrssm_bwd_launch(d, w, io, static_cast<hipStream_t>(stream));
+}
+MTRSSM_API int mtrssm_mmtrssm_rollout_fwd(const MtrssmMmtrssmDims* d, const MtrssmMmtrssmFwdWeights* w, const MtrssmMmtrssmFwdIO* io, void* stream) {
+  return mmtrssm_fwd_launch(d, w, io, static_cast<hipStream_t>(stream));
+}
+MTRSSM_API int mtrssm_mmtrssm_rollout_bwd(const MtrssmMmtrssmDims* d, const MtrssmMmtrssmBwdWeights* w, const MtrssmMmtrssmBwdIO* io, void* stream) {
+  return mmtrssm_bwd_launch(d, w, io, static_cast<hipStream_t>(stream));
+}
+MTRSSM_API int mtrssm_gaussian_nll_fwd(const float* pred, const float* target, int64_t frames, int64_t event, float* out, void* stream) {
+  return nll_fwd_launch(pred, target, frames, event, out, static_cast<hipStream_t>(stream));
+}
+MTRSSM_API int mtrssm_gaussian_nll_bwd(const float* pred, const float* target, const float* g_out, int64_t frames, int64_t event, float* g_pred, void* stream) {
+  return nll_bwd_launch(pred, target, g_out, frames, event, g_pred, static_cast<hipStream_t>(stream));
+}
+MTRSSM_API int mtrssm_sumsq(const float* x, int64_t n, float* out, void* stream) {
+  return sumsq_launch(x, n, out, static_cast<hipStream_t>(stream));
+}
+MTRSSM_API int mtrssm_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const float* sumsq,
+                                 float clip_norm, float grad_scale, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                 int32_t step, void* stream) {
+  return adamw_launch(param, grad, exp_avg, exp_avg_sq, n, sumsq, clip_norm, grad_scale, lr, beta1, beta2, eps, weight_decay, step,
+                      static_cast<hipStream_t>(stream));
+}

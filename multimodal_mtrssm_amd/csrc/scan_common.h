@@ -1,0 +1,273 @@
+// Device helpers shared by the MRSSM / MMTRSSM scan kernels (gfx950, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mtrssm.h"
+
+namespace mtrssm {
+
+constexpr int kWave = 64;
+constexpr float kLogThird = -1.0986122886681098f;  // log(1/3), mrssm/mopoe_mrssm/core.py:141-142
+
+__device__ __forceinline__ float act_fwd(float z, int act) {
+  switch (act) {
+    case MTRSSM_ACT_RELU: return z > 0.f ? z : 0.f;
+    case MTRSSM_ACT_ELU: return z > 0.f ? z : expm1f(z);
+    case MTRSSM_ACT_TANH: return tanhf(z);
+    default: return z;
+  }
+}
+
+// derivative of the activation expressed through its OUTPUT h = act(z)
+__device__ __forceinline__ float act_grad_from_out(float h, int act) {
+  switch (act) {
+    case MTRSSM_ACT_RELU: return h > 0.f ? 1.f : 0.f;
+    case MTRSSM_ACT_ELU: return h > 0.f ? 1.f : h + 1.f;
+    case MTRSSM_ACT_TANH: return 1.f - h * h;
+    default: return 1.f;
+  }
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, kWave));
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------
+// Row-tile GEMV, thread-per-output ("wide O"):
+//   acc[rb] = init(rb, o) + sum_r M[r*ld + o] * vin[rb][r];   fin(rb, o, acc[rb])
+// M is row-major [R][ld] in global memory (streamed from L2); consecutive threads read consecutive
+// o -> coalesced 256-B wave loads.  vin lives in LDS (broadcast reads).  The sum is a sequential
+// fp32 fma chain over r (deterministic).
+// ---------------------------------------------------------------------------------------
+template <int RB, typename Init, typename Fin>
+__device__ __forceinline__ void gemv_t(const float* __restrict__ M, int ld, int R, int O,
+                                       const float* vin, int vin_stride, Init init, Fin fin) {
+  for (int o = threadIdx.x; o < O; o += blockDim.x) {
+    float acc[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) acc[rb] = init(rb, o);
+    const float* m = M + o;
+    int r = 0;
+    for (; r + 8 <= R; r += 8) {
+      float w[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) w[i] = m[(size_t)(r + i) * ld];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) acc[rb] = fmaf(w[i], vin[rb * vin_stride + r + i], acc[rb]);
+      }
+    }
+    for (; r < R; ++r) {
+      const float w = m[(size_t)r * ld];
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) acc[rb] = fmaf(w, vin[rb * vin_stride + r], acc[rb]);
+    }
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) fin(rb, o, acc[rb]);
+  }
+}
+
+// Wave-per-output dot products ("narrow O"): acc[rb] = sum_r wrow[r] * vin[rb][r], all lanes return the sum.
+// wrow is one contiguous weight row in global memory; lanes stride r (coalesced), butterfly reduce.
+template <int RB>
+__device__ __forceinline__ void wave_dot(const float* __restrict__ wrow, int R, const float* vin,
+                                         int vin_stride, int lane, float (&acc)[RB]) {
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) acc[rb] = 0.f;
+  for (int r = lane; r < R; r += kWave) {
+    const float w = wrow[r];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) acc[rb] = fmaf(w, vin[rb * vin_stride + r], acc[rb]);
+  }
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) acc[rb] = wave_sum(acc[rb]);
+}
+
+// ---------------------------------------------------------------------------------------
+// Categorical helpers, executed by ONE wave for one row.  Logits are flat [K*C] in LDS.
+// ---------------------------------------------------------------------------------------
+
+// flat log-sum-exp pieces over S entries: returns (max, log(sum exp(x - max))), torch.log_softmax form
+__device__ __forceinline__ void wave_flat_lse(const float* x, int S, int lane, float& mx, float& lsum) {
+  float m = -INFINITY;
+  for (int s = lane; s < S; s += kWave) m = fmaxf(m, x[s]);
+  m = wave_max(m);
+  float acc = 0.f;
+  for (int s = lane; s < S; s += kWave) acc += expf(x[s] - m);
+  acc = wave_sum(acc);
+  mx = m;
+  lsum = logf(acc);
+}
+
+// MoPoE mix of two experts' flat logits (core.py:241-243 + 112-163) -> mixed[S] (LDS)
+__device__ __forceinline__ void wave_mopoe_mix(const float* la, const float* lv, float* mixed, int S, int lane) {
+  float ma, lsa, mv, lsv;
+  wave_flat_lse(la, S, lane, ma, lsa);
+  wave_flat_lse(lv, S, lane, mv, lsv);
+  for (int s = lane; s < S; s += kWave) {
+    const float a = (la[s] - ma) - lsa;
+    const float v = (lv[s] - mv) - lsv;
+    const float f = a + v;
+    const float x1 = kLogThird + a, x2 = kLogThird + v, x3 = kLogThird + f;
+    const float m = fmaxf(x1, fmaxf(x2, x3));
+    mixed[s] = logf(expf(x1 - m) + expf(x2 - m) + expf(x3 - m)) + m;
+  }
+}
+
+// Per-categorical softmax statistics for category k: max and log-sum
+__device__ __forceinline__ void cat_stats(const float* x, int C, float& mx, float& sum) {
+  float m = x[0];
+  for (int c = 1; c < C; ++c) m = fmaxf(m, x[c]);
+  float s = 0.f;
+  for (int c = 0; c < C; ++c) s += expf(x[c] - m);
+  mx = m;
+  sum = s;
+}
+
+// inverse-CDF index: number of c in [0, C-2] whose inclusive cumulative probability is <= u
+__device__ __forceinline__ int cat_sample(const float* x, int C, float mx, float sum, float u) {
+  float acc = 0.f;
+  int idx = 0;
+  for (int c = 0; c + 1 < C; ++c) {
+    acc += expf(x[c] - mx) / sum;
+    idx += (acc <= u) ? 1 : 0;
+  }
+  return idx;
+}
+
+
+// ---------------------------------------------------------------------------------------
+// Forward categorical block for one row, executed by one wave (lane k owns categorical k).
+//   POST: q = softmax_k(q_logits), p = softmax_k(p_logits); returns this lane's partial of
+//         sum_k KL(q_k || p_k); posterior sample -> s_lds (+ post_stoch_g); optional prior sample.
+//   !POST: prior sample -> s_lds (+ prior_stoch_g); returns 0.
+// Follows state.py:17 (sample on construction) and core.py:212-216 (KL over independent(1)).
+// ---------------------------------------------------------------------------------------
+template <bool POST>
+__device__ __forceinline__ float cat_block_fwd(const float* q_logits, const float* p_logits, int K, int C, int lane,
+                                               const float* u_post, const float* u_prior, float* s_lds,
+                                               float* post_stoch_g, float* prior_stoch_g, bool ok) {
+  float kl = 0.f;
+  for (int k = lane; k < K; k += kWave) {
+    const float* pl = p_logits + k * C;
+    float pm, ps;
+    cat_stats(pl, C, pm, ps);
+    if (POST) {
+      const float* ql = q_logits + k * C;
+      float qm, qs;
+      cat_stats(ql, C, qm, qs);
+      const float lqs = logf(qs), lps = logf(ps);
+      float klk = 0.f;
+      for (int c = 0; c < C; ++c) {
+        const float qc = expf(ql[c] - qm) / qs;
+        klk += qc * (((ql[c] - qm) - lqs) - ((pl[c] - pm) - lps));
+      }
+      kl += klk;
+      const int idx = cat_sample(ql, C, qm, qs, u_post[k]);
+      for (int c = 0; c < C; ++c) {
+        const float v = c == idx ? 1.f : 0.f;
+        s_lds[k * C + c] = v;
+        if (ok) post_stoch_g[k * C + c] = v;
+      }
+      if (u_prior && prior_stoch_g && ok) {
+        const int pidx = cat_sample(pl, C, pm, ps, u_prior[k]);
+        for (int c = 0; c < C; ++c) prior_stoch_g[k * C + c] = c == pidx ? 1.f : 0.f;
+      }
+    } else {
+      const int pidx = cat_sample(pl, C, pm, ps, u_prior[k]);
+      for (int c = 0; c < C; ++c) {
+        const float v = c == pidx ? 1.f : 0.f;
+        s_lds[k * C + c] = v;
+        if (ok) prior_stoch_g[k * C + c] = v;
+      }
+    }
+  }
+  return kl;
+}
+
+// ---------------------------------------------------------------------------------------
+// Backward categorical block for one row (one wave, lane k owns categorical k):
+//   dq[s] = q (gq - <q,gq>)                      straight-through sample, gq = g_post_stoch + carry
+//         + gk * w_post * q ((lq - lp) - KL_k)   KL wrt posterior logits
+//         + g_post_logits[s]
+//   dp[s] = gk * w_prior * (p - q) + g_prior_logits[s] + p (gps - <p,gps>)
+// (kl balancing: w_post = 1-alpha, w_prior = alpha; distribution_extension.kl_divergence restated
+//  in oracle/ref_dists.py).  Global gradient row pointers may be null (= zero).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void cat_block_bwd(const float* q_logits, const float* p_logits, int K, int C, int lane,
+                                              const float* g_post_stoch, const float* carry_s,
+                                              const float* g_prior_stoch, const float* g_post_logits,
+                                              const float* g_prior_logits, float gk, float w_post, float w_prior,
+                                              float* dq, float* dp) {
+  for (int k = lane; k < K; k += kWave) {
+    const float* ql = q_logits + k * C;
+    const float* pl = p_logits + k * C;
+    float qm, qs, pm, ps;
+    cat_stats(ql, C, qm, qs);
+    cat_stats(pl, C, pm, ps);
+    const float lqs = logf(qs), lps = logf(ps);
+    float dot = 0.f, klk = 0.f, pdot = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const int s = k * C + c;
+      const float qc = expf(ql[c] - qm) / qs;
+      const float gq = (g_post_stoch ? g_post_stoch[s] : 0.f) + carry_s[s];
+      dot += qc * gq;
+      klk += qc * (((ql[c] - qm) - lqs) - ((pl[c] - pm) - lps));
+      if (g_prior_stoch) pdot += (expf(pl[c] - pm) / ps) * g_prior_stoch[s];
+    }
+    for (int c = 0; c < C; ++c) {
+      const int s = k * C + c;
+      const float qc = expf(ql[c] - qm) / qs;
+      const float pc = expf(pl[c] - pm) / ps;
+      const float gq = (g_post_stoch ? g_post_stoch[s] : 0.f) + carry_s[s];
+      const float diff = ((ql[c] - qm) - lqs) - ((pl[c] - pm) - lps);
+      float a = qc * (gq - dot) + gk * w_post * qc * (diff - klk);
+      if (g_post_logits) a += g_post_logits[s];
+      float b = gk * w_prior * (pc - qc);
+      if (g_prior_logits) b += g_prior_logits[s];
+      if (g_prior_stoch) b += pc * (g_prior_stoch[s] - pdot);
+      dq[s] = a;
+      dp[s] = b;
+    }
+  }
+}
+
+// Backward of wave_mopoe_mix: given d mixed (dmx, LDS) and the saved expert logits, writes d la / d lv (LDS).
+__device__ __forceinline__ void wave_mopoe_mix_bwd(const float* la, const float* lv, const float* mixed, const float* dmx,
+                                                   float* dla, float* dlv, int S, int lane) {
+  float ma, lsa, mv, lsv;
+  wave_flat_lse(la, S, lane, ma, lsa);
+  wave_flat_lse(lv, S, lane, mv, lsv);
+  float suma = 0.f, sumv = 0.f;
+  for (int s = lane; s < S; s += kWave) {
+    const float a = (la[s] - ma) - lsa;
+    const float v = (lv[s] - mv) - lsv;
+    const float mx = mixed[s];
+    const float wa = expf(kLogThird + a - mx), wv = expf(kLogThird + v - mx), wf = expf(kLogThird + a + v - mx);
+    const float g = dmx[s];
+    const float da = g * (wa + wf), dv = g * (wv + wf);
+    dla[s] = da;
+    dlv[s] = dv;
+    suma += da;
+    sumv += dv;
+  }
+  suma = wave_sum(suma);
+  sumv = wave_sum(sumv);
+  for (int s = lane; s < S; s += kWave) {
+    dla[s] -= expf((la[s] - ma) - lsa) * suma;
+    dlv[s] -= expf((lv[s] - mv) - lsv) * sumv;
+  }
+}
+
+}  // namespace mtrssm

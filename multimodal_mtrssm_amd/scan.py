@@ -1,0 +1,476 @@
+"""autograd bindings of the HIP scan kernels (``include/mtrssm.h``).
+
+Division of labour:
+
+* the serial T-step recurrence runs in ONE persistent HIP launch forward and ONE backward
+  (``mtrssm_*_rollout_fwd`` / ``_bwd``);
+* contractions that do not depend on the recurrence -- the action / observation-embedding halves of the
+  first layers -- are hoisted out of the loop as ``[B*T, in] x [in, out]`` library GEMMs (``F.linear``);
+* every weight gradient is formed AFTER the backward scan as one ``[out, B*T] x [B*T, in]`` library GEMM
+  from the per-step pre-activation gradients the kernel emits.
+
+Replaces the loop bodies of ``mrssm/mopoe_mrssm/core.py:221-256`` and
+``mmtrssm/mopoe_mmtrssm/core.py:405-490`` and their autograd graphs (~870 eager ops per step).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import torch
+import torch.nn.functional as F  # noqa: N812
+from torch import Tensor
+
+from multimodal_mtrssm_amd import _lib
+from multimodal_mtrssm_amd.distributions import KL_BALANCE_ALPHA
+
+
+@dataclass(frozen=True)
+class ScanConfig:
+    cats: int
+    classes: int
+    act: int
+    balancing: bool = True
+    rows_per_block: int = 0
+    threads: int = 0
+
+    @property
+    def kl_weights(self) -> tuple[float, float]:
+        return (1.0 - KL_BALANCE_ALPHA, KL_BALANCE_ALPHA) if self.balancing else (1.0, 1.0)
+
+
+KERNEL_TIMERS = _lib.TIMERS
+
+
+def _c(t: Tensor) -> Tensor:
+    return t.contiguous()
+
+
+def _flat2(t: Tensor) -> Tensor:
+    return t.reshape(-1, t.shape[-1])
+
+
+def _new(like: Tensor, *shape: int) -> Tensor:
+    return torch.empty(shape, device=like.device, dtype=torch.float32)
+
+
+def _opt(t: Tensor | None) -> Tensor | None:
+    return None if t is None else _c(t)
+
+
+# ============================================================================================
+# MRSSM
+# ============================================================================================
+class _MrssmScan(torch.autograd.Function):
+    """Posterior rollout.  Inputs: hoisted projections, initial state, uniforms, raw parameters."""
+
+    @staticmethod
+    def forward(  # noqa: PLR0913, PLR0914
+        ctx, cfg: ScanConfig, xa, pa, pv, deter0, stoch0, u_post, u_prior,  # noqa: ANN001
+        w1, w2, b2, wih, bih, whh, bhh, w3, b3, w4, b4, wa1, wa2, ba2, wv1, wv2, bv2,  # noqa: ANN001
+    ):
+        lib = _lib.load()
+        B, T, H = xa.shape
+        D = deter0.shape[1]
+        S = cfg.cats * cfg.classes
+        A = w1.shape[1] - S
+        xa, pa, pv, deter0, stoch0, u_post = map(_c, (xa, pa, pv, deter0, stoch0, u_post))
+        u_prior = _opt(u_prior)
+        # forward layouts (include/mtrssm.h: wide outputs stream W^T, narrow outputs stream W)
+        w1s_t = _c(w1[:, A:].t())
+        wh1 = torch.cat([w3, wa1[:, :D], wv1[:, :D]], dim=0)  # [3H, D]
+        fw = _lib.fill(
+            _lib.MrssmFwdWeights(), w1s_t=w1s_t, w2_t=_c(w2.t()), b2=_c(b2), wih_t=_c(wih.t()), bih=_c(bih), whh_t=_c(whh.t()),
+            bhh=_c(bhh), wh1_t=_c(wh1.t()), b3=_c(b3), w4=_c(w4), b4=_c(b4), wa2=_c(wa2), ba2=_c(ba2), wv2=_c(wv2), bv2=_c(bv2),
+        )
+        deter = _new(xa, B, T, D)
+        prior_logits, post_logits, post_stoch = (_new(xa, B, T, S) for _ in range(3))
+        prior_stoch = _new(xa, B, T, S) if u_prior is not None else None
+        kl = _new(xa, B, T)
+        need_grad = any(ctx.needs_input_grad)
+        sv = dict(sv_h1=None, sv_h2=None, sv_gates=None, sv_heads=None, sv_la=None, sv_lv=None)
+        if need_grad:
+            sv = dict(sv_h1=_new(xa, B, T, H), sv_h2=_new(xa, B, T, H), sv_gates=_new(xa, B, T, 4 * D),
+                      sv_heads=_new(xa, B, T, 3 * H), sv_la=_new(xa, B, T, S), sv_lv=_new(xa, B, T, S))
+        io = _lib.fill(
+            _lib.MrssmFwdIO(), xa=xa, pa=pa, pv=pv, deter0=deter0, stoch0=stoch0, u_post=u_post, u_prior=u_prior,
+            deter=deter, prior_logits=prior_logits, prior_stoch=prior_stoch, post_logits=post_logits, post_stoch=post_stoch,
+            kl=kl, **sv,
+        )
+        wp, wq = cfg.kl_weights
+        dims = _lib.MrssmDims(B, T, D, H, cfg.cats, cfg.classes, cfg.act, 1, wp, wq, cfg.rows_per_block, cfg.threads)
+        _lib.check(_lib.TIMERS.call("mtrssm_mrssm_rollout_fwd", lib.mtrssm_mrssm_rollout_fwd, C.byref(dims), C.byref(fw), C.byref(io),
+                                     _lib.stream_ptr(xa.device)), "mtrssm_mrssm_rollout_fwd")
+        if need_grad:
+            ctx.cfg, ctx.A = cfg, A
+            ctx.save_for_backward(deter0, stoch0, deter, prior_logits, post_logits, post_stoch, sv["sv_h1"], sv["sv_h2"],
+                                  sv["sv_gates"], sv["sv_heads"], sv["sv_la"], sv["sv_lv"], w1s_t, wh1,
+                                  w1, w2, wih, whh, w4, wa1, wa2, wv1, wv2)
+        ctx.has_prior_stoch = prior_stoch is not None
+        outs = (deter, prior_logits, post_logits, post_stoch, prior_stoch if prior_stoch is not None else deter.new_zeros(()), kl)
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_deter, g_prior_logits, g_post_logits, g_post_stoch, g_prior_stoch, g_kl):  # noqa: ANN001, PLR0913, PLR0914
+        lib = _lib.load()
+        (deter0, stoch0, deter, prior_logits, post_logits, post_stoch, sv_h1, sv_h2, sv_gates, sv_heads, sv_la, sv_lv,
+         w1s_t, wh1, w1, w2, wih, whh, w4, wa1, wa2, wv1, wv2) = ctx.saved_tensors
+        cfg, A = ctx.cfg, ctx.A
+        B, T, D = deter.shape
+        H = sv_h1.shape[-1]
+        S = cfg.cats * cfg.classes
+        if not ctx.has_prior_stoch:
+            g_prior_stoch = None
+        bw = _lib.fill(_lib.MrssmBwdWeights(), w1s_t=w1s_t, w2=_c(w2), wih=_c(wih), whh=_c(whh), wh1=wh1, w4=_c(w4), wa2=_c(wa2),
+                       wv2=_c(wv2))
+        g_deter0, g_stoch0 = _new(deter, B, D), _new(deter, B, S)
+        d_z1, d_h2 = _new(deter, B, T, H), _new(deter, B, T, H)
+        d_gi, d_gh = _new(deter, B, T, 3 * D), _new(deter, B, T, 3 * D)
+        d_zh = _new(deter, B, T, 3 * H)
+        d_lp, d_la, d_lv = (_new(deter, B, T, S) for _ in range(3))
+        io = _lib.fill(
+            _lib.MrssmBwdIO(), deter0=deter0, deter=deter, prior_logits=prior_logits, post_logits=post_logits, sv_h1=sv_h1,
+            sv_h2=sv_h2, sv_gates=sv_gates, sv_heads=sv_heads, sv_la=sv_la, sv_lv=sv_lv,
+            g_deter=_opt(g_deter), g_post_stoch=_opt(g_post_stoch), g_prior_stoch=_opt(g_prior_stoch),
+            g_post_logits=_opt(g_post_logits), g_prior_logits=_opt(g_prior_logits), g_kl=_opt(g_kl),
+            g_deter0=g_deter0, g_stoch0=g_stoch0, d_z1=d_z1, d_h2=d_h2, d_gi=d_gi, d_gh=d_gh, d_zh=d_zh, d_lp=d_lp, d_la=d_la,
+            d_lv=d_lv,
+        )
+        wp, wq = cfg.kl_weights
+        dims = _lib.MrssmDims(B, T, D, H, cfg.cats, cfg.classes, cfg.act, 1, wp, wq, cfg.rows_per_block, cfg.threads)
+        _lib.check(_lib.TIMERS.call("mtrssm_mrssm_rollout_bwd", lib.mtrssm_mrssm_rollout_bwd, C.byref(dims), C.byref(bw), C.byref(io),
+                                     _lib.stream_ptr(deter.device)), "mtrssm_mrssm_rollout_bwd")
+
+        # ---- weight gradients: one [out, B*T] x [B*T, in] library GEMM each (rocBLAS) -------------
+        prev_stoch = _flat2(torch.cat([stoch0.unsqueeze(1), post_stoch[:, :-1]], dim=1))
+        prev_deter = _flat2(torch.cat([deter0.unsqueeze(1), deter[:, :-1]], dim=1))
+        fz1, fh2, fgi, fgh, fzh = map(_flat2, (d_z1, d_h2, d_gi, d_gh, d_zh))
+        flp, fla, flv = map(_flat2, (d_lp, d_la, d_lv))
+        fdet, fh1, fsh2, fheads = map(_flat2, (deter, sv_h1, sv_h2, sv_heads))
+        g_w1 = torch.zeros_like(w1)
+        g_w1[:, A:] = fz1.t() @ prev_stoch
+        g_w2, g_b2 = fh2.t() @ fh1, fh2.sum(0)
+        g_wih, g_bih = fgi.t() @ fsh2, fgi.sum(0)
+        g_whh, g_bhh = fgh.t() @ prev_deter, fgh.sum(0)
+        g_wh1 = fzh.t() @ fdet  # [3H, D]: prior.0 | audio.0[:, :D] | vision.0[:, :D]
+        g_w3, g_b3 = g_wh1[:H], fzh[:, :H].sum(0)
+        g_wa1 = torch.zeros_like(wa1)
+        g_wa1[:, :D] = g_wh1[H : 2 * H]
+        g_wv1 = torch.zeros_like(wv1)
+        g_wv1[:, :D] = g_wh1[2 * H :]
+        g_w4, g_b4 = flp.t() @ fheads[:, :H], flp.sum(0)
+        g_wa2, g_ba2 = fla.t() @ fheads[:, H : 2 * H], fla.sum(0)
+        g_wv2, g_bv2 = flv.t() @ fheads[:, 2 * H :], flv.sum(0)
+        g_pa, g_pv = d_zh[..., H : 2 * H], d_zh[..., 2 * H :]
+        return (None, d_z1, g_pa, g_pv, g_deter0, g_stoch0, None, None,
+                g_w1, g_w2, g_b2, g_wih, g_bih, g_whh, g_bhh, g_w3, g_b3, g_w4, g_b4, g_wa1, g_wa2, g_ba2, g_wv1, g_wv2, g_bv2)
+
+
+def mrssm_posterior_rollout(  # noqa: PLR0913
+    transition, audio_rep, vision_rep, actions: Tensor, audio_embed: Tensor, vision_embed: Tensor,  # noqa: ANN001
+    deter0: Tensor, stoch0: Tensor, u_post: Tensor, u_prior: Tensor | None, *, balancing: bool, rows_per_block: int = 0,
+    threads: int = 0,
+) -> dict[str, Tensor]:
+    """Run ``mrssm/mopoe_mrssm/core.py:221-256`` for all T steps on the GPU."""
+    factory = transition.distribution_factory
+    K, Cc = factory.category_size, factory.class_size
+    D = transition.deterministic_size
+    A = actions.shape[-1]
+    l1, l2 = transition.action_state_projector.two_layer()
+    p1, p2 = transition.rnn_to_prior_projector.two_layer()
+    a1, a2 = audio_rep.rnn_to_post_projector.two_layer()
+    v1, v2 = vision_rep.rnn_to_post_projector.two_layer()
+    act_names = {transition.action_state_projector.activation_name, transition.rnn_to_prior_projector.activation_name,
+                 audio_rep.rnn_to_post_projector.activation_name, vision_rep.rnn_to_post_projector.activation_name}
+    if len(act_names) != 1:
+        msg = f"the HIP scan uses one activation for all heads, got {sorted(act_names)}"
+        raise NotImplementedError(msg)
+    cfg = ScanConfig(K, Cc, _lib.ACT_IDS[act_names.pop()], balancing, rows_per_block, threads)
+    # hoisted, recurrence-independent halves of the first layers: plain library GEMMs
+    xa = F.linear(actions, l1.weight[:, :A], l1.bias)
+    pa = F.linear(audio_embed, a1.weight[:, D:], a1.bias)
+    pv = F.linear(vision_embed, v1.weight[:, D:], v1.bias)
+    cell = transition.rnn_cell
+    deter, prior_logits, post_logits, post_stoch, prior_stoch, kl = _MrssmScan.apply(
+        cfg, xa, pa, pv, deter0, stoch0, u_post, u_prior,
+        l1.weight, l2.weight, l2.bias, cell.weight_ih, cell.bias_ih, cell.weight_hh, cell.bias_hh,
+        p1.weight, p1.bias, p2.weight, p2.bias, a1.weight, a2.weight, a2.bias, v1.weight, v2.weight, v2.bias,
+    )
+    return {"deter": deter, "prior_logits": prior_logits, "post_logits": post_logits, "post_stoch": post_stoch,
+            "prior_stoch": prior_stoch if u_prior is not None else None, "kl": kl}
+
+
+def mrssm_prior_rollout(transition, actions: Tensor, deter0: Tensor, stoch0: Tensor, u_prior: Tensor | None,  # noqa: ANN001
+                        *, rows_per_block: int = 0, threads: int = 0) -> dict[str, Tensor]:
+    """``BaseRSSM.rollout_transition`` (``core.py:170-185``): prior-only scan, inference (no autograd)."""
+    lib = _lib.load()
+    if torch.is_grad_enabled() and any(p.requires_grad for p in transition.parameters()) and (actions.requires_grad or deter0.requires_grad):
+        msg = "the prior-only HIP rollout is an inference path (callbacks / evaluation): call it under torch.no_grad()"
+        raise NotImplementedError(msg)
+    with torch.no_grad():
+        factory = transition.distribution_factory
+        K, Cc = factory.category_size, factory.class_size
+        S = K * Cc
+        B, T, A = actions.shape
+        D, H = transition.deterministic_size, transition.hidden_size
+        l1, l2 = transition.action_state_projector.two_layer()
+        p1, p2 = transition.rnn_to_prior_projector.two_layer()
+        cell = transition.rnn_cell
+        if u_prior is None:
+            u_prior = torch.rand(B, T, K, device=actions.device)
+        xa = _c(F.linear(actions, l1.weight[:, :A], l1.bias))
+        tensors = dict(w1s_t=_c(l1.weight[:, A:].t()), w2_t=_c(l2.weight.t()), b2=_c(l2.bias), wih_t=_c(cell.weight_ih.t()),
+                       bih=_c(cell.bias_ih), whh_t=_c(cell.weight_hh.t()), bhh=_c(cell.bias_hh), wh1_t=_c(p1.weight.t()),
+                       b3=_c(p1.bias), w4=_c(p2.weight), b4=_c(p2.bias))
+        fw = _lib.fill(_lib.MrssmFwdWeights(), **tensors)
+        deter, prior_logits, prior_stoch = _new(xa, B, T, D), _new(xa, B, T, S), _new(xa, B, T, S)
+        deter0, stoch0, u_prior = _c(deter0.float()), _c(stoch0.float()), _c(u_prior.float())
+        io = _lib.fill(_lib.MrssmFwdIO(), xa=xa, deter0=deter0, stoch0=stoch0, u_prior=u_prior, deter=deter,
+                       prior_logits=prior_logits, prior_stoch=prior_stoch)
+        act = _lib.ACT_IDS[transition.action_state_projector.activation_name]
+        dims = _lib.MrssmDims(B, T, D, H, K, Cc, act, 0, 1.0, 1.0, rows_per_block, threads)
+        _lib.check(lib.mtrssm_mrssm_rollout_fwd(C.byref(dims), C.byref(fw), C.byref(io), _lib.stream_ptr(xa.device)),
+                   "mtrssm_mrssm_rollout_fwd(prior-only)")
+        del tensors
+    return {"deter": deter, "prior_logits": prior_logits, "prior_stoch": prior_stoch}
+
+
+# ============================================================================================
+# MMTRSSM
+# ============================================================================================
+@dataclass(frozen=True)
+class MTScanConfig:
+    kl_cats: int
+    kl_classes: int
+    kh_cats: int
+    kh_classes: int
+    act: int
+    tau_l: float
+    tau_h: float
+    balancing: bool = True
+    rows_per_block: int = 0
+    threads: int = 0
+
+    @property
+    def kl_weights(self) -> tuple[float, float]:
+        return (1.0 - KL_BALANCE_ALPHA, KL_BALANCE_ALPHA) if self.balancing else (1.0, 1.0)
+
+    def dims(self, B: int, T: int, LD: int, HD: int, H: int, post: int) -> C.Structure:  # noqa: N803, PLR0913
+        wp, wq = self.kl_weights
+        return _lib.MmtrssmDims(B, T, LD, HD, H, self.kl_cats, self.kl_classes, self.kh_cats, self.kh_classes, self.act, post,
+                                self.tau_l, self.tau_h, 1.0 - 1.0 / self.tau_l, 1.0 - 1.0 / self.tau_h, wp, wq,
+                                self.rows_per_block, self.threads)
+
+
+class _MmtrssmScan(torch.autograd.Function):
+    @staticmethod
+    def forward(  # noqa: PLR0913, PLR0914
+        ctx, cfg: MTScanConfig, xl, pa, pv, deter_l0, deter_h0, hidden_l0, hidden_h0, stoch_l0, stoch_h0,  # noqa: ANN001
+        u_post_l, u_post_h, u_prior_l, u_prior_h,  # noqa: ANN001
+        wxl, wdl, wxh, wdh, bh, wlp1, blp1, wlp2, blp2, wa1, wa2, ba2, wv1, wv2, bv2, whp1, bhp1, whp2, bhp2, whq1, bhq1, whq2, bhq2,  # noqa: ANN001
+    ):
+        lib = _lib.load()
+        B, T, LD = xl.shape
+        HD = deter_h0.shape[1]
+        H = pa.shape[-1]
+        LS, HS = cfg.kl_cats * cfg.kl_classes, cfg.kh_cats * cfg.kh_classes
+        A = wxl.shape[1] - LS - HS
+        (xl, pa, pv, deter_l0, deter_h0, hidden_l0, hidden_h0, stoch_l0, stoch_h0, u_post_l, u_post_h) = map(
+            _c, (xl, pa, pv, deter_l0, deter_h0, hidden_l0, hidden_h0, stoch_l0, stoch_h0, u_post_l, u_post_h))
+        u_prior_l, u_prior_h = _opt(u_prior_l), _opt(u_prior_h)
+        wxl_s_t = _c(wxl[:, A:].t())  # [LS+HS, LD]
+        wxh_t = _c(wxh.t())  # [HS, HD]
+        wl1 = torch.cat([wlp1, wa1[:, :LD], wv1[:, :LD], whq1[:, :LD]], dim=0)  # [4H, LD]
+        wh1 = torch.cat([whp1, whq1[:, LD:]], dim=0)  # [2H, HD]
+        bh1 = torch.cat([bhp1, bhq1], dim=0)
+        tensors = dict(wxl_s_t=wxl_s_t, wdl_t=_c(wdl.t()), wxh_t=wxh_t, wdh_t=_c(wdh.t()), bh=_c(bh), wl1_t=_c(wl1.t()),
+                       bl1=_c(blp1), wh1_t=_c(wh1.t()), bh1=bh1, wlp2=_c(wlp2), blp2=_c(blp2), wa2=_c(wa2), ba2=_c(ba2),
+                       wv2=_c(wv2), bv2=_c(bv2), whp2=_c(whp2), bhp2=_c(bhp2), whq2=_c(whq2), bhq2=_c(bhq2))
+        fw = _lib.fill(_lib.MmtrssmFwdWeights(), **tensors)
+        o = dict(
+            deter_l=_new(xl, B, T, LD), deter_h=_new(xl, B, T, HD), hidden_l=_new(xl, B, T, LD), hidden_h=_new(xl, B, T, HD),
+            prior_logits_l=_new(xl, B, T, LS), prior_logits_h=_new(xl, B, T, HS),
+            prior_stoch_l=_new(xl, B, T, LS) if u_prior_l is not None else None,
+            prior_stoch_h=_new(xl, B, T, HS) if u_prior_h is not None else None,
+            post_logits_l=_new(xl, B, T, LS), post_logits_h=_new(xl, B, T, HS),
+            post_stoch_l=_new(xl, B, T, LS), post_stoch_h=_new(xl, B, T, HS), kl_l=_new(xl, B, T), kl_h=_new(xl, B, T),
+        )
+        need_grad = any(ctx.needs_input_grad)
+        sv = dict(sv_l1=None, sv_h1=None, sv_la=None, sv_lv=None)
+        if need_grad:
+            sv = dict(sv_l1=_new(xl, B, T, 4 * H), sv_h1=_new(xl, B, T, H), sv_la=_new(xl, B, T, LS), sv_lv=_new(xl, B, T, LS))
+        io = _lib.fill(
+            _lib.MmtrssmFwdIO(), xl=xl, pa=pa, pv=pv, deter_l0=deter_l0, deter_h0=deter_h0, hidden_l0=hidden_l0,
+            hidden_h0=hidden_h0, stoch_l0=stoch_l0, stoch_h0=stoch_h0, u_post_l=u_post_l, u_post_h=u_post_h,
+            u_prior_l=u_prior_l, u_prior_h=u_prior_h, **o, **sv,
+        )
+        dims = cfg.dims(B, T, LD, HD, H, 1)
+        _lib.check(_lib.TIMERS.call("mtrssm_mmtrssm_rollout_fwd", lib.mtrssm_mmtrssm_rollout_fwd, C.byref(dims), C.byref(fw), C.byref(io),
+                                     _lib.stream_ptr(xl.device)), "mtrssm_mmtrssm_rollout_fwd")
+        del tensors
+        if need_grad:
+            ctx.cfg, ctx.A = cfg, A
+            ctx.save_for_backward(
+                deter_l0, deter_h0, stoch_l0, stoch_h0, o["deter_l"], o["deter_h"], o["prior_logits_l"], o["prior_logits_h"],
+                o["post_logits_l"], o["post_logits_h"], o["post_stoch_l"], o["post_stoch_h"], sv["sv_l1"], sv["sv_h1"],
+                sv["sv_la"], sv["sv_lv"], wxl_s_t, wxh_t, wl1, wh1, wxl, wdl, wxh, wdh, wlp2, wa1, wa2, wv1, wv2, whp2, whq1, whq2)
+        ctx.has_prior = (o["prior_stoch_l"] is not None, o["prior_stoch_h"] is not None)
+        z = o["deter_l"].new_zeros(())
+        return (o["deter_l"], o["deter_h"], o["hidden_l"], o["hidden_h"], o["prior_logits_l"], o["prior_logits_h"],
+                o["post_logits_l"], o["post_logits_h"], o["post_stoch_l"], o["post_stoch_h"],
+                o["prior_stoch_l"] if o["prior_stoch_l"] is not None else z,
+                o["prior_stoch_h"] if o["prior_stoch_h"] is not None else z, o["kl_l"], o["kl_h"])
+
+    @staticmethod
+    def backward(ctx, g_dl, g_dh, g_hl, g_hh, g_pll, g_plh, g_qll, g_qlh, g_qsl, g_qsh, g_psl, g_psh, g_kll, g_klh):  # noqa: ANN001, PLR0913, PLR0914, PLR0915
+        lib = _lib.load()
+        (deter_l0, deter_h0, stoch_l0, stoch_h0, deter_l, deter_h, prior_logits_l, prior_logits_h, post_logits_l, post_logits_h,
+         post_stoch_l, post_stoch_h, sv_l1, sv_h1, sv_la, sv_lv, wxl_s_t, wxh_t, wl1, wh1, wxl, wdl, wxh, wdh, wlp2, wa1, wa2,
+         wv1, wv2, whp2, whq1, whq2) = ctx.saved_tensors
+        cfg, A = ctx.cfg, ctx.A
+        B, T, LD = deter_l.shape
+        HD = deter_h.shape[-1]
+        H = sv_h1.shape[-1]
+        LS, HS = cfg.kl_cats * cfg.kl_classes, cfg.kh_cats * cfg.kh_classes
+        if not ctx.has_prior[0]:
+            g_psl = None
+        if not ctx.has_prior[1]:
+            g_psh = None
+        bw = _lib.fill(_lib.MmtrssmBwdWeights(), wxl_s_t=wxl_s_t, wdl=_c(wdl), wxh_t=wxh_t, wdh=_c(wdh), wl1=wl1, wh1=wh1,
+                       wlp2=_c(wlp2), wa2=_c(wa2), wv2=_c(wv2), whp2=_c(whp2), whq2=_c(whq2))
+        g0 = dict(g_deter_l0=_new(deter_l, B, LD), g_deter_h0=_new(deter_l, B, HD), g_hidden_l0=_new(deter_l, B, LD),
+                  g_hidden_h0=_new(deter_l, B, HD), g_stoch_l0=_new(deter_l, B, LS), g_stoch_h0=_new(deter_l, B, HS))
+        d = dict(d_ul=_new(deter_l, B, T, LD), d_uh=_new(deter_l, B, T, HD), d_zl1=_new(deter_l, B, T, 4 * H),
+                 d_zh1=_new(deter_l, B, T, H), d_lpl=_new(deter_l, B, T, LS), d_la=_new(deter_l, B, T, LS),
+                 d_lv=_new(deter_l, B, T, LS), d_lph=_new(deter_l, B, T, HS), d_lqh=_new(deter_l, B, T, HS))
+        io = _lib.fill(
+            _lib.MmtrssmBwdIO(), deter_l0=deter_l0, deter_h0=deter_h0, deter_l=deter_l, deter_h=deter_h,
+            prior_logits_l=prior_logits_l, prior_logits_h=prior_logits_h, post_logits_l=post_logits_l, post_logits_h=post_logits_h,
+            sv_l1=sv_l1, sv_h1=sv_h1, sv_la=sv_la, sv_lv=sv_lv,
+            g_deter_l=_opt(g_dl), g_deter_h=_opt(g_dh), g_hidden_l=_opt(g_hl), g_hidden_h=_opt(g_hh),
+            g_post_stoch_l=_opt(g_qsl), g_post_stoch_h=_opt(g_qsh), g_prior_stoch_l=_opt(g_psl), g_prior_stoch_h=_opt(g_psh),
+            g_post_logits_l=_opt(g_qll), g_post_logits_h=_opt(g_qlh), g_prior_logits_l=_opt(g_pll), g_prior_logits_h=_opt(g_plh),
+            g_kl_l=_opt(g_kll), g_kl_h=_opt(g_klh), **g0, **d,
+        )
+        dims = cfg.dims(B, T, LD, HD, H, 1)
+        _lib.check(_lib.TIMERS.call("mtrssm_mmtrssm_rollout_bwd", lib.mtrssm_mmtrssm_rollout_bwd, C.byref(dims), C.byref(bw), C.byref(io),
+                                     _lib.stream_ptr(deter_l.device)), "mtrssm_mmtrssm_rollout_bwd")
+
+        prev_sl = torch.cat([stoch_l0.unsqueeze(1), post_stoch_l[:, :-1]], dim=1)
+        prev_sh = torch.cat([stoch_h0.unsqueeze(1), post_stoch_h[:, :-1]], dim=1)
+        prev_slh = _flat2(torch.cat([prev_sl, prev_sh], dim=-1))
+        prev_dl = _flat2(torch.cat([deter_l0.unsqueeze(1), deter_l[:, :-1]], dim=1))
+        prev_dh = _flat2(torch.cat([deter_h0.unsqueeze(1), deter_h[:, :-1]], dim=1))
+        ful, fuh, fzl, fzh = map(_flat2, (d["d_ul"], d["d_uh"], d["d_zl1"], d["d_zh1"]))
+        flpl, fla, flv, flph, flqh = map(_flat2, (d["d_lpl"], d["d_la"], d["d_lv"], d["d_lph"], d["d_lqh"]))
+        fdl, fdh, fl1, fh1 = map(_flat2, (deter_l, deter_h, sv_l1, sv_h1))
+        g_wxl = torch.zeros_like(wxl)
+        g_wxl[:, A:] = ful.t() @ prev_slh
+        g_wdl = ful.t() @ prev_dl
+        g_wxh = fuh.t() @ _flat2(prev_sh)
+        g_wdh = fuh.t() @ prev_dh
+        g_bh = fuh.sum(0)
+        g_wl1 = fzl.t() @ fdl  # [4H, LD]
+        g_wlp1, g_blp1 = g_wl1[:H], fzl[:, :H].sum(0)
+        g_wa1 = torch.zeros_like(wa1)
+        g_wa1[:, :LD] = g_wl1[H : 2 * H]
+        g_wv1 = torch.zeros_like(wv1)
+        g_wv1[:, :LD] = g_wl1[2 * H : 3 * H]
+        fzq = fzl[:, 3 * H :]
+        g_whq1 = torch.cat([g_wl1[3 * H :], fzq.t() @ fdh], dim=1)
+        g_bhq1 = fzq.sum(0)
+        g_whp1, g_bhp1 = fzh.t() @ fdh, fzh.sum(0)
+        g_wlp2, g_blp2 = flpl.t() @ fl1[:, :H], flpl.sum(0)
+        g_wa2, g_ba2 = fla.t() @ fl1[:, H : 2 * H], fla.sum(0)
+        g_wv2, g_bv2 = flv.t() @ fl1[:, 2 * H : 3 * H], flv.sum(0)
+        g_whq2, g_bhq2 = flqh.t() @ fl1[:, 3 * H :], flqh.sum(0)
+        g_whp2, g_bhp2 = flph.t() @ fh1, flph.sum(0)
+        zl = d["d_zl1"]
+        return (None, d["d_ul"], zl[..., H : 2 * H], zl[..., 2 * H : 3 * H], g0["g_deter_l0"], g0["g_deter_h0"], g0["g_hidden_l0"],
+                g0["g_hidden_h0"], g0["g_stoch_l0"], g0["g_stoch_h0"], None, None, None, None,
+                g_wxl, g_wdl, g_wxh, g_wdh, g_bh, g_wlp1, g_blp1, g_wlp2, g_blp2, g_wa1, g_wa2, g_ba2, g_wv1, g_wv2, g_bv2,
+                g_whp1, g_bhp1, g_whp2, g_bhp2, g_whq1, g_bhq1, g_whq2, g_bhq2)
+
+
+def _mt_act(model) -> int:  # noqa: ANN001
+    names = {model.l_prior.activation_name, model.h_prior.activation_name, model.h_posterior.activation_name,
+             model.audio_representation.rnn_to_post_projector.activation_name,
+             model.vision_representation.rnn_to_post_projector.activation_name}
+    if len(names) != 1:
+        msg = f"the HIP scan uses one activation for all heads, got {sorted(names)}"
+        raise NotImplementedError(msg)
+    return _lib.ACT_IDS[names.pop()]
+
+
+def mmtrssm_posterior_rollout(model, actions: Tensor, audio_embed: Tensor, vision_embed: Tensor, state0: dict[str, Tensor],  # noqa: ANN001
+                              noise: dict[str, Tensor | None], *, rows_per_block: int = 0, threads: int = 0) -> dict[str, Tensor]:
+    """Run ``mmtrssm/mopoe_mmtrssm/core.py:405-490`` for all T steps on the GPU."""
+    LD = model.ld_dim
+    A = actions.shape[-1]
+    cfg = MTScanConfig(model.l_dist.category_size, model.l_dist.class_size, model.h_dist.category_size, model.h_dist.class_size,
+                       _mt_act(model), float(model.l_rnn.tau), float(model.h_rnn.tau), bool(model.use_kl_balancing),
+                       rows_per_block, threads)
+    lp1, lp2 = model.l_prior.two_layer()
+    hp1, hp2 = model.h_prior.two_layer()
+    hq1, hq2 = model.h_posterior.two_layer()
+    a1, a2 = model.audio_representation.rnn_to_post_projector.two_layer()
+    v1, v2 = model.vision_representation.rnn_to_post_projector.two_layer()
+    lr, hr = model.l_rnn, model.h_rnn
+    xl = F.linear(actions, lr._input2h.weight[:, :A], lr._input2h.bias + lr._d2h.bias)  # noqa: SLF001
+    pa = F.linear(audio_embed, a1.weight[:, LD:], a1.bias)
+    pv = F.linear(vision_embed, v1.weight[:, LD:], v1.bias)
+    bh = hr._input2h.bias + hr._d2h.bias  # noqa: SLF001
+    out = _MmtrssmScan.apply(
+        cfg, xl, pa, pv, state0["deter_l"], state0["deter_h"], state0["hidden_l"], state0["hidden_h"], state0["stoch_l"],
+        state0["stoch_h"], noise["u_post_l"], noise["u_post_h"], noise.get("u_prior_l"), noise.get("u_prior_h"),
+        lr._input2h.weight, lr._d2h.weight, hr._input2h.weight, hr._d2h.weight, bh,  # noqa: SLF001
+        lp1.weight, lp1.bias, lp2.weight, lp2.bias, a1.weight, a2.weight, a2.bias, v1.weight, v2.weight, v2.bias,
+        hp1.weight, hp1.bias, hp2.weight, hp2.bias, hq1.weight, hq1.bias, hq2.weight, hq2.bias,
+    )
+    names = ("deter_l", "deter_h", "hidden_l", "hidden_h", "prior_logits_l", "prior_logits_h", "post_logits_l", "post_logits_h",
+             "post_stoch_l", "post_stoch_h", "prior_stoch_l", "prior_stoch_h", "kl_l", "kl_h")
+    res = dict(zip(names, out, strict=True))
+    if noise.get("u_prior_l") is None:
+        res["prior_stoch_l"] = None
+    if noise.get("u_prior_h") is None:
+        res["prior_stoch_h"] = None
+    return res
+
+
+def mmtrssm_prior_rollout(model, actions: Tensor, state0: dict[str, Tensor], noise: dict[str, Tensor | None],  # noqa: ANN001
+                          *, rows_per_block: int = 0, threads: int = 0) -> dict[str, Tensor]:
+    """``MoPoE_MMTRSSM.rollout_transition`` (``core.py:496-544``): prior-only scan, inference."""
+    lib = _lib.load()
+    with torch.no_grad():
+        LD, HD = model.ld_dim, model.hd_dim
+        B, T, A = actions.shape
+        cfg = MTScanConfig(model.l_dist.category_size, model.l_dist.class_size, model.h_dist.category_size,
+                           model.h_dist.class_size, _mt_act(model), float(model.l_rnn.tau), float(model.h_rnn.tau), True,
+                           rows_per_block, threads)
+        LS, HS = cfg.kl_cats * cfg.kl_classes, cfg.kh_cats * cfg.kh_classes
+        lp1, lp2 = model.l_prior.two_layer()
+        hp1, hp2 = model.h_prior.two_layer()
+        H = lp1.out_features
+        lr, hr = model.l_rnn, model.h_rnn
+        xl = _c(F.linear(actions, lr._input2h.weight[:, :A], lr._input2h.bias + lr._d2h.bias))  # noqa: SLF001
+        tensors = dict(
+            wxl_s_t=_c(lr._input2h.weight[:, A:].t()), wdl_t=_c(lr._d2h.weight.t()), wxh_t=_c(hr._input2h.weight.t()),  # noqa: SLF001
+            wdh_t=_c(hr._d2h.weight.t()), bh=_c(hr._input2h.bias + hr._d2h.bias), wl1_t=_c(lp1.weight.t()), bl1=_c(lp1.bias),  # noqa: SLF001
+            wh1_t=_c(hp1.weight.t()), bh1=_c(hp1.bias), wlp2=_c(lp2.weight), blp2=_c(lp2.bias), whp2=_c(hp2.weight), bhp2=_c(hp2.bias))
+        fw = _lib.fill(_lib.MmtrssmFwdWeights(), **tensors)
+        u_l = noise.get("u_prior_l")
+        u_h = noise.get("u_prior_h")
+        u_l = torch.rand(B, T, cfg.kl_cats, device=xl.device) if u_l is None else _c(u_l.float())
+        u_h = torch.rand(B, T, cfg.kh_cats, device=xl.device) if u_h is None else _c(u_h.float())
+        o = dict(deter_l=_new(xl, B, T, LD), deter_h=_new(xl, B, T, HD), hidden_l=_new(xl, B, T, LD), hidden_h=_new(xl, B, T, HD),
+                 prior_logits_l=_new(xl, B, T, LS), prior_logits_h=_new(xl, B, T, HS), prior_stoch_l=_new(xl, B, T, LS),
+                 prior_stoch_h=_new(xl, B, T, HS))
+        st = {k: _c(state0[k].float()) for k in ("deter_l", "deter_h", "hidden_l", "hidden_h", "stoch_l", "stoch_h")}
+        io = _lib.fill(_lib.MmtrssmFwdIO(), xl=xl, deter_l0=st["deter_l"], deter_h0=st["deter_h"], hidden_l0=st["hidden_l"],
+                       hidden_h0=st["hidden_h"], stoch_l0=st["stoch_l"], stoch_h0=st["stoch_h"], u_prior_l=u_l, u_prior_h=u_h, **o)
+        dims = cfg.dims(B, T, LD, HD, H, 0)
+        _lib.check(lib.mtrssm_mmtrssm_rollout_fwd(C.byref(dims), C.byref(fw), C.byref(io), _lib.stream_ptr(xl.device)),
+                   "mtrssm_mmtrssm_rollout_fwd(prior-only)")
+        del tensors
+    return o

@@ -1,0 +1,81 @@
+"""CPU: the C-ABI library loads and exports every symbol ``include/mtrssm.h`` declares.
+
+No compute call is made here (there is no GPU): argument validation returns before any launch.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import re
+from pathlib import Path
+
+import pytest
+
+from multimodal_mtrssm_amd import _lib
+
+ROOT = Path(__file__).resolve().parents[1]
+HEADER = (ROOT / "include" / "mtrssm.h").read_text()
+
+
+def declared_functions() -> list[str]:
+    names = re.findall(r"^\s*(?:int|const char\*)\s+(mtrssm_\w+)\s*\(", HEADER, flags=re.MULTILINE)
+    assert len(names) >= 10
+    return names
+
+
+def test_library_exports_every_declared_symbol() -> None:
+    lib = _lib.load()
+    for name in declared_functions():
+        assert hasattr(lib, name), f"{name} is declared in include/mtrssm.h but not exported"
+    assert set(declared_functions()) == set(_lib.SYMBOLS), "ctypes table and header disagree"
+
+
+def test_version_matches_header() -> None:
+    want = int(re.search(r"#define MTRSSM_VERSION (\d+)", HEADER).group(1))
+    assert _lib.load().mtrssm_version() == want
+
+
+def _struct_fields(name: str) -> list[str]:
+    body = re.search(r"typedef struct " + name + r" \{(.*?)\} " + name + ";", HEADER, flags=re.DOTALL).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.DOTALL)
+    fields: list[str] = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        decl = re.sub(r"^(const\s+)?(float|int32_t)\s*\*?", "", decl)
+        fields += [f.strip().lstrip("*").strip() for f in decl.split(",")]
+    return fields
+
+
+@pytest.mark.parametrize("cls", [
+    _lib.MrssmDims, _lib.MrssmFwdWeights, _lib.MrssmFwdIO, _lib.MrssmBwdWeights, _lib.MrssmBwdIO,
+    _lib.MmtrssmDims, _lib.MmtrssmFwdWeights, _lib.MmtrssmFwdIO, _lib.MmtrssmBwdWeights, _lib.MmtrssmBwdIO,
+])
+def test_ctypes_structs_mirror_the_header(cls: type) -> None:
+    assert [n for n, _ in cls._fields_] == _struct_fields(cls.__name__)
+
+
+def test_invalid_arguments_are_rejected_without_a_launch() -> None:
+    lib = _lib.load()
+    dims = _lib.MrssmDims(0, 4, 8, 8, 2, 2, 2, 1, 0.2, 0.8, 0, 0)  # B = 0
+    rc = lib.mtrssm_mrssm_rollout_fwd(C.byref(dims), C.byref(_lib.MrssmFwdWeights()), C.byref(_lib.MrssmFwdIO()), None)
+    assert rc == -1
+    assert b"positive" in lib.mtrssm_last_error()
+    dims = _lib.MrssmDims(2, 4, 8, 8, 2, 2, 2, 1, 0.2, 0.8, 0, 0)
+    rc = lib.mtrssm_mrssm_rollout_fwd(C.byref(dims), C.byref(_lib.MrssmFwdWeights()), C.byref(_lib.MrssmFwdIO()), None)
+    assert rc == -1
+    assert b"null" in lib.mtrssm_last_error()
+    mt = _lib.MmtrssmDims(2, 4, 8, 8, 8, 2, 2, 2, 2, 2, 1, 1.0, 4.0, 0.0, 0.75, 0.2, 0.8, 0, 0)  # tau_l = 1
+    rc = lib.mtrssm_mmtrssm_rollout_fwd(C.byref(mt), C.byref(_lib.MmtrssmFwdWeights()), C.byref(_lib.MmtrssmFwdIO()), None)
+    assert rc == -1
+    assert b"tau" in lib.mtrssm_last_error()
+    assert lib.mtrssm_sumsq(None, 10, None, None) == -1
+    assert lib.mtrssm_gaussian_nll_fwd(None, None, 1, 1, None, None) == -1
+
+
+def test_missing_library_fails_loudly(monkeypatch: pytest.MonkeyPatch, tmp_path: Path) -> None:
+    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setenv("MTRSSM_LIB", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.MtrssmLibraryError, match="no CPU or eager fallback"):
+        _lib.load()

@@ -1,0 +1,314 @@
+"""GPU (MI355X): the HIP path, called through the C-ABI, against the oracle and the golden vectors.
+
+Tolerances (fp32 path; north_star: losses 1e-4 rel, probabilities 1e-5):
+  loss / recon / kl           2e-5 relative vs golden (reference-generated)
+  deter, logits, probs        1e-5 absolute
+  one-hot samples             exact (fixture draws keep a 1e-3 margin from every CDF edge)
+  gradients                   2e-4 relative to the tensor's largest entry
+The conv encoders / decoders are build-defined (``cnn`` is absent upstream): their parity is
+HIP-build vs ``oracle/ref_cnn.py``, "parity unpinned" upstream.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.cases import CASES, build_batch, build_model, build_noise, with_sizes
+from tests.conftest import check_weight_sums, golden_batch, golden_noise, load_golden, product_from_case
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _np(t: torch.Tensor) -> np.ndarray:
+    return t.detach().float().cpu().numpy()
+
+
+def _index(stoch: torch.Tensor, cats: int, classes: int) -> np.ndarray:
+    return _np(stoch).reshape(*stoch.shape[:-1], cats, classes).argmax(-1).astype(np.int8)
+
+
+def _assert_onehot(stoch: torch.Tensor, cats: int, classes: int) -> None:
+    s = _np(stoch).reshape(*stoch.shape[:-1], cats, classes)
+    assert ((s == 0) | (s == 1)).all()
+    assert (s.sum(-1) == 1).all()
+
+
+def _to(noise: dict[str, torch.Tensor], device: str) -> dict[str, torch.Tensor]:
+    return {k: v.to(device) for k, v in noise.items()}
+
+
+@pytest.fixture(scope="module")
+def lib_loaded() -> None:
+    import multimodal_mtrssm_amd as mt
+
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    assert mt._lib.load().mtrssm_version() == 100  # noqa: SLF001
+
+
+# ---------------------------------------------------------------------------------------------
+# shared_step: losses + gradients
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", list(CASES))
+def test_shared_step_matches_golden_and_oracle(name: str, lib_loaded: None) -> None:
+    case = CASES[name]
+    fx = load_golden(name)
+    oracle = build_model(case)
+    check_weight_sums(oracle, fx)
+    batch, noise = golden_batch(fx), golden_noise(fx)
+    ref = oracle.shared_step(batch, noise)
+    ref["loss"].backward()
+    model = product_from_case(case, oracle, DEV)
+    out = model.shared_step(tuple(b.to(DEV) for b in batch), _to(noise, DEV))
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    keys = [k[5:] for k in fx if k.startswith("loss/")]
+    assert set(out) == set(keys)
+    for k in keys:
+        np.testing.assert_allclose(float(out[k]), float(fx[f"loss/{k}"]), rtol=2e-5, err_msg=f"{k} vs golden")
+        np.testing.assert_allclose(float(out[k]), float(ref[k]), rtol=2e-5, err_msg=f"{k} vs oracle")
+    ref_grads = {k: p.grad for k, p in oracle.named_parameters() if p.grad is not None}
+    got = dict(model.named_parameters())
+    for k, g in ref_grads.items():
+        assert got[k].grad is not None, k
+        scale = float(g.abs().max()) + 1e-12
+        np.testing.assert_allclose(_np(got[k].grad), g.numpy(), rtol=2e-4, atol=2e-4 * scale, err_msg=f"grad {k}")
+    # golden gradient samples (reference-generated)
+    for k in [k for k in fx if k.startswith("grad/")]:
+        g = got[k[5:]].grad.flatten()
+        stride = max(1, g.numel() // 4096)
+        scale = float(np.abs(fx[k]).max()) + 1e-12
+        np.testing.assert_allclose(_np(g[::stride]), fx[k], rtol=2e-4, atol=2e-4 * scale, err_msg=k)
+    if case.kind == "mmtrssm":  # parameters the reference never trains stay untouched (zero or no gradient)
+        for k in fx["meta/no_grad_params"].tolist():
+            assert got[k].grad is None or float(got[k].grad.abs().max()) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------
+# rollout_representation / rollout_transition / State API
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", [n for n in CASES if CASES[n].kind == "mrssm"])
+def test_mrssm_rollout_matches_golden(name: str, lib_loaded: None) -> None:
+    import multimodal_mtrssm_amd as mt
+
+    case = CASES[name]
+    d = case.dims
+    fx = load_golden(name)
+    model = product_from_case(case, build_model(case), DEV)
+    batch = tuple(b.to(DEV) for b in golden_batch(fx))
+    noise = _to(golden_noise(fx), DEV)
+    with torch.no_grad():
+        state0 = model.initial_state((batch[1][:, 0], batch[2][:, 0]), noise)
+        post, prior = model.rollout_representation(actions=batch[0], observations=(batch[1], batch[2]), prev_state=state0,
+                                                   noise=noise)
+        np.testing.assert_allclose(_np(state0.deter), fx["out/deter0"], atol=1e-5)
+        assert (_index(state0.stoch, d.cats, d.classes) == fx["out/stoch0_index"]).all()
+        np.testing.assert_allclose(_np(post.deter), fx["out/deter"], atol=1e-5)
+        np.testing.assert_allclose(_np(post.distribution.probs), fx["out/post_probs"], atol=1e-5)
+        np.testing.assert_allclose(_np(prior.distribution.probs), fx["out/prior_probs"], atol=1e-5)
+        assert (_index(post.stoch, d.cats, d.classes) == fx["out/post_index"]).all()
+        assert (_index(prior.stoch, d.cats, d.classes) == fx["out/prior_index"]).all()
+        _assert_onehot(post.stoch, d.cats, d.classes)
+        assert post.feature.shape == (case.batch, case.steps, d.deter + d.stoch)
+        # callbacks' use of the API (mrssm/callback.py:156-189)
+        q = case.query
+        start = post[:, q - 1]
+        trans = model.rollout_transition(actions=batch[0][:, q:], prev_state=start, noise={"u_prior": noise["u_trans"][:, : case.steps - q]})
+        np.testing.assert_allclose(_np(trans.deter), fx["trans/deter"], atol=1e-5)
+        np.testing.assert_allclose(_np(trans.distribution.probs), fx["trans/prior_probs"], atol=1e-5)
+        assert (_index(trans.stoch, d.cats, d.classes) == fx["trans/index"]).all()
+        joined = mt.cat_states([post[:, :q], trans], dim=1)
+        assert joined.deter.shape == post.deter.shape
+        recon = model.decode_state(joined)
+        assert recon["recon/vision"].shape == batch[5].shape
+        # KL from the distribution objects == KL from the kernel
+        kl_obj = mt.kl_divergence(post.distribution.independent(1), prior.distribution.independent(1), use_balancing=True)
+        np.testing.assert_allclose(float(kl_obj), float(post.kl_per_step.mean()), rtol=1e-5)
+        # single prior step through Transition.forward (networks.py:151-173) == first step of the prior-only scan
+        step = model.transition.forward(batch[0][:, q], start)
+        np.testing.assert_allclose(_np(step.deter), fx["trans/deter"][:, 0], atol=1e-5)
+        np.testing.assert_allclose(_np(step.distribution.probs), fx["trans/prior_probs"][:, 0], atol=1e-5)
+    with pytest.raises(TypeError):
+        model.rollout_representation(actions=batch[0], observations=batch[1], prev_state=state0)
+
+
+@pytest.mark.parametrize("name", [n for n in CASES if CASES[n].kind == "mmtrssm"])
+def test_mmtrssm_rollout_matches_golden(name: str, lib_loaded: None) -> None:
+    import multimodal_mtrssm_amd as mt
+
+    case = CASES[name]
+    d = case.dims
+    fx = load_golden(name)
+    model = product_from_case(case, build_model(case), DEV)
+    batch = tuple(b.to(DEV) for b in golden_batch(fx))
+    noise = _to(golden_noise(fx), DEV)
+    with torch.no_grad():
+        state0 = model.initial_state((batch[1][:, 0], batch[2][:, 0]), noise)
+        np.testing.assert_allclose(_np(state0.deter_h), fx["out/init_deter_h"], atol=1e-5)
+        np.testing.assert_allclose(_np(state0.deter_l), fx["out/init_deter_l"], atol=1e-5)
+        assert (_index(state0.stoch_h, d.hs_cats, d.hs_classes) == fx["out/init_index_h"]).all()
+        assert (_index(state0.stoch_l, d.ls_cats, d.ls_classes) == fx["out/init_index_l"]).all()
+        post, prior = model.rollout_representation(actions=batch[0], observations=(batch[1], batch[2]), prev_state=state0,
+                                                   noise=noise)
+        for k in ("deter_l", "deter_h", "hidden_l", "hidden_h"):
+            np.testing.assert_allclose(_np(getattr(post, k)), fx[f"out/{k}"], atol=1e-5, err_msg=k)
+        np.testing.assert_allclose(_np(post.distribution_l.probs), fx["out/post_probs_l"], atol=1e-5)
+        np.testing.assert_allclose(_np(post.distribution_h.probs), fx["out/post_probs_h"], atol=1e-5)
+        np.testing.assert_allclose(_np(prior.distribution_l.probs), fx["out/prior_probs_l"], atol=1e-5)
+        np.testing.assert_allclose(_np(prior.distribution_h.probs), fx["out/prior_probs_h"], atol=1e-5)
+        assert (_index(post.stoch_l, d.ls_cats, d.ls_classes) == fx["out/post_index_l"]).all()
+        assert (_index(post.stoch_h, d.hs_cats, d.hs_classes) == fx["out/post_index_h"]).all()
+        assert (_index(prior.stoch_l, d.ls_cats, d.ls_classes) == fx["out/prior_index_l"]).all()
+        assert (_index(prior.stoch_h, d.hs_cats, d.hs_classes) == fx["out/prior_index_h"]).all()
+        assert post.feature.shape == (case.batch, case.steps, d.feature)
+        q = case.query
+        n = case.steps - q
+        trans = model.rollout_transition(actions=batch[0][:, q:], prev_state=post[:, q - 1],
+                                         noise={"u_prior_h": noise["u_trans_h"][:, :n], "u_prior_l": noise["u_trans_l"][:, :n]})
+        np.testing.assert_allclose(_np(trans.deter_l), fx["trans/deter_l"], atol=1e-5)
+        np.testing.assert_allclose(_np(trans.deter_h), fx["trans/deter_h"], atol=1e-5)
+        assert (_index(trans.stoch_l, d.ls_cats, d.ls_classes) == fx["trans/index_l"]).all()
+        assert (_index(trans.stoch_h, d.hs_cats, d.hs_classes) == fx["trans/index_h"]).all()
+        joined = mt.cat_mtstates([post[:, :q], trans], dim=1)
+        assert joined.feature.shape == post.feature.shape
+
+
+# ---------------------------------------------------------------------------------------------
+# row-tile variants and ragged batches: every tiling gives the same answer
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["mrssm_nonsquare", "mmtrssm_default"])
+@pytest.mark.parametrize(("rows", "threads"), [(2, 256), (4, 256), (1, 512), (2, 128)])
+def test_row_tiles_agree(name: str, rows: int, threads: int, lib_loaded: None) -> None:
+    case = with_sizes(CASES[name], 5, 6)  # 5 rows: ragged for 2- and 4-row tiles
+    oracle = build_model(case)
+    batch = tuple(b.to(DEV) for b in build_batch(case))
+    noise = _to(build_noise(case), DEV)
+    model = product_from_case(case, oracle, DEV)
+    base = model.shared_step(batch, noise)
+    base["loss"].backward()
+    g0 = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    model.zero_grad()
+    model.scan_rows_per_block, model.scan_threads = rows, threads
+    out = model.shared_step(batch, noise)
+    out["loss"].backward()
+    for k in base:
+        np.testing.assert_allclose(float(out[k]), float(base[k]), rtol=1e-6, err_msg=k)
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            np.testing.assert_allclose(_np(p.grad), _np(g0[k]), rtol=1e-4, atol=1e-6 * (float(g0[k].abs().max()) + 1e-9), err_msg=k)
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE config-2 / config-3 sizes (B=64, T=50): size-independent properties
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["mrssm_cfg2dims", "mmtrssm_cfg3dims"])
+def test_full_size_properties(name: str, lib_loaded: None) -> None:
+    case = with_sizes(CASES[name], 64, 50)
+    oracle = build_model(case)
+    model = product_from_case(case, oracle, DEV)
+    batch = tuple(b.to(DEV) for b in build_batch(case))
+    noise = _to(build_noise(case), DEV)
+    d = case.dims
+    with torch.no_grad():
+        state0 = model.initial_state((batch[1][:, 0], batch[2][:, 0]), noise)
+        post, prior = model.rollout_representation(actions=batch[0], observations=(batch[1], batch[2]), prev_state=state0, noise=noise)
+        # (1) rows are independent: a sub-batch reproduces its rows of the full batch bit for bit
+        rows = slice(7, 19)
+        sub_noise = {k: v[rows] for k, v in noise.items()}
+        post_sub, _ = model.rollout_representation(actions=batch[0][rows], observations=(batch[1][rows], batch[2][rows]),
+                                                   prev_state=state0[rows], noise=sub_noise)
+        if case.kind == "mrssm":
+            assert torch.equal(post_sub.deter, post.deter[rows])
+            assert torch.equal(post_sub.stoch, post.stoch[rows])
+            _assert_onehot(post.stoch, d.cats, d.classes)
+            _assert_onehot(prior.stoch, d.cats, d.classes)
+            probs = [post.distribution.probs, prior.distribution.probs]
+            kls = [post.kl_per_step]
+        else:
+            assert torch.equal(post_sub.deter_l, post.deter_l[rows])
+            assert torch.equal(post_sub.stoch_h, post.stoch_h[rows])
+            _assert_onehot(post.stoch_l, d.ls_cats, d.ls_classes)
+            _assert_onehot(post.stoch_h, d.hs_cats, d.hs_classes)
+            probs = [post.distribution_l.probs, post.distribution_h.probs, prior.distribution_l.probs]
+            kls = [post.kl_per_step, post.kl_h_per_step]
+        # (2) every categorical is a distribution; (3) KL >= 0; (4) a prefix of the sequence is a shorter rollout
+        for p in probs:
+            np.testing.assert_allclose(_np(p.sum(-1)), 1.0, atol=1e-5)
+        for kl in kls:
+            assert float(kl.min()) > -1e-6
+            assert torch.isfinite(kl).all()
+        t_half = 20
+        half_noise = {k: (v[:, :t_half] if v.dim() == 3 else v) for k, v in noise.items()}
+        post_half, _ = model.rollout_representation(actions=batch[0][:, :t_half], observations=(batch[1][:, :t_half], batch[2][:, :t_half]),
+                                                    prev_state=state0, noise=half_noise)
+        if case.kind == "mrssm":
+            assert torch.equal(post_half.deter, post.deter[:, :t_half])
+        else:
+            assert torch.equal(post_half.deter_h, post.deter_h[:, :t_half])
+    # (5) full-size train step against the oracle on a row subset (the oracle finishes 8 rows in seconds)
+    sub = slice(0, 8)
+    sub_batch = tuple(b[sub] for b in batch)
+    sub_noise = {k: v[sub] for k, v in noise.items()}
+    out = model.shared_step(sub_batch, sub_noise)
+    ref = oracle.shared_step(tuple(b.cpu() for b in sub_batch), {k: v.cpu() for k, v in sub_noise.items()})
+    for k in out:
+        np.testing.assert_allclose(float(out[k]), float(ref[k]), rtol=1e-4, err_msg=k)
+
+
+# ---------------------------------------------------------------------------------------------
+# the small streaming kernels
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(3, 5, 1, 8, 8), (2, 7, 1, 5, 3), (4, 1, 3, 16, 16)])
+def test_gaussian_nll_kernel(shape: tuple[int, ...], lib_loaded: None) -> None:
+    import multimodal_mtrssm_amd as mt
+    from oracle.ref_model import gaussian_nll
+
+    g = torch.Generator().manual_seed(3)
+    pred = torch.randn(shape, generator=g).requires_grad_()
+    tgt = torch.randn(shape, generator=g)
+    want = gaussian_nll(pred, tgt, 3)
+    want.backward()
+    p = pred.detach().to(DEV).requires_grad_()
+    got = mt.likelihood(prediction=p, target=tgt.to(DEV), event_ndims=3)
+    (got * 1.0).backward()
+    np.testing.assert_allclose(float(got), float(want), rtol=2e-6)
+    np.testing.assert_allclose(_np(p.grad), pred.grad.numpy(), rtol=1e-6, atol=1e-8)
+    with pytest.raises(ValueError, match="same shape"):
+        mt.likelihood(prediction=p, target=tgt.to(DEV)[1:], event_ndims=3)
+
+
+def test_flat_adamw_matches_torch(lib_loaded: None) -> None:
+    import multimodal_mtrssm_amd as mt
+    from multimodal_mtrssm_amd.optim import FlatParameters
+
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(13, 7), torch.nn.Tanh(), torch.nn.Linear(7, 3)).to(DEV)
+    twin = torch.nn.Sequential(torch.nn.Linear(13, 7), torch.nn.Tanh(), torch.nn.Linear(7, 3)).to(DEV)
+    twin.load_state_dict(net.state_dict())
+    flat = FlatParameters(net)
+    opt = mt.FlatAdamW(flat, lr=1e-2, clip_norm=0.5)
+    ref = torch.optim.AdamW(twin.parameters(), lr=1e-2)
+    x = torch.randn(32, 13, device=DEV)
+    for _ in range(5):
+        opt.zero_grad()
+        net(x).square().sum().backward()
+        flat.check_views()
+        opt.step()
+        ref.zero_grad()
+        twin(x).square().sum().backward()
+        torch.nn.utils.clip_grad_norm_(twin.parameters(), 0.5)
+        ref.step()
+    for a, b in zip(net.parameters(), twin.parameters(), strict=True):
+        np.testing.assert_allclose(_np(a), _np(b), rtol=2e-5, atol=1e-6)
+
+
+def test_cpu_tensors_are_refused(lib_loaded: None) -> None:
+    """No silent fallback: the product path raises on CPU inputs."""
+    import multimodal_mtrssm_amd as mt
+
+    case = CASES["mrssm_nonsquare"]
+    model = product_from_case(case, build_model(case), "cpu")
+    with pytest.raises(mt._lib.MtrssmLibraryError):  # noqa: SLF001
+        model.shared_step(build_batch(case), build_noise(case))

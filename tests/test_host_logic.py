@@ -1,0 +1,142 @@
+"""CPU: host-side types and argument handling (the parts of the boundary that need no GPU)."""
+
+from __future__ import annotations
+
+import numpy as np
+import pytest
+import torch
+
+import multimodal_mtrssm_amd as mt
+from oracle import ref_dists
+from oracle.cases import CASES, build_batch, build_model, build_noise
+from tests.conftest import product_from_case
+
+
+def test_distribution_matches_oracle_definition() -> None:
+    g = torch.Generator().manual_seed(0)
+    logits_q, logits_p = torch.randn(3, 5, 12, generator=g), torch.randn(3, 5, 12, generator=g)
+    u = torch.rand(3, 5, 3, generator=g)
+    q, p = mt.MultiOneHotFactory(class_size=4, category_size=3)(logits_q), mt.MultiOneHotFactory(4, 3)(logits_p)
+    oq, op = ref_dists.MultiOneHotFactory(4, 3)(logits_q), ref_dists.MultiOneHotFactory(4, 3)(logits_p)
+    assert q.probs.shape == (3, 5, 3, 4)
+    torch.testing.assert_close(q.probs, oq.probs)
+    for bal in (True, False):
+        torch.testing.assert_close(mt.kl_divergence(q.independent(1), p.independent(1), use_balancing=bal),
+                                   ref_dists.kl_divergence(oq.independent(1), op.independent(1), use_balancing=bal))
+    ref_dists.TAPE.clear()
+    ref_dists.TAPE.push(u)
+    with mt.inject_uniforms([u]):
+        got = q.rsample()
+    want = oq.rsample()
+    assert torch.equal(got, want)
+    assert got.shape == (3, 5, 12)
+    assert torch.equal(got.reshape(3, 5, 3, 4).sum(-1), torch.ones(3, 5, 3))
+
+
+def test_straight_through_gradient() -> None:
+    logits = torch.randn(2, 6, requires_grad=True)
+    d = mt.MultiOneHotFactory(class_size=3, category_size=2)(logits)
+    w = torch.randn(6)
+    (d.rsample() * w).sum().backward()
+    probs = torch.softmax(logits.detach().reshape(2, 2, 3), -1)
+    gw = w.reshape(1, 2, 3)
+    want = probs * (gw - (probs * gw).sum(-1, keepdim=True))
+    torch.testing.assert_close(logits.grad, want.reshape(2, 6))
+
+
+def test_state_api() -> None:
+    f = mt.MultiOneHotFactory(class_size=4, category_size=3)
+    s = mt.State(torch.randn(2, 5, 7), f(torch.randn(2, 5, 12)))
+    assert s.feature.shape == (2, 5, 19)
+    assert torch.equal(s.feature, torch.cat([s.deter, s.stoch], -1))
+    one = s[:, 2]
+    assert one.deter.shape == (2, 7) and one.distribution.probs.shape == (2, 3, 4)
+    assert len(list(iter(s))) == 2
+    assert s.unsqueeze(0).deter.shape == (1, 2, 5, 7) and s.unsqueeze(0).squeeze(0).stoch.shape == (2, 5, 12)
+    assert s.detach().deter.requires_grad is False and s.clone().deter.data_ptr() != s.deter.data_ptr()
+    joined = mt.cat_states([s[:, :2], s[:, 2:]], dim=1)
+    assert torch.equal(joined.deter, s.deter) and torch.equal(joined.distribution.probs, s.distribution.probs)
+    stacked = mt.stack_states([s[:, t] for t in range(5)], dim=1)
+    assert torch.equal(stacked.stoch, s.stoch) and torch.equal(stacked.distribution.logits, s.distribution.logits)
+
+
+def test_mtstate_api() -> None:
+    fl, fh = mt.MultiOneHotFactory(4, 4), mt.MultiOneHotFactory(class_size=2, category_size=8)
+    kw = dict(deter_h=torch.randn(2, 5, 6), deter_l=torch.randn(2, 5, 7), distribution_h=fh(torch.randn(2, 5, 16)),
+              distribution_l=fl(torch.randn(2, 5, 16)), hidden_h=torch.randn(2, 5, 6), hidden_l=torch.randn(2, 5, 7))
+    s = mt.MTState(**kw)
+    assert s.feature.shape == (2, 5, 6 + 16 + 7 + 16)
+    assert torch.equal(s.feature, torch.cat([s.deter_h, s.stoch_h, s.deter_l, s.stoch_l], -1))  # mmtrssm/state.py:51
+    assert s[:, 1].hidden_l.shape == (2, 7) and s[:, 1].distribution_h.probs.shape == (2, 8, 2)
+    c = s.clone()
+    assert torch.equal(c.distribution_h.probs, s.distribution_h.probs)  # upstream clones distribution_l here (bug, state.py:133)
+    joined = mt.cat_mtstates([s[:, :3], s[:, 3:]], dim=1)
+    assert torch.equal(joined.deter_l, s.deter_l) and joined.hidden_h.shape == (2, 2, 6)  # keeps the LAST hidden (state.py:237)
+    stacked = mt.stack_mtstates([s[:, t] for t in range(5)], dim=1)
+    assert torch.equal(stacked.stoch_h, s.stoch_h) and torch.equal(stacked.hidden_l, s.hidden_l)
+    vec = mt.MTState(**{**kw, "hidden_h": torch.zeros(6), "hidden_l": torch.zeros(7)})
+    assert vec[:, 0].hidden_h.shape == (6,)  # 1-d hidden is passed through untouched (state.py:78-79)
+
+
+def test_constructor_validation() -> None:
+    with pytest.raises(ValueError, match="2 elements"):
+        mt.Representation(deterministic_size=4, hidden_size=4, obs_embed_size=4, distribution_config=[2, 2, 2])
+    with pytest.raises(ValueError, match="2 elements"):
+        mt.Transition(deterministic_size=4, hidden_size=4, action_size=2, distribution_config=[2], activation_name="ELU")
+    with pytest.raises(AssertionError, match="tau"):
+        mt.MTRNN(4, 4, tau=1.0)
+    t = mt.Transition(deterministic_size=4, hidden_size=6, action_size=2, distribution_config=(3, 2), activation_name="ELU")
+    assert t.rnn_cell.weight_ih.shape == (12, 6) and t.action_state_projector[0].weight.shape == (6, 8)
+    assert t.distribution_factory.class_size == 3 and t.distribution_factory.category_size == 2
+
+
+@pytest.mark.parametrize("name", ["mrssm_default", "mmtrssm_default"])
+def test_state_dict_names_match_the_reference(name: str) -> None:
+    """checkpoints interchange by name (the oracle's names were checked against the
+    reference's own modules with strict=True when the fixtures were generated)."""
+    case = CASES[name]
+    oracle = build_model(case)
+    model = product_from_case(case, oracle, "cpu")
+    assert list(model.state_dict()) == list(oracle.state_dict())
+    assert [k for k, _ in model.named_parameters()] == [k for k, _ in oracle.named_parameters()]
+    sd = model.state_dict()
+    assert sd["representation.rnn_to_post_projector.0.weight"].data_ptr() == sd["audio_representation.rnn_to_post_projector.0.weight"].data_ptr()
+    assert "transition.rnn_cell.weight_ih" in sd
+    if case.kind == "mmtrssm":
+        assert sd["transition.action_state_projector.0.weight"].shape == (32, 2)  # the dummy Transition(A=1, S=1)
+        assert {"l_rnn._d2h.weight", "h_rnn._input2h.bias", "l_posterior.0.weight", "h_posterior.2.bias"} <= set(sd)
+
+
+def test_rollout_argument_errors_and_no_cpu_fallback() -> None:
+    case = CASES["mrssm_nonsquare"]
+    model = product_from_case(case, build_model(case), "cpu")
+    batch, noise = build_batch(case), build_noise(case)
+    with pytest.raises(TypeError, match="tuple"):
+        model.rollout_representation(actions=batch[0], observations=batch[1], prev_state=None)
+    with pytest.raises(mt._lib.MtrssmLibraryError, match="no CPU fallback"):  # noqa: SLF001
+        model.shared_step(batch, noise)
+    assert model.get_observations_from_batch(batch)[1] is batch[2]
+    assert model.get_targets_from_batch(batch)["recon/audio"] is batch[4]
+    a0, v0 = model.get_initial_observation((batch[1], batch[2]))
+    assert a0.shape == batch[1][:, 0].shape and v0.shape == batch[2][:, 0].shape
+
+
+def test_encoder_decoder_match_oracle_architecture() -> None:
+    """Build-defined conv stacks: product definition == oracle definition (CPU, torch ops)."""
+    from oracle.ref_cnn import Decoder, Encoder
+
+    case = CASES["mrssm_default"]
+    torch.manual_seed(1)
+    enc, dec = Encoder(case.dims.enc_audio), Decoder(case.dims.dec_audio)
+    penc, pdec = mt.Encoder(case.dims.enc_audio), mt.Decoder(case.dims.dec_audio)
+    penc.load_state_dict(enc.state_dict())
+    pdec.load_state_dict(dec.state_dict())
+    x = torch.rand(2, 3, 1, 32, 32) * 2 - 1
+    e = enc(x)
+    assert e.shape == (2, 3, 64)
+    torch.testing.assert_close(penc(x), e)
+    f = torch.randn(2, 3, 48)
+    r = dec(f)
+    assert r.shape == (2, 3, 1, 32, 32) and float(r.abs().max()) <= 1.0
+    torch.testing.assert_close(pdec(f), r)
+    np.testing.assert_allclose(penc(x[:, 0]).detach().numpy(), e[:, 0].detach().numpy(), rtol=1e-5, atol=1e-6)
