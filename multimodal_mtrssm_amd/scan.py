@@ -59,6 +59,14 @@ def _opt(t: Tensor | None) -> Tensor | None:
     return None if t is None else _c(t)
 
 
+def _expect(**named: tuple[Tensor | None, tuple[int, ...]]) -> None:
+    """Host-side shape check of every operand before a launch (a wrong extent would fault the GPU)."""
+    for name, (t, shape) in named.items():
+        if t is not None and tuple(t.shape) != tuple(shape):
+            msg = f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}"
+            raise ValueError(msg)
+
+
 # ============================================================================================
 # MRSSM
 # ============================================================================================
@@ -75,6 +83,15 @@ class _MrssmScan(torch.autograd.Function):
         D = deter0.shape[1]
         S = cfg.cats * cfg.classes
         A = w1.shape[1] - S
+        K = cfg.cats
+        _expect(pa=(pa, (B, T, H)), pv=(pv, (B, T, H)), deter0=(deter0, (B, D)), stoch0=(stoch0, (B, S)),
+                u_post=(u_post, (B, T, K)), u_prior=(u_prior, (B, T, K)), w1=(w1, (H, A + S)), w2=(w2, (H, H)), b2=(b2, (H,)),
+                wih=(wih, (3 * D, H)), bih=(bih, (3 * D,)), whh=(whh, (3 * D, D)), bhh=(bhh, (3 * D,)), w3=(w3, (H, D)),
+                b3=(b3, (H,)), w4=(w4, (S, H)), b4=(b4, (S,)), wa2=(wa2, (S, H)), ba2=(ba2, (S,)), wv2=(wv2, (S, H)),
+                bv2=(bv2, (S,)), wa1_rows=(wa1[:, :1], (H, 1)), wv1_rows=(wv1[:, :1], (H, 1)))
+        if A < 0 or wa1.shape[1] <= D or wv1.shape[1] <= D:
+            msg = "weight shapes are inconsistent with (deter, stoch, action, embed)"
+            raise ValueError(msg)
         xa, pa, pv, deter0, stoch0, u_post = map(_c, (xa, pa, pv, deter0, stoch0, u_post))
         u_prior = _opt(u_prior)
         # forward layouts (include/mtrssm.h: wide outputs stream W^T, narrow outputs stream W)
@@ -122,6 +139,8 @@ class _MrssmScan(torch.autograd.Function):
         S = cfg.cats * cfg.classes
         if not ctx.has_prior_stoch:
             g_prior_stoch = None
+        _expect(g_deter=(g_deter, (B, T, D)), g_prior_logits=(g_prior_logits, (B, T, S)), g_post_logits=(g_post_logits, (B, T, S)),
+                g_post_stoch=(g_post_stoch, (B, T, S)), g_prior_stoch=(g_prior_stoch, (B, T, S)), g_kl=(g_kl, (B, T)))
         bw = _lib.fill(_lib.MrssmBwdWeights(), w1s_t=w1s_t, w2=_c(w2), wih=_c(wih), whh=_c(whh), wh1=wh1, w4=_c(w4), wa2=_c(wa2),
                        wv2=_c(wv2))
         g_deter0, g_stoch0 = _new(deter, B, D), _new(deter, B, S)
@@ -226,6 +245,9 @@ def mrssm_prior_rollout(transition, actions: Tensor, deter0: Tensor, stoch0: Ten
         fw = _lib.fill(_lib.MrssmFwdWeights(), **tensors)
         deter, prior_logits, prior_stoch = _new(xa, B, T, D), _new(xa, B, T, S), _new(xa, B, T, S)
         deter0, stoch0, u_prior = _c(deter0.float()), _c(stoch0.float()), _c(u_prior.float())
+        _expect(deter0=(deter0, (B, D)), stoch0=(stoch0, (B, S)), u_prior=(u_prior, (B, T, K)), xa=(xa, (B, T, H)),
+                w1=(l1.weight, (H, A + S)), wih=(cell.weight_ih, (3 * D, H)), whh=(cell.weight_hh, (3 * D, D)),
+                w3=(p1.weight, (H, D)), w4=(p2.weight, (S, H)))
         io = _lib.fill(_lib.MrssmFwdIO(), xa=xa, deter0=deter0, stoch0=stoch0, u_prior=u_prior, deter=deter,
                        prior_logits=prior_logits, prior_stoch=prior_stoch)
         act = _lib.ACT_IDS[transition.action_state_projector.activation_name]
@@ -276,6 +298,18 @@ class _MmtrssmScan(torch.autograd.Function):
         H = pa.shape[-1]
         LS, HS = cfg.kl_cats * cfg.kl_classes, cfg.kh_cats * cfg.kh_classes
         A = wxl.shape[1] - LS - HS
+        _expect(pa=(pa, (B, T, H)), pv=(pv, (B, T, H)), deter_l0=(deter_l0, (B, LD)), deter_h0=(deter_h0, (B, HD)),
+                hidden_l0=(hidden_l0, (B, LD)), hidden_h0=(hidden_h0, (B, HD)), stoch_l0=(stoch_l0, (B, LS)),
+                stoch_h0=(stoch_h0, (B, HS)), u_post_l=(u_post_l, (B, T, cfg.kl_cats)), u_post_h=(u_post_h, (B, T, cfg.kh_cats)),
+                u_prior_l=(u_prior_l, (B, T, cfg.kl_cats)), u_prior_h=(u_prior_h, (B, T, cfg.kh_cats)),
+                wxl=(wxl, (LD, A + LS + HS)), wdl=(wdl, (LD, LD)), wxh=(wxh, (HD, HS)), wdh=(wdh, (HD, HD)), bh=(bh, (HD,)),
+                wlp1=(wlp1, (H, LD)), blp1=(blp1, (H,)), wlp2=(wlp2, (LS, H)), blp2=(blp2, (LS,)), wa2=(wa2, (LS, H)),
+                ba2=(ba2, (LS,)), wv2=(wv2, (LS, H)), bv2=(bv2, (LS,)), whp1=(whp1, (H, HD)), bhp1=(bhp1, (H,)),
+                whp2=(whp2, (HS, H)), bhp2=(bhp2, (HS,)), whq1=(whq1, (H, LD + HD)), bhq1=(bhq1, (H,)), whq2=(whq2, (HS, H)),
+                bhq2=(bhq2, (HS,)), wa1_rows=(wa1[:, :1], (H, 1)), wv1_rows=(wv1[:, :1], (H, 1)))
+        if A < 0 or wa1.shape[1] <= LD or wv1.shape[1] <= LD:
+            msg = "weight shapes are inconsistent with (ld, ls, hs, action, embed)"
+            raise ValueError(msg)
         (xl, pa, pv, deter_l0, deter_h0, hidden_l0, hidden_h0, stoch_l0, stoch_h0, u_post_l, u_post_h) = map(
             _c, (xl, pa, pv, deter_l0, deter_h0, hidden_l0, hidden_h0, stoch_l0, stoch_h0, u_post_l, u_post_h))
         u_prior_l, u_prior_h = _opt(u_prior_l), _opt(u_prior_h)
@@ -467,6 +501,12 @@ def mmtrssm_prior_rollout(model, actions: Tensor, state0: dict[str, Tensor], noi
                  prior_logits_l=_new(xl, B, T, LS), prior_logits_h=_new(xl, B, T, HS), prior_stoch_l=_new(xl, B, T, LS),
                  prior_stoch_h=_new(xl, B, T, HS))
         st = {k: _c(state0[k].float()) for k in ("deter_l", "deter_h", "hidden_l", "hidden_h", "stoch_l", "stoch_h")}
+        _expect(deter_l=(st["deter_l"], (B, LD)), deter_h=(st["deter_h"], (B, HD)), hidden_l=(st["hidden_l"], (B, LD)),
+                hidden_h=(st["hidden_h"], (B, HD)), stoch_l=(st["stoch_l"], (B, LS)), stoch_h=(st["stoch_h"], (B, HS)),
+                u_prior_l=(u_l, (B, T, cfg.kl_cats)), u_prior_h=(u_h, (B, T, cfg.kh_cats)),
+                wxl=(lr._input2h.weight, (LD, A + LS + HS)), wdl=(lr._d2h.weight, (LD, LD)),  # noqa: SLF001
+                wxh=(hr._input2h.weight, (HD, HS)), wdh=(hr._d2h.weight, (HD, HD)), wlp1=(lp1.weight, (H, LD)),  # noqa: SLF001
+                wlp2=(lp2.weight, (LS, H)), whp1=(hp1.weight, (H, HD)), whp2=(hp2.weight, (HS, H)))
         io = _lib.fill(_lib.MmtrssmFwdIO(), xl=xl, deter_l0=st["deter_l"], deter_h0=st["deter_h"], hidden_l0=st["hidden_l"],
                        hidden_h0=st["hidden_h"], stoch_l0=st["stoch_l"], stoch_h0=st["stoch_h"], u_prior_l=u_l, u_prior_h=u_h, **o)
         dims = cfg.dims(B, T, LD, HD, H, 0)
