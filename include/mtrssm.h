@@ -314,6 +314,48 @@ int mtrssm_mmtrssm_rollout_bwd(const MtrssmMmtrssmDims* dims, const MtrssmMmtrss
                                const MtrssmMmtrssmBwdIO* io, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Conv encoder / decoder kernels (fp32 MFMA implicit GEMM, NCHW).  Replace the layers of the
+ * `cnn.Encoder` / `cnn.Decoder` stacks the reference YAML instantiates
+ * (mrssm/mopoe_mrssm/configs/default.yaml:31-92; called at mrssm core.py:179-180,215-216,272-273).
+ *
+ * mtrssm_conv_gather_gemm computes, for every frame n and output channel co,
+ *   out[n, co, oy*OS+QY, ox*OS+QX] = (bias[co] + sum_{ty<KH, tx<KW} sum_{c<C+C2} wp[co][ty*KW+tx][c] * pre(S[n,c,sy,sx])) * egrad
+ *   sy = oy*SS + ty*TS + OFFY, sx = ox*SS + tx*TS + OFFX (zero outside [0,Hs)x[0,Ws)),  oy < Hq, ox < Wq
+ * where S = src for c < C and the frame-independent src2 (coordinate channels) for C <= c < C+C2,
+ * pre() = act() if pre_act, and egrad = act'(actgrad_in[same element as out]) when actgrad_in != NULL.
+ *   Conv2d forward (k,s,p):            KH=KW=k, SS=s, TS=+1, OFF=-p, OS=1, Hq=Ho
+ *   Conv2d backward-data / ConvTranspose2d forward: one call per output parity class (qy,qx) in [0,s)^2 with
+ *     the taps ky = ky0 + s*ty (ky0 = (qy+p) mod s): SS=1, TS=-1, OFFY=(qy+p-ky0)/s, OS=s, QY=qy.
+ * wp is the packed weight matrix [CoutPad][KH*KW][Cpad], zero padded (Cpad % 16 == 0, CoutPad % 32 == 0,
+ * CoutPad % 64 == 0 when Cout > 32), 16-byte aligned.
+ *
+ * mtrssm_conv_weight_grad accumulates (atomically; the caller zeroes dwp)
+ *   dwp[co][ty*KW+tx][c] += sum_{n, y<Hq, x<Wq} preA(a[n,co,y,x]) * pre(S[n,c,y*SS+ty*TS+OFFY,x*SS+tx*TS+OFFX])
+ * with a of shape [N, Cout, Hq, Wq] (geometry must have OS=1, QY=QX=0).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct MtrssmConvGeom {
+  int32_t N;                    /* frames (B*T) */
+  int32_t C, Hs, Ws;            /* gathered tensor [N, C, Hs, Ws] */
+  int32_t C2;                   /* extra frame-independent channels src2 [C2, Hs, Ws] appended after C */
+  int32_t Cpad;                 /* channel extent of wp */
+  int32_t KH, KW;
+  int32_t SS, TS, OFFY, OFFX;
+  int32_t Hq, Wq;               /* output sub-grid enumerated by this call */
+  int32_t OS, QY, QX;
+  int32_t Ho, Wo;               /* full output plane */
+  int32_t Cout, CoutPad;
+  int32_t pre_act;              /* apply act() to gathered values */
+  int32_t act;                  /* MTRSSM_ACT_* */
+} MtrssmConvGeom;
+
+int mtrssm_conv_gather_gemm(const MtrssmConvGeom* g, const float* src, const float* src2, const float* wp,
+                            const float* bias, const float* actgrad_in, float* out, void* stream);
+int mtrssm_conv_weight_grad(const MtrssmConvGeom* g, const float* a, const float* src, const float* src2,
+                            int32_t pre_act_a, float* dwp, void* stream);
+/* out[c] += sum_{n, i<HW} x[n, c, i]   (bias gradients; the caller zeroes out) */
+int mtrssm_channel_sum(const float* x, int32_t N, int32_t C, int32_t HW, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Gaussian NLL with unit scale, fused reduction.  Replaces objective.likelihood
  * (objective.py:7-23) as used by compute_reconstruction_loss (mrssm/mopoe_mrssm/core.py:279-308):
  *   nll = mean_n sum_e [ 0.5 (target - pred)^2 + 0.5 log(2 pi) ],  n = B*T frames, e = C*H*W.

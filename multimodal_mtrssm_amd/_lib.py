@@ -72,6 +72,10 @@ MmtrssmBwdIO = _struct("MtrssmMmtrssmBwdIO", _ptrs(
     "g_deter_l0", "g_deter_h0", "g_hidden_l0", "g_hidden_h0", "g_stoch_l0", "g_stoch_h0",
     "d_ul", "d_uh", "d_zl1", "d_zh1", "d_lpl", "d_la", "d_lv", "d_lph", "d_lqh"))
 
+ConvGeom = _struct("MtrssmConvGeom", [(n, _i) for n in (
+    "N", "C", "Hs", "Ws", "C2", "Cpad", "KH", "KW", "SS", "TS", "OFFY", "OFFX", "Hq", "Wq", "OS", "QY", "QX", "Ho", "Wo",
+    "Cout", "CoutPad", "pre_act", "act")])
+
 # every symbol include/mtrssm.h declares (tests/test_capi.py checks the header against this list)
 SYMBOLS: dict[str, tuple[type | None, list[type]]] = {
     "mtrssm_version": (C.c_int, []),
@@ -80,6 +84,9 @@ SYMBOLS: dict[str, tuple[type | None, list[type]]] = {
     "mtrssm_mrssm_rollout_bwd": (C.c_int, [C.POINTER(MrssmDims), C.POINTER(MrssmBwdWeights), C.POINTER(MrssmBwdIO), _p]),
     "mtrssm_mmtrssm_rollout_fwd": (C.c_int, [C.POINTER(MmtrssmDims), C.POINTER(MmtrssmFwdWeights), C.POINTER(MmtrssmFwdIO), _p]),
     "mtrssm_mmtrssm_rollout_bwd": (C.c_int, [C.POINTER(MmtrssmDims), C.POINTER(MmtrssmBwdWeights), C.POINTER(MmtrssmBwdIO), _p]),
+    "mtrssm_conv_gather_gemm": (C.c_int, [C.POINTER(ConvGeom), _p, _p, _p, _p, _p, _p, _p]),
+    "mtrssm_conv_weight_grad": (C.c_int, [C.POINTER(ConvGeom), _p, _p, _p, _i, _p, _p]),
+    "mtrssm_channel_sum": (C.c_int, [_p, _i, _i, _i, _p, _p]),
     "mtrssm_gaussian_nll_fwd": (C.c_int, [_p, _p, C.c_int64, C.c_int64, _p, _p]),
     "mtrssm_gaussian_nll_bwd": (C.c_int, [_p, _p, _p, C.c_int64, C.c_int64, _p, _p]),
     "mtrssm_sumsq": (C.c_int, [_p, C.c_int64, _p, _p]),

@@ -13,9 +13,13 @@ Both take arbitrary leading batch dims (``[B,T,C,H,W]`` and ``[B,C,H,W]`` are bo
 ``mrssm/mopoe_mrssm/core.py:179-180,215-216,272-273``).  Frames are folded to one ``[B*T, C, H, W]`` batch so
 every layer is a single dense launch over all B*T frames.
 
-Round-1 status: the layers below run through MIOpen / rocBLAS via torch ops (dense library
-convolutions / GEMMs); hand-written gfx950 conv kernels with a fused tanh + Gaussian-NLL epilogue are
-the next item.
+Every convolution runs on the hand-written fp32-MFMA implicit-GEMM kernels of ``csrc/conv.hip`` (``conv.py``):
+because each stack is "activation -> conv" throughout, the activation is fused into the consumer's operand
+staging (``pre_act``) and never materialised; bias is fused into the epilogue; the backward kernels fuse the
+multiplication by act'(x).  The Linear layers are plain library GEMMs (rocBLAS via ``F.linear``); the few
+remaining elementwise ops (final activation before ``flatten``, residual adds, ``tanh``) are torch elementwise
+kernels.  No MIOpen call is made anywhere (its first-run kernel JIT costs minutes on a fresh box).
+The nn.Conv2d / nn.ConvTranspose2d / nn.Linear objects below are parameter containers only.
 """
 
 from __future__ import annotations
@@ -24,6 +28,9 @@ from typing import Any
 
 import torch
 from torch import Tensor, nn
+
+from multimodal_mtrssm_amd import _lib
+from multimodal_mtrssm_amd.conv import conv2d, conv_transpose2d
 
 
 def _act(name: str) -> nn.Module:
@@ -34,15 +41,26 @@ def _cfg(config: Any) -> dict[str, Any]:  # noqa: ANN401
     return dict(config) if isinstance(config, dict) else dict(vars(config))
 
 
+def _conv(x: Tensor, m: nn.Conv2d, *, pre_act: bool, act: int, coords: Tensor | None = None) -> Tensor:
+    return conv2d(x, m.weight, m.bias, stride=m.stride[0], padding=m.padding[0], pre_act=pre_act, act=act, coords=coords)
+
+
+def _deconv(x: Tensor, m: nn.ConvTranspose2d, *, pre_act: bool, act: int) -> Tensor:
+    return conv_transpose2d(x, m.weight, m.bias, stride=m.stride[0], padding=m.padding[0],
+                            output_padding=m.output_padding[0], pre_act=pre_act, act=act)
+
+
 class ResidualBlock(nn.Module):
+    """``x + Conv1x1(act(Conv3x3(act(x))))`` -- both activations fused into the convs' operand staging."""
+
     def __init__(self, channels: int, intermediate: int, activation_name: str) -> None:
         super().__init__()
         self.conv3 = nn.Conv2d(channels, intermediate, 3, 1, 1)
         self.conv1 = nn.Conv2d(intermediate, channels, 1, 1, 0)
-        self.act = _act(activation_name)
+        self.act_id = _lib.ACT_IDS[activation_name]
 
     def forward(self, x: Tensor) -> Tensor:
-        return x + self.conv1(self.act(self.conv3(self.act(x))))
+        return x + _conv(_conv(x, self.conv3, pre_act=True, act=self.act_id), self.conv1, pre_act=True, act=self.act_id)
 
 
 class Encoder(nn.Module):
@@ -53,6 +71,7 @@ class Encoder(nn.Module):
         self.cfg = _cfg(config)
         self.coord_conv = bool(self.cfg.get("coord_conv", False))
         self.act = _act(self.cfg["activation_name"])
+        self.act_id = _lib.ACT_IDS[self.cfg["activation_name"]]
         self.out_act = _act(self.cfg.get("out_activation_name", "Identity"))
         self.convs = nn.ModuleList()
         self.res_in: nn.Module | None = None
@@ -95,17 +114,16 @@ class Encoder(nn.Module):
             self.materialize(tuple(x.shape[-3:]))
             self.to(x.device)
         lead = x.shape[:-3]
-        x = x.reshape(-1, *x.shape[-3:])
-        if self.coord_conv:
-            x = torch.cat([x, self._coord_channels(x).unsqueeze(0).expand(x.shape[0], -1, -1, -1)], dim=1)
-        for conv in self.convs:
-            x = self.act(conv(x))
+        x = x.reshape(-1, *x.shape[-3:]).float()
+        # the coordinate channels are frame-independent: the first conv gathers them from one [2,H,W] plane
+        coords = self._coord_channels(x) if self.coord_conv else None
+        for i, conv in enumerate(self.convs):
+            x = _conv(x, conv, pre_act=i > 0, act=self.act_id, coords=coords if i == 0 else None)
         if self.res_in is not None:
-            x = self.res_in(x)
+            x = _conv(x, self.res_in, pre_act=True, act=self.act_id)
             for blk in self.res:
                 x = blk(x)
-            x = self.act(x)
-        x = x.flatten(start_dim=1)
+        x = self.act(x).flatten(start_dim=1)
         for i, lin in enumerate(self.linears):
             x = lin(x)
             if i + 1 < len(self.linears):
@@ -120,6 +138,7 @@ class Decoder(nn.Module):
         super().__init__()
         cfg = self.cfg = _cfg(config)
         self.act = _act(cfg["activation_name"])
+        self.act_id = _lib.ACT_IDS[cfg["activation_name"]]
         self.out_act = _act(cfg.get("out_activation_name", "Identity"))
         self.conv_in_shape = tuple(int(v) for v in cfg["conv_in_shape"])
         self.linears = nn.ModuleList()
@@ -154,11 +173,10 @@ class Decoder(nn.Module):
             if i + 1 < len(self.linears):
                 x = self.act(x)
         x = x.reshape(-1, *self.conv_in_shape)
-        if len(self.res) > 0:
-            for blk in self.res:
-                x = blk(x)
-            x = self.act(x)
+        for blk in self.res:
+            x = blk(x)
         for i, dc in enumerate(self.deconvs):
-            x = dc(x)
-            x = self.act(x) if i + 1 < len(self.deconvs) else self.out_act(x)
+            # "act -> deconv" everywhere except a first deconv fed straight by the Linear (no residual stack)
+            x = _deconv(x, dc, pre_act=i > 0 or len(self.res) > 0, act=self.act_id)
+        x = self.out_act(x)
         return x.reshape(*lead, *x.shape[-3:])

@@ -1,0 +1,196 @@
+"""autograd bindings of the MFMA conv kernels (``mtrssm_conv_gather_gemm`` / ``_weight_grad``).
+
+Two layer functions cover every convolution of the encoder / decoder stacks (``oracle/ref_cnn.py``):
+
+* ``conv2d(x, weight, bias, stride, padding, pre_act, act, coords)``            = ``Conv2d(act?(x ++ coords))``
+* ``conv_transpose2d(x, weight, bias, stride, padding, output_padding, pre_act, act)`` = ``ConvTranspose2d(act?(x))``
+
+Forward and both data-gradient directions are ONE kernel with different gather geometry (see
+``csrc/conv.hip``); weight gradients are the transposed implicit GEMM; bias gradients a channel sum.
+Weights are re-packed per call into the kernel's ``[CoutPad][taps][Cpad]`` layout (zero padded) with torch
+permutes -- a few KB per layer.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+from torch import Tensor
+
+from multimodal_mtrssm_amd import _lib
+
+
+def _pad_to(n: int, m: int) -> int:
+    return (n + m - 1) // m * m
+
+
+def _pads(cout: int, cin: int) -> tuple[int, int]:
+    return _pad_to(cout, 64 if cout > 32 else 32), _pad_to(cin, 16)
+
+
+def pack_weight(w: Tensor) -> Tensor:
+    """``w[O][I][kh][kw]`` -> zero-padded ``wp[OPad][kh*kw][IPad]`` (channel fastest)."""
+    o, i, kh, kw = w.shape
+    opad, ipad = _pads(o, i)
+    wp = torch.zeros(opad, kh * kw, ipad, device=w.device, dtype=torch.float32)
+    if kh * kw > 0:
+        wp[:o, :, :i] = w.permute(0, 2, 3, 1).reshape(o, kh * kw, i)
+    return wp
+
+
+def _geom(**kw: int) -> C.Structure:
+    g = _lib.ConvGeom()
+    for k, v in kw.items():
+        setattr(g, k, int(v))
+    return g
+
+
+def _gather_gemm(geom: C.Structure, src: Tensor, src2: Tensor | None, wp: Tensor, bias: Tensor | None,
+                 actgrad_in: Tensor | None, out: Tensor) -> None:
+    lib = _lib.load()
+    _lib.check(_lib.TIMERS.call(
+        "mtrssm_conv_gather_gemm", lib.mtrssm_conv_gather_gemm, C.byref(geom), _lib.ptr(src), _lib.ptr(src2), _lib.ptr(wp),
+        _lib.ptr(bias), _lib.ptr(actgrad_in), _lib.ptr(out), _lib.stream_ptr(src.device)), "mtrssm_conv_gather_gemm")
+
+
+def _conv_forward_gather(x: Tensor, coords: Tensor | None, w: Tensor, bias: Tensor | None, stride: int, pad: int,
+                         pre_act: bool, act: int, actgrad_in: Tensor | None = None) -> Tensor:  # noqa: FBT001
+    """``out = (bias + Conv2d_{w}(pre(x ++ coords))) * act'(actgrad_in)``; ``w[O][I][k][k]``."""
+    n, c, hs, ws = x.shape
+    o, i, kh, kw = w.shape
+    c2 = 0 if coords is None else coords.shape[0]
+    if i != c + c2:
+        msg = f"weight expects {i} input channels, got {c}+{c2}"
+        raise ValueError(msg)
+    ho = (hs + 2 * pad - kh) // stride + 1
+    wo = (ws + 2 * pad - kw) // stride + 1
+    wp = pack_weight(w)
+    out = torch.empty(n, o, ho, wo, device=x.device, dtype=torch.float32)
+    geom = _geom(N=n, C=c, Hs=hs, Ws=ws, C2=c2, Cpad=wp.shape[2], KH=kh, KW=kw, SS=stride, TS=1, OFFY=-pad, OFFX=-pad,
+                 Hq=ho, Wq=wo, OS=1, QY=0, QX=0, Ho=ho, Wo=wo, Cout=o, CoutPad=wp.shape[0], pre_act=int(pre_act), act=act)
+    _gather_gemm(geom, x, coords, wp, bias, actgrad_in, out)
+    return out
+
+
+def _conv_transposed_gather(y: Tensor, w: Tensor, bias: Tensor | None, stride: int, pad: int, out_hw: tuple[int, int],
+                            pre_act: bool, act: int, actgrad_in: Tensor | None = None) -> Tensor:  # noqa: FBT001
+    """``out[n,c,iy,ix] = (bias[c] + sum_{o,ky,kx} w[o][c][ky][kx] pre(y)[n,o,(iy+p-ky)/s,(ix+p-kx)/s]) * act'(actgrad_in)``.
+
+    = Conv2d backward-data (``y`` = dOut, ``w`` the conv weight) = ConvTranspose2d forward (``y`` = input, ``w`` its weight).
+    One launch per output parity class; each visits only the taps that reach it.
+    """
+    n, o, hs, ws = y.shape
+    o2, c, kh, kw = w.shape
+    if o2 != o:
+        msg = f"weight expects {o2} gathered channels, got {o}"
+        raise ValueError(msg)
+    ho, wo = out_hw
+    out = torch.empty(n, c, ho, wo, device=y.device, dtype=torch.float32)
+    for qy in range(min(stride, ho)):
+        ky0 = (qy + pad) % stride
+        for qx in range(min(stride, wo)):
+            kx0 = (qx + pad) % stride
+            wsub = w[:, :, ky0::stride, kx0::stride].permute(1, 0, 2, 3)  # [c][o][nty][ntx]
+            wp = pack_weight(wsub)
+            geom = _geom(N=n, C=o, Hs=hs, Ws=ws, C2=0, Cpad=wp.shape[2], KH=wsub.shape[2], KW=wsub.shape[3], SS=1, TS=-1,
+                         OFFY=(qy + pad - ky0) // stride, OFFX=(qx + pad - kx0) // stride,
+                         Hq=(ho - qy + stride - 1) // stride, Wq=(wo - qx + stride - 1) // stride, OS=stride, QY=qy, QX=qx,
+                         Ho=ho, Wo=wo, Cout=c, CoutPad=wp.shape[0], pre_act=int(pre_act), act=act)
+            _gather_gemm(geom, y, None, wp, bias, actgrad_in, out)
+    return out
+
+
+def _weight_grad(a: Tensor, src: Tensor, coords: Tensor | None, kh: int, kw: int, stride: int, pad: int, pre_act_a: bool,
+                 pre_act_src: bool, act: int) -> Tensor:  # noqa: FBT001
+    """``dw[o][i][ky][kx] = sum preA(a)[n,o,y,x] * pre(src ++ coords)[n,i,y*s-p+ky,x*s-p+kx]`` -> ``[O][I][kh][kw]``."""
+    lib = _lib.load()
+    n, o, hq, wq = a.shape
+    _, c, hs, ws = src.shape
+    c2 = 0 if coords is None else coords.shape[0]
+    opad, ipad = _pads(o, c + c2)
+    dwp = torch.zeros(opad, kh * kw, ipad, device=a.device, dtype=torch.float32)
+    geom = _geom(N=n, C=c, Hs=hs, Ws=ws, C2=c2, Cpad=ipad, KH=kh, KW=kw, SS=stride, TS=1, OFFY=-pad, OFFX=-pad, Hq=hq, Wq=wq,
+                 OS=1, QY=0, QX=0, Ho=hq, Wo=wq, Cout=o, CoutPad=opad, pre_act=int(pre_act_src), act=act)
+    _lib.check(_lib.TIMERS.call(
+        "mtrssm_conv_weight_grad", lib.mtrssm_conv_weight_grad, C.byref(geom), _lib.ptr(a), _lib.ptr(src), _lib.ptr(coords),
+        int(pre_act_a), _lib.ptr(dwp), _lib.stream_ptr(a.device)), "mtrssm_conv_weight_grad")
+    return dwp[:o, :, : c + c2].reshape(o, kh, kw, c + c2).permute(0, 3, 1, 2)
+
+
+def _channel_sum(x: Tensor) -> Tensor:
+    lib = _lib.load()
+    n, c, h, w = x.shape
+    out = torch.zeros(c, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.TIMERS.call("mtrssm_channel_sum", lib.mtrssm_channel_sum, _lib.ptr(x), n, c, h * w, _lib.ptr(out),
+                                _lib.stream_ptr(x.device)), "mtrssm_channel_sum")
+    return out
+
+
+class _Conv2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, coords, stride, pad, pre_act, act):  # noqa: ANN001, PLR0913
+        x, weight = x.contiguous(), weight.contiguous()
+        bias = None if bias is None else bias.contiguous()
+        coords = None if coords is None else coords.contiguous()
+        out = _conv_forward_gather(x, coords, weight, bias, stride, pad, pre_act, act)
+        ctx.save_for_backward(x, weight, coords if coords is not None else x.new_zeros(0))
+        ctx.cfg = (stride, pad, pre_act, act, coords is not None, bias is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):  # noqa: ANN001, ANN205
+        x, weight, coords = ctx.saved_tensors
+        stride, pad, pre_act, act, has_coords, has_bias = ctx.cfg
+        coords = coords if has_coords else None
+        g_out = g_out.contiguous()
+        kh, kw = weight.shape[2:]
+        c = x.shape[1]
+        g_x = None
+        if ctx.needs_input_grad[0]:
+            g_x = _conv_transposed_gather(g_out, weight[:, :c], None, stride, pad, (x.shape[2], x.shape[3]), False, act,
+                                          actgrad_in=x if pre_act else None)
+        g_w = _weight_grad(g_out, x, coords, kh, kw, stride, pad, False, pre_act, act) if ctx.needs_input_grad[1] else None
+        g_b = _channel_sum(g_out) if has_bias and ctx.needs_input_grad[2] else None
+        return g_x, g_w, g_b, None, None, None, None, None
+
+
+class _ConvTranspose2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, out_pad, pre_act, act):  # noqa: ANN001, PLR0913
+        x, weight = x.contiguous(), weight.contiguous()
+        bias = None if bias is None else bias.contiguous()
+        kh, kw = weight.shape[2:]
+        ho = (x.shape[2] - 1) * stride - 2 * pad + kh + out_pad
+        wo = (x.shape[3] - 1) * stride - 2 * pad + kw + out_pad
+        out = _conv_transposed_gather(x, weight, bias, stride, pad, (ho, wo), pre_act, act)
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (stride, pad, pre_act, act, bias is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):  # noqa: ANN001, ANN205
+        x, weight = ctx.saved_tensors
+        stride, pad, pre_act, act, has_bias = ctx.cfg
+        g_out = g_out.contiguous()
+        kh, kw = weight.shape[2:]
+        g_x = None
+        if ctx.needs_input_grad[0]:
+            # dX[n,ci,y,x] = sum_{co,ky,kx} w[ci][co][ky][kx] dOut[n,co,y*s-p+ky,x*s-p+kx]: a plain conv gather of dOut
+            g_x = _conv_forward_gather(g_out, None, weight, None, stride, pad, False, act, actgrad_in=x if pre_act else None)
+        g_w = None
+        if ctx.needs_input_grad[1]:
+            # dW[ci][co][ky][kx] = sum pre(x)[n,ci,y,x] dOut[n,co,y*s-p+ky,x*s-p+kx]
+            g_w = _weight_grad(x, g_out, None, kh, kw, stride, pad, pre_act, False, act)
+        g_b = _channel_sum(g_out) if has_bias and ctx.needs_input_grad[2] else None
+        return g_x, g_w, g_b, None, None, None, None, None
+
+
+def conv2d(x: Tensor, weight: Tensor, bias: Tensor | None, *, stride: int, padding: int, pre_act: bool, act: int,  # noqa: PLR0913
+           coords: Tensor | None = None) -> Tensor:
+    return _Conv2d.apply(x, weight, bias, coords, int(stride), int(padding), bool(pre_act), int(act))
+
+
+def conv_transpose2d(x: Tensor, weight: Tensor, bias: Tensor | None, *, stride: int, padding: int, output_padding: int,  # noqa: PLR0913
+                     pre_act: bool, act: int) -> Tensor:
+    return _ConvTranspose2d.apply(x, weight, bias, int(stride), int(padding), int(output_padding), bool(pre_act), int(act))

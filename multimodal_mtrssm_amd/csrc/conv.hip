@@ -1,0 +1,377 @@
+// Conv encoder / decoder kernels for gfx950 (MI355X): fp32 MFMA implicit GEMM over all B*T frames.
+//
+// One gather-GEMM kernel serves Conv2d forward, Conv2d backward-data, ConvTranspose2d forward and
+// ConvTranspose2d backward-data (NCHW, fp32):
+//
+//     out[n, co, oy*OS+QY, ox*OS+QX] = epi( bias[co] + sum_{tap=(ty,tx)} sum_c Wp[co][tap][c] * pre(src[n, c, sy, sx]) )
+//     sy = oy*SS + ty*TS + OFFY,   sx = ox*SS + tx*TS + OFFX        (zero outside the source plane)
+//
+//   Conv2d forward          : SS = stride, TS = +1, OFF = -pad, OS = 1
+//   transposed gather (s=1) : SS = 1, TS = -1, OFF = +pad
+//   transposed gather (s>1) : one launch per output parity class (qy,qx): only the taps that can reach
+//                             that class are visited (sub-pixel decomposition -> no multiplies by zero),
+//                             SS = 1, TS = -1, OS = stride, QY = qy
+//
+// As a GEMM: D[co][pixel] = sum_k A[co][k] B[k][pixel], k = (tap, c).  Each wave owns 32 pixels x TCO
+// channels and issues v_mfma_f32_32x32x2_f32 (exact fp32: bitwise an fma chain, 64 FLOP/clk/SIMD), the
+// A operand = packed weights [co][k] and the B operand = the gathered patch [k][pixel], both staged
+// through LDS in 16-channel chunks (double-buffered, one barrier per chunk).  Lanes = pixels on the
+// output side, so every store is a coalesced 128-byte row segment of one channel plane.
+//
+// pre() fuses the activation that precedes the layer (the stacks are "act -> conv" everywhere, see
+// oracle/ref_cnn.py), epi() fuses bias and, for the backward-data use, the multiplication by act'(x).
+//
+// The weight-gradient kernel is the transposed problem: dWp[co][tap][c] += sum_pixels A[co][pix] G[pix][c],
+// reduction over all N*H*W pixels split across workgroups, partial tiles combined with fp32 atomics.
+#include "scan_common.h"
+
+namespace mtrssm {
+
+void set_error(const char* fmt, ...);
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int kKC = 16;          // channels per K chunk
+constexpr int kTP = 128;         // pixels per workgroup tile (4 waves x 32)
+constexpr int kConvThreads = 256;
+
+__device__ __forceinline__ float act_grad_from_in(float x, int act) {
+  switch (act) {
+    case MTRSSM_ACT_RELU: return x > 0.f ? 1.f : 0.f;
+    case MTRSSM_ACT_ELU: return x > 0.f ? 1.f : expf(x);
+    case MTRSSM_ACT_TANH: { const float t = tanhf(x); return 1.f - t * t; }
+    default: return 1.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// gather-GEMM
+// ------------------------------------------------------------------------------------------------
+template <int NT>  // NT = number of 32-channel output tiles per workgroup (1 or 2)
+__global__ __launch_bounds__(kConvThreads) void conv_gather_gemm_kernel(
+    const MtrssmConvGeom g, const float* __restrict__ src, const float* __restrict__ src2, const float* __restrict__ wp,
+    const float* __restrict__ bias, const float* __restrict__ actgrad_in, float* __restrict__ out) {
+  constexpr int TCO = 32 * NT;
+  constexpr int LDW = kKC + 1;
+  __shared__ float g_lds[2][kKC][kTP];
+  __shared__ float w_lds[2][TCO][LDW];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int taps = g.KH * g.KW;
+  const int ctot = g.C + g.C2;
+  const int nchunk_c = g.Cpad / kKC;
+  const int nchunks = taps * nchunk_c;
+  const int plane_s = g.Hs * g.Ws;
+  const long ptot = (long)g.N * g.Hq * g.Wq;
+  const long p0 = (long)blockIdx.x * kTP;
+  const int co0 = blockIdx.y * TCO;
+
+  // --- staging roles: thread -> (pixel column, row group) for the patch; (row, 4-float column) for the weights
+  const int pc = tid & (kTP - 1), rg = tid >> 7;
+  const long pst = p0 + pc;
+  const bool pvalid = pst < ptot;
+  int sn = 0, soy = 0, sox = 0;
+  if (pvalid) {
+    sn = (int)(pst / (g.Hq * g.Wq));
+    const int rem = (int)(pst - (long)sn * g.Hq * g.Wq);
+    soy = rem / g.Wq;
+    sox = rem - soy * g.Wq;
+  }
+  const float* src_n = src + (size_t)sn * g.C * plane_s;
+  const int wrow = tid >> 2, wcol = (tid & 3) * 4;  // 64 rows x 16 floats per pass
+
+  float greg[kKC / 2];
+  float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  auto load_chunk = [&](int chunk) {
+    const int tap = chunk / nchunk_c, c0 = (chunk - tap * nchunk_c) * kKC;
+    const int ty = tap / g.KW, tx = tap - ty * g.KW;
+    const int sy = soy * g.SS + ty * g.TS + g.OFFY, sx = sox * g.SS + tx * g.TS + g.OFFX;
+    const bool ok = pvalid && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
+    const int off = sy * g.Ws + sx;
+#pragma unroll
+    for (int i = 0; i < kKC / 2; ++i) {
+      const int c = c0 + rg + 2 * i;
+      float v = 0.f;
+      if (ok && c < ctot) {
+        v = c < g.C ? src_n[(size_t)c * plane_s + off] : src2[(size_t)(c - g.C) * plane_s + off];
+        if (g.pre_act) v = act_fwd(v, g.act);
+      }
+      greg[i] = v;
+    }
+    if (wrow < TCO) {
+      const float* wsrc = wp + ((size_t)(co0 + wrow) * taps + tap) * g.Cpad + c0 + wcol;
+      wv = *reinterpret_cast<const float4*>(wsrc);
+    }
+  };
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < kKC / 2; ++i) g_lds[buf][rg + 2 * i][pc] = greg[i];
+    if (wrow < TCO) {
+      float* d = &w_lds[buf][wrow][wcol];
+      d[0] = wv.x; d[1] = wv.y; d[2] = wv.z; d[3] = wv.w;
+    }
+  };
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  if (nchunks > 0) {
+    load_chunk(0);
+    store_chunk(0);
+  }
+  __syncthreads();
+  const int kl = lane >> 5, il = lane & 31;
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    const int buf = chunk & 1;
+    if (chunk + 1 < nchunks) load_chunk(chunk + 1);
+#pragma unroll
+    for (int step = 0; step < kKC / 2; ++step) {
+      const float b = g_lds[buf][2 * step + kl][wave * 32 + il];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const float a = w_lds[buf][j * 32 + il][2 * step + kl];
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+      }
+    }
+    if (chunk + 1 < nchunks) store_chunk(buf ^ 1);
+    __syncthreads();
+  }
+
+  // --- epilogue: lane = pixel, registers = channels
+  const long pe = p0 + wave * 32 + il;
+  if (pe < ptot) {
+    const int n = (int)(pe / (g.Hq * g.Wq));
+    const int rem = (int)(pe - (long)n * g.Hq * g.Wq);
+    const int oy = rem / g.Wq, ox = rem - oy * g.Wq;
+    const size_t plane_o = (size_t)g.Ho * g.Wo;
+    const size_t base = (size_t)n * g.Cout * plane_o + (size_t)(oy * g.OS + g.QY) * g.Wo + (ox * g.OS + g.QX);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
+        if (co < g.Cout) {
+          float v = acc[j][r] + (bias ? bias[co] : 0.f);
+          const size_t o = base + (size_t)co * plane_o;
+          if (actgrad_in) v *= act_grad_from_in(actgrad_in[o], g.act);
+          out[o] = v;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient:  dwp[co][tap][c] += sum_{n,y,x} preA(a[n,co,y,x]) * preG(src[n,c,y*SS+ty+OFFY, x*SS+tx+OFFX])
+// grid: (c tiles of 32, taps, pixel splits); each wave reduces its own 32-pixel slices; tiles of TCO=64
+// output rows are looped inside (co tiles), partial sums combined through LDS then one atomic per element.
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(kConvThreads) void conv_weight_grad_kernel(
+    const MtrssmConvGeom g, const float* __restrict__ a, const float* __restrict__ src, const float* __restrict__ src2,
+    const int pre_act_a, float* __restrict__ dwp) {
+  constexpr int TCO = 32 * NT;
+  constexpr int LDP = 33;
+  __shared__ float a_lds[4][TCO][LDP];
+  __shared__ float g_lds[4][32][LDP];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kl = lane >> 5, il = lane & 31;
+  const int taps = g.KH * g.KW;
+  const int ctot = g.C + g.C2;
+  const int c0 = blockIdx.x * 32;
+  const int tap = blockIdx.y;
+  const int ty = tap / g.KW, tx = tap - ty * g.KW;
+  const int plane_s = g.Hs * g.Ws, plane_a = g.Hq * g.Wq;
+  const long ptot = (long)g.N * plane_a;
+  const int nsplit = gridDim.z;
+  // this workgroup's pixel range, in units of 128-pixel groups
+  const long groups = (ptot + kTP - 1) / kTP;
+  const long gper = (groups + nsplit - 1) / nsplit;
+  const long gbeg = (long)blockIdx.z * gper;
+  const long gend = gbeg + gper < groups ? gbeg + gper : groups;
+
+  for (int cot = 0; cot < g.CoutPad; cot += TCO) {
+    f32x16 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    for (long grp = gbeg; grp < gend; ++grp) {
+      // each wave stages its own 32 pixels: lane -> (pixel il, row parity kl)
+      const long p = grp * kTP + wave * 32 + il;
+      const bool pv = p < ptot;
+      int n = 0, y = 0, x = 0;
+      if (pv) {
+        n = (int)(p / plane_a);
+        const int rem = (int)(p - (long)n * plane_a);
+        y = rem / g.Wq;
+        x = rem - y * g.Wq;
+      }
+      const int sy = y * g.SS + ty * g.TS + g.OFFY, sx = x * g.SS + tx * g.TS + g.OFFX;
+      const bool ok = pv && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
+      const float* a_n = a + (size_t)n * g.Cout * plane_a + (size_t)y * g.Wq + x;
+      const float* s_n = src + (size_t)n * g.C * plane_s + (size_t)sy * g.Ws + sx;
+#pragma unroll 4
+      for (int i = 0; i < TCO / 2; ++i) {
+        const int co = cot + kl + 2 * i;
+        float v = 0.f;
+        if (pv && co < g.Cout) {
+          v = a_n[(size_t)co * plane_a];
+          if (pre_act_a) v = act_fwd(v, g.act);
+        }
+        a_lds[wave][kl + 2 * i][il] = v;
+      }
+#pragma unroll 4
+      for (int i = 0; i < 16; ++i) {
+        const int c = c0 + kl + 2 * i;
+        float v = 0.f;
+        if (ok && c < ctot) {
+          v = c < g.C ? s_n[(size_t)c * plane_s] : src2[(size_t)(c - g.C) * plane_s + (size_t)sy * g.Ws + sx];
+          if (g.pre_act) v = act_fwd(v, g.act);
+        }
+        g_lds[wave][kl + 2 * i][il] = v;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int step = 0; step < 16; ++step) {
+        const float b = g_lds[wave][il][2 * step + kl];  // B[k = pixel][j = c]
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const float av = a_lds[wave][j * 32 + il][2 * step + kl];  // A[i = co][k = pixel]
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc[j], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+    }
+
+    // combine the four waves' partial tiles through LDS (reuse a_lds as [4][TCO*32] floats), then atomics
+    float* red = &a_lds[0][0][0];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;  // co within tile
+        red[(wave * TCO + row) * LDP + il] = acc[j][r];             // col = c within tile
+      }
+    __syncthreads();
+    for (int e = tid; e < TCO * 32; e += kConvThreads) {
+      const int row = e >> 5, col = e & 31;
+      const float s = red[(0 * TCO + row) * LDP + col] + red[(1 * TCO + row) * LDP + col] + red[(2 * TCO + row) * LDP + col] +
+                      red[(3 * TCO + row) * LDP + col];
+      const int co = cot + row, c = c0 + col;
+      if (co < g.CoutPad && c < g.Cpad && s != 0.f) atomicAdd(&dwp[((size_t)co * taps + tap) * g.Cpad + c], s);
+    }
+    __syncthreads();
+  }
+}
+
+// per-channel sum over (N, H*W): out[c] += sum x[n, c, :]
+__global__ void channel_sum_kernel(const float* __restrict__ x, int N, int C, int HW, float* __restrict__ out) {
+  __shared__ float red[4];
+  const int c = blockIdx.x;
+  const long total = (long)N * HW;
+  const long per = (total + gridDim.y - 1) / gridDim.y;
+  const long beg = (long)blockIdx.y * per, end = beg + per < total ? beg + per : total;
+  float acc = 0.f;
+  for (long i = beg + threadIdx.x; i < end; i += blockDim.x) {
+    const long n = i / HW, r = i - n * HW;
+    acc += x[((size_t)n * C + c) * HW + r];
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(&out[c], red[0] + red[1] + red[2] + red[3]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host launchers
+// ------------------------------------------------------------------------------------------------
+static int check_geom(const MtrssmConvGeom* g, const char* who) {
+  if (!g || g->N <= 0 || g->C <= 0 || g->Hs <= 0 || g->Ws <= 0 || g->C2 < 0 || g->KH < 0 || g->KW < 0 || g->Hq <= 0 || g->Wq <= 0 ||
+      g->Ho <= 0 || g->Wo <= 0 || g->Cout <= 0 || g->OS <= 0) {
+    set_error("%s: bad geometry", who);
+    return MTRSSM_EINVAL;
+  }
+  if (g->Cpad % kKC || g->Cpad < g->C + g->C2 || g->CoutPad % 32 || g->CoutPad < g->Cout) {
+    set_error("%s: Cpad must be a multiple of 16 covering C+C2, CoutPad a multiple of 32 covering Cout", who);
+    return MTRSSM_EINVAL;
+  }
+  if ((g->Hq - 1) * g->OS + g->QY >= g->Ho || (g->Wq - 1) * g->OS + g->QX >= g->Wo || g->QY < 0 || g->QX < 0) {
+    set_error("%s: output sub-grid exceeds the output plane", who);
+    return MTRSSM_EINVAL;
+  }
+  if (g->Cout > 32 && g->CoutPad % 64) {
+    set_error("%s: CoutPad must be a multiple of 64 when Cout > 32", who);
+    return MTRSSM_EINVAL;
+  }
+  if (g->act < MTRSSM_ACT_IDENTITY || g->act > MTRSSM_ACT_TANH) {
+    set_error("%s: unknown activation id %d", who, g->act);
+    return MTRSSM_EINVAL;
+  }
+  return MTRSSM_OK;
+}
+
+static int launched(const char* who) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s launch failed: %s", who, hipGetErrorString(e));
+    return MTRSSM_ELAUNCH;
+  }
+  return MTRSSM_OK;
+}
+
+int conv_gather_gemm_launch(const MtrssmConvGeom* g, const float* src, const float* src2, const float* wp, const float* bias,
+                            const float* actgrad_in, float* out, hipStream_t stream) {
+  if (int rc = check_geom(g, "conv_gather_gemm")) return rc;
+  if (!src || !wp || !out || (g->C2 > 0 && !src2)) { set_error("conv_gather_gemm: null pointer"); return MTRSSM_EINVAL; }
+  if ((uintptr_t)wp & 15) { set_error("conv_gather_gemm: packed weights must be 16-byte aligned"); return MTRSSM_EINVAL; }
+  const long ptot = (long)g->N * g->Hq * g->Wq;
+  const int gx = (int)((ptot + kTP - 1) / kTP);
+  if (g->Cout > 32) {
+    dim3 grid(gx, g->CoutPad / 64);
+    hipLaunchKernelGGL(conv_gather_gemm_kernel<2>, grid, dim3(kConvThreads), 0, stream, *g, src, src2, wp, bias, actgrad_in, out);
+  } else {
+    dim3 grid(gx, 1);
+    hipLaunchKernelGGL(conv_gather_gemm_kernel<1>, grid, dim3(kConvThreads), 0, stream, *g, src, src2, wp, bias, actgrad_in, out);
+  }
+  return launched("conv_gather_gemm");
+}
+
+int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float* src, const float* src2, int pre_act_a,
+                            float* dwp, hipStream_t stream) {
+  if (int rc = check_geom(g, "conv_weight_grad")) return rc;
+  if (!a || !src || !dwp || (g->C2 > 0 && !src2)) { set_error("conv_weight_grad: null pointer"); return MTRSSM_EINVAL; }
+  if (g->OS != 1 || g->QY != 0 || g->QX != 0 || g->KH * g->KW <= 0) { set_error("conv_weight_grad: needs a plain (OS=1) geometry with taps"); return MTRSSM_EINVAL; }
+  const long ptot = (long)g->N * g->Hq * g->Wq;
+  const long groups = (ptot + kTP - 1) / kTP;
+  const int ctiles = g->Cpad / 32 + (g->Cpad % 32 ? 1 : 0);
+  const int taps = g->KH * g->KW;
+  // enough pixel splits to fill the chip (~4 workgroups per CU) without drowning in atomics
+  long want = 1024 / ((long)ctiles * taps);
+  if (want < 1) want = 1;
+  if (want > groups) want = groups;
+  if (want > 512) want = 512;
+  dim3 grid(ctiles, taps, (int)want);
+  if (g->Cout > 32)
+    hipLaunchKernelGGL(conv_weight_grad_kernel<2>, grid, dim3(kConvThreads), 0, stream, *g, a, src, src2, pre_act_a, dwp);
+  else
+    hipLaunchKernelGGL(conv_weight_grad_kernel<1>, grid, dim3(kConvThreads), 0, stream, *g, a, src, src2, pre_act_a, dwp);
+  return launched("conv_weight_grad");
+}
+
+int channel_sum_launch(const float* x, int N, int C, int HW, float* out, hipStream_t stream) {
+  if (!x || !out || N <= 0 || C <= 0 || HW <= 0) { set_error("channel_sum: bad argument"); return MTRSSM_EINVAL; }
+  const long total = (long)N * HW;
+  int splits = (int)((total + 16383) / 16384);
+  if (splits > 256) splits = 256;
+  hipLaunchKernelGGL(channel_sum_kernel, dim3(C, splits), dim3(256), 0, stream, x, N, C, HW, out);
+  return launched("channel_sum");
+}
+
+}  // namespace mtrssm

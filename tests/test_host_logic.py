@@ -121,22 +121,16 @@ def test_rollout_argument_errors_and_no_cpu_fallback() -> None:
     assert a0.shape == batch[1][:, 0].shape and v0.shape == batch[2][:, 0].shape
 
 
-def test_encoder_decoder_match_oracle_architecture() -> None:
-    """Build-defined conv stacks: product definition == oracle definition (CPU, torch ops)."""
+def test_encoder_decoder_share_the_oracle_architecture() -> None:
+    """Build-defined conv stacks: same parameters (names, shapes) as oracle/ref_cnn.py; numerics are a GPU test."""
     from oracle.ref_cnn import Decoder, Encoder
 
-    case = CASES["mrssm_default"]
-    torch.manual_seed(1)
-    enc, dec = Encoder(case.dims.enc_audio), Decoder(case.dims.dec_audio)
-    penc, pdec = mt.Encoder(case.dims.enc_audio), mt.Decoder(case.dims.dec_audio)
-    penc.load_state_dict(enc.state_dict())
-    pdec.load_state_dict(dec.state_dict())
-    x = torch.rand(2, 3, 1, 32, 32) * 2 - 1
-    e = enc(x)
-    assert e.shape == (2, 3, 64)
-    torch.testing.assert_close(penc(x), e)
-    f = torch.randn(2, 3, 48)
-    r = dec(f)
-    assert r.shape == (2, 3, 1, 32, 32) and float(r.abs().max()) <= 1.0
-    torch.testing.assert_close(pdec(f), r)
-    np.testing.assert_allclose(penc(x[:, 0]).detach().numpy(), e[:, 0].detach().numpy(), rtol=1e-5, atol=1e-6)
+    for case in (CASES["mrssm_default"], CASES["mrssm_nonsquare"]):
+        for mine, ref in ((mt.Encoder(case.dims.enc_audio), Encoder(case.dims.enc_audio)),
+                          (mt.Decoder(case.dims.dec_vision), Decoder(case.dims.dec_vision))):
+            got = {k: tuple(v.shape) for k, v in mine.state_dict().items()}
+            want = {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+            assert got == want
+    enc = mt.Encoder(CASES["mrssm_default"].dims.enc_audio)
+    with pytest.raises(mt._lib.MtrssmLibraryError, match="no CPU fallback"):  # noqa: SLF001
+        enc(torch.zeros(1, 1, 32, 32))
