@@ -271,6 +271,169 @@ __global__ __launch_bounds__(kConvThreads) void conv_weight_grad_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// weight gradient, patch-staged (v2).  Same result as conv_weight_grad_kernel, different data flow:
+//   * a workgroup owns a contiguous range of 64-pixel GROUPS (whole rows of one frame, or whole small
+//     frames) and ALL (tap, 32-channel) column tiles of dwp for one 32*NT-row block of output channels;
+//   * per group it stages the A tile [32*NT x 64 pixels] and ONE zero-haloed source patch
+//     [channels][rows with halo][cols with halo] in LDS; every tap reads the same patch at a shifted
+//     offset, so each source element is fetched once instead of once per tap and each A element feeds
+//     every column tile (18 for a 64-channel 3x3) instead of one;
+//   * the four waves split the column tiles (<= kMaxQ each, accumulators in registers across the whole
+//     pixel range), and finish with fp32 atomics shaped as 128-byte row segments.
+// Applicable when 64 % Wq == 0 and groups tile frames exactly (host-checked); otherwise v1 runs.
+// ------------------------------------------------------------------------------------------------
+constexpr int kGP = 64;    // pixels per group
+constexpr int kMaxQ = 5;   // column tiles per wave
+constexpr int kLDA = kGP + 1;
+
+struct PatchGeom {
+  int rpg, rp, ipg, ph, pw, ps_raw, ps;
+  __host__ __device__ PatchGeom(const MtrssmConvGeom& g, int gp) {
+    rpg = gp / g.Wq;
+    rp = rpg < g.Hq ? rpg : g.Hq;
+    ipg = rpg / rp;
+    ph = (rp - 1) * g.SS + g.KH;
+    pw = (g.Wq - 1) * g.SS + g.KW;
+    ps_raw = ipg * ph * pw;
+    ps = ps_raw | 1;  // odd channel stride: conflict-free when lanes index channels
+  }
+};
+
+template <int NT>
+__global__ __launch_bounds__(kConvThreads) void conv_weight_grad_patch_kernel(
+    const MtrssmConvGeom g, const float* __restrict__ a, const float* __restrict__ src, const float* __restrict__ src2,
+    const int pre_act_a, float* __restrict__ dwp) {
+  constexpr int TCO = 32 * NT;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const PatchGeom pg(g, kGP);
+  const int ctot = g.C + g.C2;
+  float* a_lds = lds;                          // [TCO][kLDA]
+  float* patch = a_lds + TCO * kLDA;           // [ctot][ps]
+  int* pixtab = reinterpret_cast<int*>(patch + (size_t)ctot * pg.ps);  // [kGP]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kl = lane >> 5, il = lane & 31;
+  const int taps = g.KH * g.KW;
+  const int nct = (ctot + 31) / 32;
+  const int nq = taps * nct;
+  const int co0 = blockIdx.y * TCO;
+  const int plane_s = g.Hs * g.Ws, plane_a = g.Hq * g.Wq;
+  const long ptot = (long)g.N * plane_a;
+  const long groups = (ptot + kGP - 1) / kGP;
+  const long gper = (groups + gridDim.x - 1) / gridDim.x;
+  const long gbeg = (long)blockIdx.x * gper;
+  const long gend = gbeg + gper < groups ? gbeg + gper : groups;
+
+  // pixel -> patch offset (identical for every group)
+  if (tid < kGP) {
+    const int row = tid / g.Wq, ox = tid - row * g.Wq;
+    const int ip = row / pg.rp, lr = row - ip * pg.rp;
+    pixtab[tid] = ip * pg.ph * pg.pw + lr * g.SS * pg.pw + ox * g.SS;
+  }
+  // this wave's column tiles
+  int cbase[kMaxQ], qtap[kMaxQ], qc[kMaxQ];
+  int nsl = 0;
+#pragma unroll
+  for (int s = 0; s < kMaxQ; ++s) {
+    const int q = wave + 4 * s;
+    cbase[s] = -1; qtap[s] = 0; qc[s] = 0;
+    if (q < nq) {
+      nsl = s + 1;
+      const int tap = q / nct, ct = q - tap * nct;
+      const int ty = tap / g.KW, tx = tap - ty * g.KW;
+      const int c = ct * 32 + il;
+      qtap[s] = tap;
+      qc[s] = c;
+      if (c < ctot) cbase[s] = c * pg.ps + ty * pg.pw + tx;
+    }
+  }
+  f32x16 acc[kMaxQ][NT];
+#pragma unroll
+  for (int s = 0; s < kMaxQ; ++s)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[s][j][r] = 0.f;
+
+  const int apix = tid & (kGP - 1), arow0 = tid >> 6;  // A staging: pixel column, rows arow0 + 4 i
+  for (long grp = gbeg; grp < gend; ++grp) {
+    const long p0 = grp * kGP;
+    // ---- stage A
+    {
+      const long p = p0 + apix;
+      const bool pv = p < ptot;
+      int n = 0, rem = 0;
+      if (pv) { n = (int)(p / plane_a); rem = (int)(p - (long)n * plane_a); }
+      const float* a_n = a + (size_t)n * g.Cout * plane_a + rem;
+#pragma unroll 4
+      for (int i = 0; i < TCO / 4; ++i) {
+        const int row = arow0 + 4 * i, co = co0 + row;
+        float v = 0.f;
+        if (pv && co < g.Cout) {
+          v = a_n[(size_t)co * plane_a];
+          if (pre_act_a) v = act_fwd(v, g.act);
+        }
+        a_lds[row * kLDA + apix] = v;
+      }
+    }
+    // ---- stage the source patch (zero halo)
+    {
+      const int n0 = (int)(p0 / plane_a);
+      const int r0 = (int)((p0 - (long)n0 * plane_a) / g.Wq);  // first output row of the group (0 when ipg > 1)
+      const int sy0 = r0 * g.SS + g.OFFY, sx0 = g.OFFX;
+      const int phw = pg.ph * pg.pw;
+      const int total = ctot * pg.ps_raw;
+      for (int e = tid; e < total; e += kConvThreads) {
+        const int c = e / pg.ps_raw, r = e - c * pg.ps_raw;
+        const int ip = r / phw, q = r - ip * phw;
+        const int pr = q / pg.pw, pcn = q - pr * pg.pw;
+        const int n = n0 + ip, sy = sy0 + pr, sx = sx0 + pcn;
+        float v = 0.f;
+        if (n < g.N && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws) {
+          v = c < g.C ? src[((size_t)n * g.C + c) * plane_s + (size_t)sy * g.Ws + sx]
+                      : src2[(size_t)(c - g.C) * plane_s + (size_t)sy * g.Ws + sx];
+          if (g.pre_act) v = act_fwd(v, g.act);
+        }
+        patch[c * pg.ps + r] = v;
+      }
+    }
+    __syncthreads();
+    // ---- MFMA: D[co][c] += sum_pix A[co][pix] * patch[c][pix shifted by tap]
+#pragma unroll 2
+    for (int step = 0; step < kGP / 2; ++step) {
+      const int pix = 2 * step + kl;
+      const int poff = pixtab[pix];
+      float av[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) av[j] = a_lds[(j * 32 + il) * kLDA + pix];
+#pragma unroll
+      for (int s = 0; s < kMaxQ; ++s) {
+        if (s < nsl) {
+          const float b = cbase[s] >= 0 ? patch[cbase[s] + poff] : 0.f;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[s][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], b, acc[s][j], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lanes il = consecutive c -> 128-byte atomic row segments
+#pragma unroll
+  for (int s = 0; s < kMaxQ; ++s) {
+    if (s < nsl && qc[s] < ctot) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
+          if (co < g.Cout) atomicAdd(&dwp[((size_t)co * taps + qtap[s]) * g.Cpad + qc[s]], acc[s][j][r]);
+        }
+    }
+  }
+}
+
 // per-channel sum over (N, H*W): out[c] += sum x[n, c, :]
 __global__ void channel_sum_kernel(const float* __restrict__ x, int N, int C, int HW, float* __restrict__ out) {
   __shared__ float red[4];
@@ -349,9 +512,35 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
   if (!a || !src || !dwp || (g->C2 > 0 && !src2)) { set_error("conv_weight_grad: null pointer"); return MTRSSM_EINVAL; }
   if (g->OS != 1 || g->QY != 0 || g->QX != 0 || g->KH * g->KW <= 0) { set_error("conv_weight_grad: needs a plain (OS=1) geometry with taps"); return MTRSSM_EINVAL; }
   const long ptot = (long)g->N * g->Hq * g->Wq;
+  const int taps = g->KH * g->KW;
+  const int ctot = g->C + g->C2;
+  // ---- patch-staged kernel when the 64-pixel groups tile the frames exactly
+  if (g->TS == 1 && g->Wq <= kGP && kGP % g->Wq == 0) {
+    const PatchGeom pg(*g, kGP);
+    const bool tiles = (g->Hq % pg.rpg == 0) || (pg.rpg % g->Hq == 0);
+    const int nq = taps * ((ctot + 31) / 32);
+    const int tco = g->Cout > 32 ? 64 : 32;
+    const size_t lds = ((size_t)tco * kLDA + (size_t)ctot * pg.ps + kGP) * sizeof(float);
+    if (tiles && nq <= 4 * kMaxQ && lds <= 96 * 1024) {
+      const long groups = (ptot + kGP - 1) / kGP;
+      const int cotiles = g->Cout > 32 ? g->CoutPad / 64 : 1;
+      long splits = 512 / cotiles;  // ~2 workgroups per CU: enough to hide staging, few enough atomics
+      if (splits > groups) splits = groups;
+      if (splits < 1) splits = 1;
+      dim3 grid((unsigned)splits, cotiles);
+      if (g->Cout > 32) {
+        if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(conv_weight_grad_patch_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(conv_weight_grad_patch_kernel<2>, grid, dim3(kConvThreads), lds, stream, *g, a, src, src2, pre_act_a, dwp);
+      } else {
+        if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(conv_weight_grad_patch_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(conv_weight_grad_patch_kernel<1>, grid, dim3(kConvThreads), lds, stream, *g, a, src, src2, pre_act_a, dwp);
+      }
+      return launched("conv_weight_grad(patch)");
+    }
+  }
+  // ---- general kernel
   const long groups = (ptot + kTP - 1) / kTP;
   const int ctiles = g->Cpad / 32 + (g->Cpad % 32 ? 1 : 0);
-  const int taps = g->KH * g->KW;
   // enough pixel splits to fill the chip (~4 workgroups per CU) without drowning in atomics
   long want = 1024 / ((long)ctiles * taps);
   if (want < 1) want = 1;

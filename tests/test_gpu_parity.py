@@ -268,6 +268,11 @@ CONV_CASES = [
     (2, 64, 8, 8, 128, 3, 1, 1, True, False),   # decoder residual 3x3, Cout = 128 (two workgroup rows)
     (4, 128, 4, 4, 64, 1, 1, 0, True, False),   # 1x1
     (1, 20, 5, 6, 40, 3, 1, 1, False, False),   # Cin, Cout not multiples of the tile sizes
+    (3, 16, 16, 16, 32, 3, 2, 1, True, False),  # stride-2 patch, 8x8 output: one frame per 64-pixel group
+    (2, 8, 32, 32, 16, 3, 2, 1, True, False),   # 16x16 output: four-row groups
+    (2, 3, 64, 64, 8, 3, 2, 1, False, True),    # 32x32 output: two-row groups, coordinate channels
+    (9, 32, 4, 4, 64, 3, 1, 1, True, False),    # 4x4 planes: four frames per group, ragged last group
+    (3, 64, 16, 4, 64, 3, 1, 1, True, False),   # 16x4 audio plane
 ]
 
 
@@ -307,6 +312,10 @@ DECONV_CASES = [
     (2, 16, 8, 8, 1, 4, 2, 1, 0, True),    # last decoder layer: one output channel
     (2, 8, 5, 3, 4, 3, 2, 1, 1, False),    # odd kernel, output_padding
     (2, 12, 6, 5, 7, 3, 1, 1, 0, True),    # stride 1
+    (3, 64, 8, 8, 32, 4, 2, 1, 0, True),   # decoder shapes: patch-staged weight gradient with 16 taps
+    (2, 32, 16, 16, 16, 4, 2, 1, 0, True),
+    (2, 16, 32, 32, 1, 4, 2, 1, 0, True),
+    (5, 64, 16, 4, 32, 4, 2, 1, 0, True),  # audio decoder plane
 ]
 
 
