@@ -366,15 +366,20 @@ __global__ __launch_bounds__(kConvThreads) void conv_weight_grad_patch_kernel(
       int n = 0, rem = 0;
       if (pv) { n = (int)(p / plane_a); rem = (int)(p - (long)n * plane_a); }
       const float* a_n = a + (size_t)n * g.Cout * plane_a + rem;
-#pragma unroll 4
-      for (int i = 0; i < TCO / 4; ++i) {
-        const int row = arow0 + 4 * i, co = co0 + row;
-        float v = 0.f;
-        if (pv && co < g.Cout) {
-          v = a_n[(size_t)co * plane_a];
-          if (pre_act_a) v = act_fwd(v, g.act);
+      // batches of 8 independent loads per lane: the staging phase is latency-bound otherwise
+#pragma unroll
+      for (int ib = 0; ib < TCO / 4; ib += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int co = co0 + arow0 + 4 * (ib + u);
+          v[u] = (pv && co < g.Cout) ? a_n[(size_t)co * plane_a] : 0.f;
         }
-        a_lds[row * kLDA + apix] = v;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int row = arow0 + 4 * (ib + u);
+          a_lds[row * kLDA + apix] = pre_act_a ? act_fwd(v[u], g.act) : v[u];
+        }
       }
     }
     // ---- stage the source patch (zero halo)
@@ -383,19 +388,33 @@ __global__ __launch_bounds__(kConvThreads) void conv_weight_grad_patch_kernel(
       const int r0 = (int)((p0 - (long)n0 * plane_a) / g.Wq);  // first output row of the group (0 when ipg > 1)
       const int sy0 = r0 * g.SS + g.OFFY, sx0 = g.OFFX;
       const int phw = pg.ph * pg.pw;
-      const int total = ctot * pg.ps_raw;
-      for (int e = tid; e < total; e += kConvThreads) {
-        const int c = e / pg.ps_raw, r = e - c * pg.ps_raw;
+      // wave w stages channels w, w+4, ...; lanes walk the patch positions r (decoded once per r: three
+      // integer divisions) and issue 8 independent channel loads at a time
+      for (int rb = 0; rb < pg.ps_raw; rb += 64) {
+        const int r = rb + lane;
+        const bool rv = r < pg.ps_raw;
         const int ip = r / phw, q = r - ip * phw;
         const int pr = q / pg.pw, pcn = q - pr * pg.pw;
         const int n = n0 + ip, sy = sy0 + pr, sx = sx0 + pcn;
-        float v = 0.f;
-        if (n < g.N && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws) {
-          v = c < g.C ? src[((size_t)n * g.C + c) * plane_s + (size_t)sy * g.Ws + sx]
-                      : src2[(size_t)(c - g.C) * plane_s + (size_t)sy * g.Ws + sx];
-          if (g.pre_act) v = act_fwd(v, g.act);
+        const bool ok = rv && n < g.N && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
+        const size_t off = (size_t)sy * g.Ws + sx;
+        const float* s_n = src + (size_t)n * g.C * plane_s + off;
+        for (int cb = wave; cb < ctot; cb += 32) {
+          float v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int c = cb + 4 * u;
+            v[u] = 0.f;
+            if (ok && c < ctot) v[u] = c < g.C ? s_n[(size_t)c * plane_s] : src2[(size_t)(c - g.C) * plane_s + off];
+          }
+          if (rv) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int c = cb + 4 * u;
+              if (c < ctot) patch[c * pg.ps + r] = (g.pre_act && ok) ? act_fwd(v[u], g.act) : v[u];
+            }
+          }
         }
-        patch[c * pg.ps + r] = v;
       }
     }
     __syncthreads();
@@ -430,6 +449,174 @@ __global__ __launch_bounds__(kConvThreads) void conv_weight_grad_patch_kernel(
           const int co = co0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
           if (co < g.Cout) atomicAdd(&dwp[((size_t)co * taps + qtap[s]) * g.Cpad + qc[s]], acc[s][j][r]);
         }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Thin layers (few channels on big planes: first encoder conv 3->8, last decoder deconv 16->1 ...):
+// a 32x32 MFMA tile would be >90 % padding and the layers are HBM-bound anyway, so they run on the VALU.
+// gather: one thread per output pixel, COT output channels in registers, weights broadcast from LDS.
+// ------------------------------------------------------------------------------------------------
+constexpr int kThinMaxK = 256;  // taps * channels
+
+template <int COT>
+__global__ __launch_bounds__(kConvThreads) void conv_gather_thin_kernel(
+    const MtrssmConvGeom g, const float* __restrict__ src, const float* __restrict__ src2, const float* __restrict__ wp,
+    const float* __restrict__ bias, const float* __restrict__ actgrad_in, float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float w_lds[kThinMaxK * COT];
+  const int tid = threadIdx.x;
+  const int taps = g.KH * g.KW, ctot = g.C + g.C2;
+  const int K = taps * ctot;
+  for (int e = tid; e < K * COT; e += kConvThreads) {
+    const int k = e / COT, co = e - k * COT;
+    const int tap = k / ctot, c = k - tap * ctot;
+    w_lds[e] = co < g.Cout ? wp[((size_t)co * taps + tap) * g.Cpad + c] : 0.f;
+  }
+  __syncthreads();
+  const long ptot = (long)g.N * g.Hq * g.Wq;
+  const long p = (long)blockIdx.x * kConvThreads + tid;
+  if (p >= ptot) return;
+  const int n = (int)(p / (g.Hq * g.Wq));
+  const int rem = (int)(p - (long)n * g.Hq * g.Wq);
+  const int oy = rem / g.Wq, ox = rem - oy * g.Wq;
+  const int plane_s = g.Hs * g.Ws;
+  const float* src_n = src + (size_t)n * g.C * plane_s;
+  float acc[COT];
+#pragma unroll
+  for (int j = 0; j < COT; ++j) acc[j] = (bias && j < g.Cout) ? bias[j] : 0.f;
+  for (int ty = 0; ty < g.KH; ++ty) {
+    const int sy = oy * g.SS + ty * g.TS + g.OFFY;
+    if (sy < 0 || sy >= g.Hs) continue;
+    for (int tx = 0; tx < g.KW; ++tx) {
+      const int sx = ox * g.SS + tx * g.TS + g.OFFX;
+      if (sx < 0 || sx >= g.Ws) continue;
+      const int off = sy * g.Ws + sx;
+      const float* wk = w_lds + (size_t)(ty * g.KW + tx) * ctot * COT;
+      for (int c = 0; c < ctot; ++c) {
+        float v = c < g.C ? src_n[(size_t)c * plane_s + off] : src2[(size_t)(c - g.C) * plane_s + off];
+        if (g.pre_act) v = act_fwd(v, g.act);
+#pragma unroll
+        for (int j = 0; j < COT; ++j) acc[j] = fmaf(v, wk[c * COT + j], acc[j]);
+      }
+    }
+  }
+  const size_t plane_o = (size_t)g.Ho * g.Wo;
+  const size_t base = (size_t)n * g.Cout * plane_o + (size_t)(oy * g.OS + g.QY) * g.Wo + (ox * g.OS + g.QX);
+#pragma unroll
+  for (int j = 0; j < COT; ++j) {
+    if (j < g.Cout) {
+      const size_t o = base + (size_t)j * plane_o;
+      float v = acc[j];
+      if (actgrad_in) v *= act_grad_from_in(actgrad_in[o], g.act);
+      out[o] = v;
+    }
+  }
+}
+
+// weight gradient of a thin layer: same group / patch staging as the patch kernel, but each thread owns up to
+// kThinOut output elements (co, tap, c) and reduces over the group's 64 pixels with VALU fmas.
+constexpr int kThinOut = 5;
+
+__global__ __launch_bounds__(kConvThreads) void conv_weight_grad_thin_kernel(
+    const MtrssmConvGeom g, const float* __restrict__ a, const float* __restrict__ src, const float* __restrict__ src2,
+    const int pre_act_a, float* __restrict__ dwp) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const PatchGeom pg(g, kGP);
+  const int ctot = g.C + g.C2;
+  float* a_lds = lds;                                   // [Cout][kLDA]
+  float* patch = a_lds + (size_t)g.Cout * kLDA;         // [ctot][ps]
+  int* pixtab = reinterpret_cast<int*>(patch + (size_t)ctot * pg.ps);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int taps = g.KH * g.KW;
+  const int n_out = g.Cout * taps * ctot;
+  const int plane_s = g.Hs * g.Ws, plane_a = g.Hq * g.Wq;
+  const long ptot = (long)g.N * plane_a;
+  const long groups = (ptot + kGP - 1) / kGP;
+  const long gper = (groups + gridDim.x - 1) / gridDim.x;
+  const long gbeg = (long)blockIdx.x * gper;
+  const long gend = gbeg + gper < groups ? gbeg + gper : groups;
+  if (tid < kGP) {
+    const int row = tid / g.Wq, ox = tid - row * g.Wq;
+    const int ip = row / pg.rp, lr = row - ip * pg.rp;
+    pixtab[tid] = ip * pg.ph * pg.pw + lr * g.SS * pg.pw + ox * g.SS;
+  }
+  int arow[kThinOut], pbase[kThinOut];
+  float acc[kThinOut];
+#pragma unroll
+  for (int s = 0; s < kThinOut; ++s) {
+    const int o = tid + s * kConvThreads;  // o = (co * taps + tap) * ctot + c
+    acc[s] = 0.f;
+    arow[s] = -1;
+    pbase[s] = 0;
+    if (o < n_out) {
+      const int co = o / (taps * ctot), r = o - co * taps * ctot;
+      const int tap = r / ctot, c = r - tap * ctot;
+      const int ty = tap / g.KW, tx = tap - ty * g.KW;
+      arow[s] = co * kLDA;
+      pbase[s] = c * pg.ps + ty * pg.pw + tx;
+    }
+  }
+  const int apix = tid & (kGP - 1), arow0 = tid >> 6;
+  for (long grp = gbeg; grp < gend; ++grp) {
+    const long p0 = grp * kGP;
+    {
+      const long p = p0 + apix;
+      const bool pv = p < ptot;
+      int n = 0, rem = 0;
+      if (pv) { n = (int)(p / plane_a); rem = (int)(p - (long)n * plane_a); }
+      const float* a_n = a + (size_t)n * g.Cout * plane_a + rem;
+      for (int row = arow0; row < g.Cout; row += 4) {
+        float v = pv ? a_n[(size_t)row * plane_a] : 0.f;
+        if (pre_act_a) v = act_fwd(v, g.act);
+        a_lds[row * kLDA + apix] = v;
+      }
+    }
+    {
+      const int n0 = (int)(p0 / plane_a);
+      const int r0 = (int)((p0 - (long)n0 * plane_a) / g.Wq);
+      const int sy0 = r0 * g.SS + g.OFFY, sx0 = g.OFFX;
+      const int phw = pg.ph * pg.pw;
+      for (int rb = 0; rb < pg.ps_raw; rb += 64) {
+        const int r = rb + lane;
+        const bool rv = r < pg.ps_raw;
+        const int ip = r / phw, q = r - ip * phw;
+        const int pr = q / pg.pw, pcn = q - pr * pg.pw;
+        const int n = n0 + ip, sy = sy0 + pr, sx = sx0 + pcn;
+        const bool ok = rv && n < g.N && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
+        const size_t off = (size_t)sy * g.Ws + sx;
+        const float* s_n = src + (size_t)n * g.C * plane_s + off;
+        for (int c = wave; c < ctot; c += 4) {
+          float v = 0.f;
+          if (ok) {
+            v = c < g.C ? s_n[(size_t)c * plane_s] : src2[(size_t)(c - g.C) * plane_s + off];
+            if (g.pre_act) v = act_fwd(v, g.act);
+          }
+          if (rv) patch[c * pg.ps + r] = v;
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < kThinOut; ++s) {
+      if (arow[s] >= 0) {
+        const float* ar = a_lds + arow[s];
+        const float* pb = patch + pbase[s];
+        float t = 0.f;
+#pragma unroll 8
+        for (int pix = 0; pix < kGP; ++pix) t = fmaf(ar[pix], pb[pixtab[pix]], t);
+        acc[s] += t;
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int s = 0; s < kThinOut; ++s) {
+    const int o = tid + s * kConvThreads;
+    if (o < n_out) {
+      const int co = o / (taps * ctot), r = o - co * taps * ctot;
+      const int tap = r / ctot, c = r - tap * ctot;
+      atomicAdd(&dwp[((size_t)co * taps + tap) * g.Cpad + c], acc[s]);
     }
   }
 }
@@ -495,6 +682,16 @@ int conv_gather_gemm_launch(const MtrssmConvGeom* g, const float* src, const flo
   if (!src || !wp || !out || (g->C2 > 0 && !src2)) { set_error("conv_gather_gemm: null pointer"); return MTRSSM_EINVAL; }
   if ((uintptr_t)wp & 15) { set_error("conv_gather_gemm: packed weights must be 16-byte aligned"); return MTRSSM_EINVAL; }
   const long ptot = (long)g->N * g->Hq * g->Wq;
+  if (g->Cout <= 16 && g->KH * g->KW * (g->C + g->C2) <= kThinMaxK) {  // thin layer: VALU kernel
+    const dim3 grid((unsigned)((ptot + kConvThreads - 1) / kConvThreads));
+    if (g->Cout <= 2)
+      hipLaunchKernelGGL(conv_gather_thin_kernel<2>, grid, dim3(kConvThreads), 0, stream, *g, src, src2, wp, bias, actgrad_in, out);
+    else if (g->Cout <= 8)
+      hipLaunchKernelGGL(conv_gather_thin_kernel<8>, grid, dim3(kConvThreads), 0, stream, *g, src, src2, wp, bias, actgrad_in, out);
+    else
+      hipLaunchKernelGGL(conv_gather_thin_kernel<16>, grid, dim3(kConvThreads), 0, stream, *g, src, src2, wp, bias, actgrad_in, out);
+    return launched("conv_gather_gemm(thin)");
+  }
   const int gx = (int)((ptot + kTP - 1) / kTP);
   if (g->Cout > 32) {
     dim3 grid(gx, g->CoutPad / 64);
@@ -521,6 +718,15 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
     const int nq = taps * ((ctot + 31) / 32);
     const int tco = g->Cout > 32 ? 64 : 32;
     const size_t lds = ((size_t)tco * kLDA + (size_t)ctot * pg.ps + kGP) * sizeof(float);
+    const int n_out = g->Cout * taps * ctot;
+    const size_t lds_thin = ((size_t)g->Cout * kLDA + (size_t)ctot * pg.ps + kGP) * sizeof(float);
+    if (tiles && n_out <= kThinOut * kConvThreads && lds_thin <= 64 * 1024) {  // thin layer: VALU reduction
+      const long groups = (ptot + kGP - 1) / kGP;
+      long splits = 1024;
+      if (splits > groups) splits = groups;
+      hipLaunchKernelGGL(conv_weight_grad_thin_kernel, dim3((unsigned)splits), dim3(kConvThreads), lds_thin, stream, *g, a, src, src2, pre_act_a, dwp);
+      return launched("conv_weight_grad(thin)");
+    }
     if (tiles && nq <= 4 * kMaxQ && lds <= 96 * 1024) {
       const long groups = (ptot + kGP - 1) / kGP;
       const int cotiles = g->Cout > 32 ? g->CoutPad / 64 : 1;
