@@ -454,6 +454,142 @@ __global__ __launch_bounds__(kConvThreads) void conv_weight_grad_patch_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// gather-GEMM, patch-staged (v2).  One workgroup = one 128-pixel group (whole rows of a frame, or whole
+// small frames) x 32*NT output channels.  Per 16-channel chunk the zero-haloed source patch is staged ONCE
+// (activation applied once per element) and every tap reads it at a shifted offset; v1 re-gathers and
+// re-activates the same pixels for each of the KH*KW taps, which made it VALU/L1-bound.
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(kConvThreads) void conv_gather_gemm_patch_kernel(
+    const MtrssmConvGeom g, const float* __restrict__ src, const float* __restrict__ src2, const float* __restrict__ wp,
+    const float* __restrict__ bias, const float* __restrict__ actgrad_in, float* __restrict__ out) {
+  constexpr int TCO = 32 * NT;
+  constexpr int LDW = kKC + 1;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const PatchGeom pg(g, kTP);
+  float* patch = lds;                                            // [kKC][ps]
+  float* w_lds = patch + (size_t)kKC * pg.ps;                    // [2][TCO][LDW]
+  int* rtab = reinterpret_cast<int*>(w_lds + 2 * TCO * LDW);     // [ps_raw]: (frame-in-group << 26) | plane offset, or -1
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kl = lane >> 5, il = lane & 31;
+  const int taps = g.KH * g.KW;
+  const int ctot = g.C + g.C2;
+  const int plane_s = g.Hs * g.Ws, plane_q = g.Hq * g.Wq;
+  const long ptot = (long)g.N * plane_q;
+  const long p0 = (long)blockIdx.x * kTP;
+  const int co0 = blockIdx.y * TCO;
+  const int n0 = (int)(p0 / plane_q);
+  const int r0 = (int)((p0 - (long)n0 * plane_q) / g.Wq);
+
+  // patch position -> source offset, once per workgroup
+  {
+    const int khm = g.TS > 0 ? 0 : g.KH - 1, kwm = g.TS > 0 ? 0 : g.KW - 1;
+    const int sy0 = r0 * g.SS + g.OFFY - khm, sx0 = g.OFFX - kwm;
+    const int phw = pg.ph * pg.pw;
+    for (int r = tid; r < pg.ps_raw; r += kConvThreads) {
+      const int ip = r / phw, q = r - ip * phw;
+      const int pr = q / pg.pw, pcn = q - pr * pg.pw;
+      const int sy = sy0 + pr, sx = sx0 + pcn;
+      const bool ok = n0 + ip < g.N && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
+      rtab[r] = ok ? ((ip << 26) | (sy * g.Ws + sx)) : -1;
+    }
+  }
+  // this lane's pixel -> patch offset (B operand: lane il = pixel)
+  int pixoff;
+  {
+    const int pix = wave * 32 + il;
+    const int row = pix / g.Wq, ox = pix - row * g.Wq;
+    const int ip = row / pg.rp, lr = row - ip * pg.rp;
+    pixoff = ip * pg.ph * pg.pw + lr * g.SS * pg.pw + ox * g.SS;
+  }
+  const int wrow = tid >> 2, wcol = (tid & 3) * 4;
+  float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto load_w = [&](int tap, int c0) {
+    if (wrow < TCO) wv = *reinterpret_cast<const float4*>(wp + ((size_t)(co0 + wrow) * taps + tap) * g.Cpad + c0 + wcol);
+  };
+  auto store_w = [&](int buf) {
+    if (wrow < TCO) {
+      float* d = w_lds + ((size_t)buf * TCO + wrow) * LDW + wcol;
+      d[0] = wv.x; d[1] = wv.y; d[2] = wv.z; d[3] = wv.w;
+    }
+  };
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  const float* src_n0 = src + (size_t)n0 * g.C * plane_s;
+  __syncthreads();  // rtab
+  int wbuf = 0;
+  for (int c0 = 0; c0 < g.Cpad && taps > 0; c0 += kKC) {
+    // ---- stage the patch chunk: wave w -> channels c0 + w + 4u, lanes -> patch positions
+    for (int rb = 0; rb < pg.ps_raw; rb += 64) {
+      const int r = rb + lane;
+      const bool rv = r < pg.ps_raw;
+      const int t = rv ? rtab[r] : -1;
+      const bool ok = t >= 0;
+      const int ip = t >> 26, off = t & ((1 << 26) - 1);
+      const float* s_n = src_n0 + (size_t)ip * g.C * plane_s + off;
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = c0 + wave + 4 * u;
+        v[u] = 0.f;
+        if (ok && c < ctot) v[u] = c < g.C ? s_n[(size_t)c * plane_s] : src2[(size_t)(c - g.C) * plane_s + off];
+      }
+      if (rv) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) patch[(wave + 4 * u) * pg.ps + r] = (g.pre_act && ok) ? act_fwd(v[u], g.act) : v[u];
+      }
+    }
+    load_w(0, c0);
+    store_w(wbuf);
+    __syncthreads();
+    for (int tap = 0; tap < taps; ++tap) {
+      if (tap + 1 < taps) load_w(tap + 1, c0);
+      const int ty = tap / g.KW, tx = tap - ty * g.KW;
+      const int tapoff = g.TS > 0 ? ty * pg.pw + tx : (g.KH - 1 - ty) * pg.pw + (g.KW - 1 - tx);
+      const float* pb = patch + pixoff + tapoff + kl * pg.ps;
+      const float* wb = w_lds + ((size_t)wbuf * TCO + il) * LDW + kl;
+#pragma unroll
+      for (int step = 0; step < kKC / 2; ++step) {
+        const float b = pb[2 * step * pg.ps];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[j * 32 * LDW + 2 * step], b, acc[j], 0, 0, 0);
+      }
+      if (tap + 1 < taps) store_w(wbuf ^ 1);
+      __syncthreads();
+      wbuf ^= 1;
+    }
+  }
+
+  const long pe = p0 + wave * 32 + il;
+  if (pe < ptot) {
+    const int n = (int)(pe / plane_q);
+    const int rem = (int)(pe - (long)n * plane_q);
+    const int oy = rem / g.Wq, ox = rem - oy * g.Wq;
+    const size_t plane_o = (size_t)g.Ho * g.Wo;
+    const size_t base = (size_t)n * g.Cout * plane_o + (size_t)(oy * g.OS + g.QY) * g.Wo + (ox * g.OS + g.QX);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
+        if (co < g.Cout) {
+          float v = acc[j][r] + (bias ? bias[co] : 0.f);
+          const size_t o = base + (size_t)co * plane_o;
+          if (actgrad_in) v *= act_grad_from_in(actgrad_in[o], g.act);
+          out[o] = v;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Thin layers (few channels on big planes: first encoder conv 3->8, last decoder deconv 16->1 ...):
 // a 32x32 MFMA tile would be >90 % padding and the layers are HBM-bound anyway, so they run on the VALU.
 // gather: one thread per output pixel, COT output channels in registers, weights broadcast from LDS.
@@ -642,6 +778,8 @@ __global__ void channel_sum_kernel(const float* __restrict__ x, int N, int C, in
 // ------------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------------
+static bool plane_fits_26bit(const MtrssmConvGeom* g) { return (long)g->Hs * g->Ws < (1L << 26); }
+
 static int check_geom(const MtrssmConvGeom* g, const char* who) {
   if (!g || g->N <= 0 || g->C <= 0 || g->Hs <= 0 || g->Ws <= 0 || g->C2 < 0 || g->KH < 0 || g->KW < 0 || g->Hq <= 0 || g->Wq <= 0 ||
       g->Ho <= 0 || g->Wo <= 0 || g->Cout <= 0 || g->OS <= 0) {
@@ -693,6 +831,22 @@ int conv_gather_gemm_launch(const MtrssmConvGeom* g, const float* src, const flo
     return launched("conv_gather_gemm(thin)");
   }
   const int gx = (int)((ptot + kTP - 1) / kTP);
+  if ((g->TS == 1 || g->TS == -1) && g->Wq <= kTP && kTP % g->Wq == 0 && g->KH * g->KW > 0 && plane_fits_26bit(g)) {
+    const PatchGeom pg(*g, kTP);
+    const bool tiles = (g->Hq % pg.rpg == 0) || (pg.rpg % g->Hq == 0);
+    const int tco = g->Cout > 32 ? 64 : 32;
+    const size_t lds = ((size_t)kKC * pg.ps + 2 * (size_t)tco * (kKC + 1) + pg.ps_raw) * sizeof(float);
+    if (tiles && pg.ipg < 32 && lds <= 64 * 1024) {
+      if (g->Cout > 32) {
+        dim3 grid(gx, g->CoutPad / 64);
+        hipLaunchKernelGGL(conv_gather_gemm_patch_kernel<2>, grid, dim3(kConvThreads), lds, stream, *g, src, src2, wp, bias, actgrad_in, out);
+      } else {
+        dim3 grid(gx, 1);
+        hipLaunchKernelGGL(conv_gather_gemm_patch_kernel<1>, grid, dim3(kConvThreads), lds, stream, *g, src, src2, wp, bias, actgrad_in, out);
+      }
+      return launched("conv_gather_gemm(patch)");
+    }
+  }
   if (g->Cout > 32) {
     dim3 grid(gx, g->CoutPad / 64);
     hipLaunchKernelGGL(conv_gather_gemm_kernel<2>, grid, dim3(kConvThreads), 0, stream, *g, src, src2, wp, bias, actgrad_in, out);
