@@ -46,6 +46,10 @@ extern "C" {
 
 int mtrssm_version(void);
 const char* mtrssm_last_error(void);
+/* name of the device kernel the calling thread's most recent entry-point call launched (as rocprofv3 prints it,
+ * without the argument list), e.g. "mtrssm::conv_gather_gemm_patch_kernel<2>": lets a caller key its own HIP-event
+ * timings exactly like a kernel trace. */
+const char* mtrssm_last_kernel(void);
 
 /* ------------------------------------------------------------------------------------------
  * MoPoE-MRSSM scan.  Replaces the T loop of MoPoE_MRSSM.rollout_representation

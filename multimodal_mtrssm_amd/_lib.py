@@ -80,6 +80,7 @@ ConvGeom = _struct("MtrssmConvGeom", [(n, _i) for n in (
 SYMBOLS: dict[str, tuple[type | None, list[type]]] = {
     "mtrssm_version": (C.c_int, []),
     "mtrssm_last_error": (C.c_char_p, []),
+    "mtrssm_last_kernel": (C.c_char_p, []),
     "mtrssm_mrssm_rollout_fwd": (C.c_int, [C.POINTER(MrssmDims), C.POINTER(MrssmFwdWeights), C.POINTER(MrssmFwdIO), _p]),
     "mtrssm_mrssm_rollout_bwd": (C.c_int, [C.POINTER(MrssmDims), C.POINTER(MrssmBwdWeights), C.POINTER(MrssmBwdIO), _p]),
     "mtrssm_mmtrssm_rollout_fwd": (C.c_int, [C.POINTER(MmtrssmDims), C.POINTER(MmtrssmFwdWeights), C.POINTER(MmtrssmFwdIO), _p]),
@@ -147,34 +148,43 @@ class KernelTimers:
     """Optional HIP-event timing of the library's launches (used by bench.py for the roofline line).
 
     The kernels are enqueued on torch's CURRENT stream, so ``torch.cuda.Event`` records on that same
-    stream bracket exactly the launch.  Disabled (zero overhead) unless ``enable()`` was called.
+    stream bracket exactly the launch.  Rows are keyed by the device kernel's name as rocprofv3 prints it
+    (``mtrssm_last_kernel()``), and carry the algorithmic FLOPs / bytes the caller states for the launch.
+    Disabled (zero overhead) unless ``enable()`` was called.
     """
 
     def __init__(self) -> None:
         self.on = False
-        self._events: dict[str, list[tuple[torch.cuda.Event, torch.cuda.Event]]] = {}
+        self._rows: dict[str, list[tuple[torch.cuda.Event, torch.cuda.Event, float, float]]] = {}
 
     def enable(self) -> None:
         self.on = True
-        self._events = {}
+        self._rows = {}
 
     def disable(self) -> None:
         self.on = False
 
-    def call(self, name: str, fn, *args) -> int:  # noqa: ANN001, ANN002
+    def call(self, name: str, fn, *args, flops: float = 0.0, nbytes: float = 0.0) -> int:  # noqa: ANN001, ANN002
         if not self.on:
             return fn(*args)
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         start.record()
         rc = fn(*args)
         end.record()
-        self._events.setdefault(name, []).append((start, end))
+        kernel = load().mtrssm_last_kernel()
+        key = kernel.decode() if kernel else name
+        self._rows.setdefault(key, []).append((start, end, flops, nbytes))
         return rc
 
-    def summary(self) -> dict[str, float]:
-        """Average milliseconds per launch, by entry point."""
+    def summary(self) -> dict[str, dict[str, float]]:
+        """Per device kernel: launches, total / average milliseconds, algorithmic FLOPs and bytes (totals)."""
         torch.cuda.synchronize()
-        return {k: sum(s.elapsed_time(e) for s, e in v) / len(v) for k, v in self._events.items()}
+        out: dict[str, dict[str, float]] = {}
+        for k, rows in self._rows.items():
+            total = sum(s.elapsed_time(e) for s, e, _, _ in rows)
+            out[k] = {"launches": len(rows), "total_ms": total, "avg_ms": total / len(rows),
+                      "flops": sum(r[2] for r in rows), "bytes": sum(r[3] for r in rows)}
+        return out
 
 
 TIMERS = KernelTimers()

@@ -49,9 +49,14 @@ def _geom(**kw: int) -> C.Structure:
 def _gather_gemm(geom: C.Structure, src: Tensor, src2: Tensor | None, wp: Tensor, bias: Tensor | None,
                  actgrad_in: Tensor | None, out: Tensor) -> None:
     lib = _lib.load()
+    # algorithmic work of this launch: 2 FLOPs per (output element, tap, real channel); bytes = source read once + output written once
+    pixels = geom.N * geom.Hq * geom.Wq
+    flops = 2.0 * pixels * geom.Cout * geom.KH * geom.KW * (geom.C + geom.C2)
+    nbytes = 4.0 * (geom.N * geom.C * geom.Hs * geom.Ws + pixels * geom.Cout * (2 if actgrad_in is not None else 1))
     _lib.check(_lib.TIMERS.call(
         "mtrssm_conv_gather_gemm", lib.mtrssm_conv_gather_gemm, C.byref(geom), _lib.ptr(src), _lib.ptr(src2), _lib.ptr(wp),
-        _lib.ptr(bias), _lib.ptr(actgrad_in), _lib.ptr(out), _lib.stream_ptr(src.device)), "mtrssm_conv_gather_gemm")
+        _lib.ptr(bias), _lib.ptr(actgrad_in), _lib.ptr(out), _lib.stream_ptr(src.device), flops=flops, nbytes=nbytes),
+        "mtrssm_conv_gather_gemm")
 
 
 def _conv_forward_gather(x: Tensor, coords: Tensor | None, w: Tensor, bias: Tensor | None, stride: int, pad: int,
@@ -112,9 +117,11 @@ def _weight_grad(a: Tensor, src: Tensor, coords: Tensor | None, kh: int, kw: int
     dwp = torch.zeros(opad, kh * kw, ipad, device=a.device, dtype=torch.float32)
     geom = _geom(N=n, C=c, Hs=hs, Ws=ws, C2=c2, Cpad=ipad, KH=kh, KW=kw, SS=stride, TS=1, OFFY=-pad, OFFX=-pad, Hq=hq, Wq=wq,
                  OS=1, QY=0, QX=0, Ho=hq, Wo=wq, Cout=o, CoutPad=opad, pre_act=int(pre_act_src), act=act)
+    flops = 2.0 * n * hq * wq * o * kh * kw * (c + c2)
+    nbytes = 4.0 * (a.numel() + src.numel())
     _lib.check(_lib.TIMERS.call(
         "mtrssm_conv_weight_grad", lib.mtrssm_conv_weight_grad, C.byref(geom), _lib.ptr(a), _lib.ptr(src), _lib.ptr(coords),
-        int(pre_act_a), _lib.ptr(dwp), _lib.stream_ptr(a.device)), "mtrssm_conv_weight_grad")
+        int(pre_act_a), _lib.ptr(dwp), _lib.stream_ptr(a.device), flops=flops, nbytes=nbytes), "mtrssm_conv_weight_grad")
     return dwp[:o, :, : c + c2].reshape(o, kh, kw, c + c2).permute(0, 3, 1, 2)
 
 

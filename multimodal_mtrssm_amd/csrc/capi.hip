@@ -7,6 +7,9 @@
 namespace mtrssm {
 
 static thread_local char g_err[512] = "";
+static thread_local const char* g_kernel = "";
+
+void set_last_kernel(const char* name) { g_kernel = name; }
 
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -34,6 +37,7 @@ using namespace mtrssm;
 
 MTRSSM_API int mtrssm_version(void) { return MTRSSM_VERSION; }
 MTRSSM_API const char* mtrssm_last_error(void) { return g_err; }
+MTRSSM_API const char* mtrssm_last_kernel(void) { return g_kernel; }
 
 MTRSSM_API int mtrssm_mrssm_rollout_fwd(const MtrssmMrssmDims* d, const MtrssmMrssmFwdWeights* w, const MtrssmMrssmFwdIO* io, void* stream) {
   return mrssm_fwd_launch(d, w, io, static_cast<hipStream_t>(stream));

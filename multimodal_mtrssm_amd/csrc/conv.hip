@@ -28,6 +28,7 @@
 namespace mtrssm {
 
 void set_error(const char* fmt, ...);
+void set_last_kernel(const char* name);
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
@@ -823,11 +824,11 @@ int conv_gather_gemm_launch(const MtrssmConvGeom* g, const float* src, const flo
   if (g->Cout <= 16 && g->KH * g->KW * (g->C + g->C2) <= kThinMaxK) {  // thin layer: VALU kernel
     const dim3 grid((unsigned)((ptot + kConvThreads - 1) / kConvThreads));
     if (g->Cout <= 2)
-      hipLaunchKernelGGL(conv_gather_thin_kernel<2>, grid, dim3(kConvThreads), 0, stream, *g, src, src2, wp, bias, actgrad_in, out);
+      { set_last_kernel("mtrssm::conv_gather_thin_kernel<2>"); hipLaunchKernelGGL(conv_gather_thin_kernel<2>, grid, dim3(kConvThreads), 0, stream, *g, src, src2, wp, bias, actgrad_in, out); }
     else if (g->Cout <= 8)
-      hipLaunchKernelGGL(conv_gather_thin_kernel<8>, grid, dim3(kConvThreads), 0, stream, *g, src, src2, wp, bias, actgrad_in, out);
+      { set_last_kernel("mtrssm::conv_gather_thin_kernel<8>"); hipLaunchKernelGGL(conv_gather_thin_kernel<8>, grid, dim3(kConvThreads), 0, stream, *g, src, src2, wp, bias, actgrad_in, out); }
     else
-      hipLaunchKernelGGL(conv_gather_thin_kernel<16>, grid, dim3(kConvThreads), 0, stream, *g, src, src2, wp, bias, actgrad_in, out);
+      { set_last_kernel("mtrssm::conv_gather_thin_kernel<16>"); hipLaunchKernelGGL(conv_gather_thin_kernel<16>, grid, dim3(kConvThreads), 0, stream, *g, src, src2, wp, bias, actgrad_in, out); }
     return launched("conv_gather_gemm(thin)");
   }
   const int gx = (int)((ptot + kTP - 1) / kTP);
@@ -839,20 +840,20 @@ int conv_gather_gemm_launch(const MtrssmConvGeom* g, const float* src, const flo
     if (tiles && pg.ipg < 32 && lds <= 64 * 1024) {
       if (g->Cout > 32) {
         dim3 grid(gx, g->CoutPad / 64);
-        hipLaunchKernelGGL(conv_gather_gemm_patch_kernel<2>, grid, dim3(kConvThreads), lds, stream, *g, src, src2, wp, bias, actgrad_in, out);
+        { set_last_kernel("mtrssm::conv_gather_gemm_patch_kernel<2>"); hipLaunchKernelGGL(conv_gather_gemm_patch_kernel<2>, grid, dim3(kConvThreads), lds, stream, *g, src, src2, wp, bias, actgrad_in, out); }
       } else {
         dim3 grid(gx, 1);
-        hipLaunchKernelGGL(conv_gather_gemm_patch_kernel<1>, grid, dim3(kConvThreads), lds, stream, *g, src, src2, wp, bias, actgrad_in, out);
+        { set_last_kernel("mtrssm::conv_gather_gemm_patch_kernel<1>"); hipLaunchKernelGGL(conv_gather_gemm_patch_kernel<1>, grid, dim3(kConvThreads), lds, stream, *g, src, src2, wp, bias, actgrad_in, out); }
       }
       return launched("conv_gather_gemm(patch)");
     }
   }
   if (g->Cout > 32) {
     dim3 grid(gx, g->CoutPad / 64);
-    hipLaunchKernelGGL(conv_gather_gemm_kernel<2>, grid, dim3(kConvThreads), 0, stream, *g, src, src2, wp, bias, actgrad_in, out);
+    { set_last_kernel("mtrssm::conv_gather_gemm_kernel<2>"); hipLaunchKernelGGL(conv_gather_gemm_kernel<2>, grid, dim3(kConvThreads), 0, stream, *g, src, src2, wp, bias, actgrad_in, out); }
   } else {
     dim3 grid(gx, 1);
-    hipLaunchKernelGGL(conv_gather_gemm_kernel<1>, grid, dim3(kConvThreads), 0, stream, *g, src, src2, wp, bias, actgrad_in, out);
+    { set_last_kernel("mtrssm::conv_gather_gemm_kernel<1>"); hipLaunchKernelGGL(conv_gather_gemm_kernel<1>, grid, dim3(kConvThreads), 0, stream, *g, src, src2, wp, bias, actgrad_in, out); }
   }
   return launched("conv_gather_gemm");
 }
@@ -878,7 +879,7 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
       const long groups = (ptot + kGP - 1) / kGP;
       long splits = 1024;
       if (splits > groups) splits = groups;
-      hipLaunchKernelGGL(conv_weight_grad_thin_kernel, dim3((unsigned)splits), dim3(kConvThreads), lds_thin, stream, *g, a, src, src2, pre_act_a, dwp);
+      { set_last_kernel("mtrssm::conv_weight_grad_thin_kernel"); hipLaunchKernelGGL(conv_weight_grad_thin_kernel, dim3((unsigned)splits), dim3(kConvThreads), lds_thin, stream, *g, a, src, src2, pre_act_a, dwp); }
       return launched("conv_weight_grad(thin)");
     }
     if (tiles && nq <= 4 * kMaxQ && lds <= 96 * 1024) {
@@ -890,10 +891,10 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
       dim3 grid((unsigned)splits, cotiles);
       if (g->Cout > 32) {
         if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(conv_weight_grad_patch_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(conv_weight_grad_patch_kernel<2>, grid, dim3(kConvThreads), lds, stream, *g, a, src, src2, pre_act_a, dwp);
+        { set_last_kernel("mtrssm::conv_weight_grad_patch_kernel<2>"); hipLaunchKernelGGL(conv_weight_grad_patch_kernel<2>, grid, dim3(kConvThreads), lds, stream, *g, a, src, src2, pre_act_a, dwp); }
       } else {
         if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(conv_weight_grad_patch_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(conv_weight_grad_patch_kernel<1>, grid, dim3(kConvThreads), lds, stream, *g, a, src, src2, pre_act_a, dwp);
+        { set_last_kernel("mtrssm::conv_weight_grad_patch_kernel<1>"); hipLaunchKernelGGL(conv_weight_grad_patch_kernel<1>, grid, dim3(kConvThreads), lds, stream, *g, a, src, src2, pre_act_a, dwp); }
       }
       return launched("conv_weight_grad(patch)");
     }
@@ -908,9 +909,9 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
   if (want > 512) want = 512;
   dim3 grid(ctiles, taps, (int)want);
   if (g->Cout > 32)
-    hipLaunchKernelGGL(conv_weight_grad_kernel<2>, grid, dim3(kConvThreads), 0, stream, *g, a, src, src2, pre_act_a, dwp);
+    { set_last_kernel("mtrssm::conv_weight_grad_kernel<2>"); hipLaunchKernelGGL(conv_weight_grad_kernel<2>, grid, dim3(kConvThreads), 0, stream, *g, a, src, src2, pre_act_a, dwp); }
   else
-    hipLaunchKernelGGL(conv_weight_grad_kernel<1>, grid, dim3(kConvThreads), 0, stream, *g, a, src, src2, pre_act_a, dwp);
+    { set_last_kernel("mtrssm::conv_weight_grad_kernel<1>"); hipLaunchKernelGGL(conv_weight_grad_kernel<1>, grid, dim3(kConvThreads), 0, stream, *g, a, src, src2, pre_act_a, dwp); }
   return launched("conv_weight_grad");
 }
 
@@ -919,7 +920,7 @@ int channel_sum_launch(const float* x, int N, int C, int HW, float* out, hipStre
   const long total = (long)N * HW;
   int splits = (int)((total + 16383) / 16384);
   if (splits > 256) splits = 256;
-  hipLaunchKernelGGL(channel_sum_kernel, dim3(C, splits), dim3(256), 0, stream, x, N, C, HW, out);
+  { set_last_kernel("mtrssm::channel_sum_kernel"); hipLaunchKernelGGL(channel_sum_kernel, dim3(C, splits), dim3(256), 0, stream, x, N, C, HW, out); }
   return launched("channel_sum");
 }
 

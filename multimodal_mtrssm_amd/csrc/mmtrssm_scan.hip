@@ -7,6 +7,7 @@
 namespace mtrssm {
 
 void set_error(const char* fmt, ...);
+void set_last_kernel(const char* name);
 
 struct MmtLds {
   // slh = [stoch_l ; stoch_h] contiguous (the MTRNN input vector without the action part)
@@ -366,7 +367,7 @@ __global__ void mmtrssm_bwd_kernel(const MtrssmMmtrssmDims dm, const MtrssmMmtrs
 // host launchers
 // ------------------------------------------------------------------------------------------------
 template <typename Kern, typename... Args>
-static int launch_mmt(Kern kern, int grid, int threads, size_t lds_bytes, hipStream_t stream, Args... args) {
+static int launch_mmt(const char* name, Kern kern, int grid, int threads, size_t lds_bytes, hipStream_t stream, Args... args) {
   if (lds_bytes > 160 * 1024) {
     set_error("mmtrssm scan needs %zu bytes of LDS per workgroup (> 160 KiB): dims too large for the row-parallel regime", lds_bytes);
     return MTRSSM_ELDS;
@@ -375,6 +376,7 @@ static int launch_mmt(Kern kern, int grid, int threads, size_t lds_bytes, hipStr
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) { set_error("hipFuncSetAttribute(max dynamic LDS=%zu): %s", lds_bytes, hipGetErrorString(e)); return MTRSSM_ELAUNCH; }
   }
+  set_last_kernel(name);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds_bytes, stream, args...);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("kernel launch failed: %s", hipGetErrorString(e)); return MTRSSM_ELAUNCH; }
@@ -429,8 +431,8 @@ int mmtrssm_fwd_launch(const MtrssmMmtrssmDims* d, const MtrssmMmtrssmFwdWeights
   if (rb > threads / kWave) { set_error("rows_per_block %d exceeds waves per block %d", rb, threads / kWave); return MTRSSM_EINVAL; }
 #define MTRSSM_CASE(R)                                                                                 \
   case R:                                                                                               \
-    return d->post ? launch_mmt(mmtrssm_fwd_kernel<R, true>, grid, threads, lds, stream, *d, *w, *io)   \
-                   : launch_mmt(mmtrssm_fwd_kernel<R, false>, grid, threads, lds, stream, *d, *w, *io);
+    return d->post ? launch_mmt("mtrssm::mmtrssm_fwd_kernel<" #R ", true>", mmtrssm_fwd_kernel<R, true>, grid, threads, lds, stream, *d, *w, *io)   \
+                   : launch_mmt("mtrssm::mmtrssm_fwd_kernel<" #R ", false>", mmtrssm_fwd_kernel<R, false>, grid, threads, lds, stream, *d, *w, *io);
   switch (rb) {
     MTRSSM_CASE(1)
     MTRSSM_CASE(2)
@@ -456,9 +458,9 @@ int mmtrssm_bwd_launch(const MtrssmMmtrssmDims* d, const MtrssmMmtrssmBwdWeights
   const size_t lds = (size_t)rb * L.stride * sizeof(float);
   if (rb > threads / kWave) { set_error("rows_per_block %d exceeds waves per block %d", rb, threads / kWave); return MTRSSM_EINVAL; }
   switch (rb) {
-    case 1: return launch_mmt(mmtrssm_bwd_kernel<1>, grid, threads, lds, stream, *d, *w, *io);
-    case 2: return launch_mmt(mmtrssm_bwd_kernel<2>, grid, threads, lds, stream, *d, *w, *io);
-    case 4: return launch_mmt(mmtrssm_bwd_kernel<4>, grid, threads, lds, stream, *d, *w, *io);
+    case 1: return launch_mmt("mtrssm::mmtrssm_bwd_kernel<1>", mmtrssm_bwd_kernel<1>, grid, threads, lds, stream, *d, *w, *io);
+    case 2: return launch_mmt("mtrssm::mmtrssm_bwd_kernel<2>", mmtrssm_bwd_kernel<2>, grid, threads, lds, stream, *d, *w, *io);
+    case 4: return launch_mmt("mtrssm::mmtrssm_bwd_kernel<4>", mmtrssm_bwd_kernel<4>, grid, threads, lds, stream, *d, *w, *io);
     default: set_error("rows_per_block must be 1, 2 or 4 (got %d)", rb); return MTRSSM_EINVAL;
   }
 }

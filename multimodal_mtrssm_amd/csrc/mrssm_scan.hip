@@ -330,6 +330,7 @@ __global__ void mrssm_bwd_kernel(const MtrssmMrssmDims dm, const MtrssmMrssmBwdW
 // host launchers
 // ------------------------------------------------------------------------------------------------
 void set_error(const char* fmt, ...);
+void set_last_kernel(const char* name);
 
 static int pick_rows(int B, int requested, int lds_floats_per_row) {
   if (requested > 0) return requested;
@@ -341,7 +342,7 @@ static int pick_rows(int B, int requested, int lds_floats_per_row) {
 }
 
 template <typename Kern, typename... Args>
-static int launch(Kern kern, int grid, int threads, size_t lds_bytes, hipStream_t stream, Args... args) {
+static int launch(const char* name, Kern kern, int grid, int threads, size_t lds_bytes, hipStream_t stream, Args... args) {
   if (lds_bytes > 160 * 1024) {
     set_error("scan kernel needs %zu bytes of LDS per workgroup (> 160 KiB): dims too large for the row-parallel regime", lds_bytes);
     return MTRSSM_ELDS;
@@ -353,6 +354,7 @@ static int launch(Kern kern, int grid, int threads, size_t lds_bytes, hipStream_
       return MTRSSM_ELAUNCH;
     }
   }
+  set_last_kernel(name);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds_bytes, stream, args...);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -399,8 +401,8 @@ int mrssm_fwd_launch(const MtrssmMrssmDims* d, const MtrssmMrssmFwdWeights* w, c
   }
 #define MTRSSM_FWD_CASE(R)                                                                          \
   case R:                                                                                            \
-    return d->post ? launch(mrssm_fwd_kernel<R, true>, grid, threads, lds, stream, *d, *w, *io)      \
-                   : launch(mrssm_fwd_kernel<R, false>, grid, threads, lds, stream, *d, *w, *io);
+    return d->post ? launch("mtrssm::mrssm_fwd_kernel<" #R ", true>", mrssm_fwd_kernel<R, true>, grid, threads, lds, stream, *d, *w, *io)      \
+                   : launch("mtrssm::mrssm_fwd_kernel<" #R ", false>", mrssm_fwd_kernel<R, false>, grid, threads, lds, stream, *d, *w, *io);
   switch (rb) {
     MTRSSM_FWD_CASE(1)
     MTRSSM_FWD_CASE(2)
@@ -430,9 +432,9 @@ int mrssm_bwd_launch(const MtrssmMrssmDims* d, const MtrssmMrssmBwdWeights* w, c
     return MTRSSM_EINVAL;
   }
   switch (rb) {
-    case 1: return launch(mrssm_bwd_kernel<1>, grid, threads, lds, stream, *d, *w, *io);
-    case 2: return launch(mrssm_bwd_kernel<2>, grid, threads, lds, stream, *d, *w, *io);
-    case 4: return launch(mrssm_bwd_kernel<4>, grid, threads, lds, stream, *d, *w, *io);
+    case 1: return launch("mtrssm::mrssm_bwd_kernel<1>", mrssm_bwd_kernel<1>, grid, threads, lds, stream, *d, *w, *io);
+    case 2: return launch("mtrssm::mrssm_bwd_kernel<2>", mrssm_bwd_kernel<2>, grid, threads, lds, stream, *d, *w, *io);
+    case 4: return launch("mtrssm::mrssm_bwd_kernel<4>", mrssm_bwd_kernel<4>, grid, threads, lds, stream, *d, *w, *io);
     default:
       set_error("rows_per_block must be 1, 2 or 4 (got %d)", rb);
       return MTRSSM_EINVAL;

@@ -7,6 +7,7 @@
 namespace mtrssm {
 
 void set_error(const char* fmt, ...);
+void set_last_kernel(const char* name);
 
 constexpr int kThreads = 256;
 
@@ -122,6 +123,7 @@ int nll_fwd_launch(const float* pred, const float* target, int64_t frames, int64
   if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return MTRSSM_ELAUNCH; }
   const int64_t n = frames * event;
   const float constant = 0.5f * 1.8378770664093453f * (float)event;  // 0.5 log(2 pi) per element
+  set_last_kernel("mtrssm::nll_fwd_kernel");
   hipLaunchKernelGGL(nll_fwd_kernel, dim3(grid_for(n / 4)), dim3(kThreads), 0, s, pred, target, n, 1.f / (float)frames, constant, out);
   return check_launch("gaussian_nll_fwd");
 }
@@ -130,6 +132,7 @@ int nll_bwd_launch(const float* pred, const float* target, const float* g_out, i
   if (!pred || !target || !g_out || !g_pred || frames <= 0 || event <= 0) { set_error("gaussian_nll_bwd: bad argument"); return MTRSSM_EINVAL; }
   if (((uintptr_t)pred | (uintptr_t)target | (uintptr_t)g_pred) & 15) { set_error("gaussian_nll_bwd: buffers must be 16-byte aligned"); return MTRSSM_EINVAL; }
   const int64_t n = frames * event;
+  set_last_kernel("mtrssm::nll_bwd_kernel");
   hipLaunchKernelGGL(nll_bwd_kernel, dim3(grid_for(n / 4)), dim3(kThreads), 0, s, pred, target, g_out, n, 1.f / (float)frames, g_pred);
   return check_launch("gaussian_nll_bwd");
 }
@@ -139,6 +142,7 @@ int sumsq_launch(const float* x, int64_t n, float* out, hipStream_t s) {
   if ((uintptr_t)x & 15) { set_error("sumsq: x must be 16-byte aligned"); return MTRSSM_EINVAL; }
   hipError_t e = hipMemsetAsync(out, 0, sizeof(float), s);
   if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return MTRSSM_ELAUNCH; }
+  set_last_kernel("mtrssm::sumsq_kernel");
   hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n / 4)), dim3(kThreads), 0, s, x, n, out);
   return check_launch("sumsq");
 }
@@ -148,6 +152,7 @@ int adamw_launch(float* p, const float* g, float* m, float* v, int64_t n, const 
   if (!p || !g || !m || !v || n <= 0 || step <= 0) { set_error("adamw_step: bad argument"); return MTRSSM_EINVAL; }
   const float bc1 = 1.f - powf(b1, (float)step);
   const float bc2_sqrt = sqrtf(1.f - powf(b2, (float)step));
+  set_last_kernel("mtrssm::adamw_kernel");
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(kThreads), 0, s, p, g, m, v, n, sumsq, clip, gscale, lr, b1, b2, eps, wd, bc1, bc2_sqrt);
   return check_launch("adamw_step");
 }

@@ -117,8 +117,13 @@ class _MrssmScan(torch.autograd.Function):
         )
         wp, wq = cfg.kl_weights
         dims = _lib.MrssmDims(B, T, D, H, cfg.cats, cfg.classes, cfg.act, 1, wp, wq, cfg.rows_per_block, cfg.threads)
+        # algorithmic work: per (b,t) the scan reads xa,pa,pv + two uniform rows and writes deter, three
+        # S-wide rows, kl and (training) the saved activations; FLOPs = 2 x every weight element touched per row-step
+        per_bt = 3 * H + 2 * K + D + 3 * S + 1 + (2 * H + 4 * D + 3 * H + 2 * S if need_grad else 0)
+        macs = S * H + H * H + 3 * D * H + 3 * D * D + 3 * H * D + 3 * S * H
         _lib.check(_lib.TIMERS.call("mtrssm_mrssm_rollout_fwd", lib.mtrssm_mrssm_rollout_fwd, C.byref(dims), C.byref(fw), C.byref(io),
-                                     _lib.stream_ptr(xa.device)), "mtrssm_mrssm_rollout_fwd")
+                                     _lib.stream_ptr(xa.device), flops=2.0 * B * T * macs, nbytes=4.0 * B * T * per_bt),
+                   "mtrssm_mrssm_rollout_fwd")
         if need_grad:
             ctx.cfg, ctx.A = cfg, A
             ctx.save_for_backward(deter0, stoch0, deter, prior_logits, post_logits, post_stoch, sv["sv_h1"], sv["sv_h2"],
@@ -158,8 +163,11 @@ class _MrssmScan(torch.autograd.Function):
         )
         wp, wq = cfg.kl_weights
         dims = _lib.MrssmDims(B, T, D, H, cfg.cats, cfg.classes, cfg.act, 1, wp, wq, cfg.rows_per_block, cfg.threads)
+        per_bt = (2 * H + 4 * D + 3 * H + 2 * S) + D + 2 * S + (D + S + 1) + 2 * H + 6 * D + 3 * H + 3 * S
+        macs = S * H + H * H + 3 * D * H + 3 * D * D + 3 * H * D + 3 * S * H
         _lib.check(_lib.TIMERS.call("mtrssm_mrssm_rollout_bwd", lib.mtrssm_mrssm_rollout_bwd, C.byref(dims), C.byref(bw), C.byref(io),
-                                     _lib.stream_ptr(deter.device)), "mtrssm_mrssm_rollout_bwd")
+                                     _lib.stream_ptr(deter.device), flops=2.0 * B * T * macs, nbytes=4.0 * B * T * per_bt),
+                   "mtrssm_mrssm_rollout_bwd")
 
         # ---- weight gradients: one [out, B*T] x [B*T, in] library GEMM each (rocBLAS) -------------
         prev_stoch = _flat2(torch.cat([stoch0.unsqueeze(1), post_stoch[:, :-1]], dim=1))
