@@ -302,18 +302,21 @@ struct PatchGeom {
 };
 
 template <int NT>
-__global__ __launch_bounds__(kConvThreads) void conv_weight_grad_patch_kernel(
+__global__ __launch_bounds__(2 * kConvThreads) void conv_weight_grad_patch_kernel(
     const MtrssmConvGeom g, const float* __restrict__ a, const float* __restrict__ src, const float* __restrict__ src2,
     const int pre_act_a, float* __restrict__ dwp) {
+  // 8 waves: waves 0-3 issue MFMAs on LDS buffer `cur`, waves 4-7 stage the next group into the other buffer
+  // (wave specialisation: each SIMD holds one compute wave and one loader wave), one barrier per group.
   constexpr int TCO = 32 * NT;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const PatchGeom pg(g, kGP);
   const int ctot = g.C + g.C2;
-  float* a_lds = lds;                          // [TCO][kLDA]
-  float* patch = a_lds + TCO * kLDA;           // [ctot][ps]
-  int* pixtab = reinterpret_cast<int*>(patch + (size_t)ctot * pg.ps);  // [kGP]
+  const int buf_floats = TCO * kLDA + ctot * pg.ps;
+  int* pixtab = reinterpret_cast<int*>(lds + 2 * (size_t)buf_floats);  // [kGP]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool loader = wave >= 4;
+  const int lw = wave & 3, ltid = tid & (kConvThreads - 1);
   const int kl = lane >> 5, il = lane & 31;
   const int taps = g.KH * g.KW;
   const int nct = (ctot + 31) / 32;
@@ -326,48 +329,24 @@ __global__ __launch_bounds__(kConvThreads) void conv_weight_grad_patch_kernel(
   const long gbeg = (long)blockIdx.x * gper;
   const long gend = gbeg + gper < groups ? gbeg + gper : groups;
 
-  // pixel -> patch offset (identical for every group)
   if (tid < kGP) {
     const int row = tid / g.Wq, ox = tid - row * g.Wq;
     const int ip = row / pg.rp, lr = row - ip * pg.rp;
     pixtab[tid] = ip * pg.ph * pg.pw + lr * g.SS * pg.pw + ox * g.SS;
   }
-  // this wave's column tiles
-  int cbase[kMaxQ], qtap[kMaxQ], qc[kMaxQ];
-  int nsl = 0;
-#pragma unroll
-  for (int s = 0; s < kMaxQ; ++s) {
-    const int q = wave + 4 * s;
-    cbase[s] = -1; qtap[s] = 0; qc[s] = 0;
-    if (q < nq) {
-      nsl = s + 1;
-      const int tap = q / nct, ct = q - tap * nct;
-      const int ty = tap / g.KW, tx = tap - ty * g.KW;
-      const int c = ct * 32 + il;
-      qtap[s] = tap;
-      qc[s] = c;
-      if (c < ctot) cbase[s] = c * pg.ps + ty * pg.pw + tx;
-    }
-  }
-  f32x16 acc[kMaxQ][NT];
-#pragma unroll
-  for (int s = 0; s < kMaxQ; ++s)
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[s][j][r] = 0.f;
 
-  const int apix = tid & (kGP - 1), arow0 = tid >> 6;  // A staging: pixel column, rows arow0 + 4 i
-  for (long grp = gbeg; grp < gend; ++grp) {
+  // ---- loader role: stage one group (A tile + zero-haloed patch) into buffer `buf`
+  auto stage = [&](long grp, int buf) {
+    float* a_lds = lds + (size_t)buf * buf_floats;
+    float* patch = a_lds + TCO * kLDA;
     const long p0 = grp * kGP;
-    // ---- stage A
     {
+      const int apix = ltid & (kGP - 1), arow0 = ltid >> 6;
       const long p = p0 + apix;
       const bool pv = p < ptot;
       int n = 0, rem = 0;
       if (pv) { n = (int)(p / plane_a); rem = (int)(p - (long)n * plane_a); }
       const float* a_n = a + (size_t)n * g.Cout * plane_a + rem;
-      // batches of 8 independent loads per lane: the staging phase is latency-bound otherwise
 #pragma unroll
       for (int ib = 0; ib < TCO / 4; ib += 8) {
         float v[8];
@@ -383,14 +362,11 @@ __global__ __launch_bounds__(kConvThreads) void conv_weight_grad_patch_kernel(
         }
       }
     }
-    // ---- stage the source patch (zero halo)
     {
       const int n0 = (int)(p0 / plane_a);
-      const int r0 = (int)((p0 - (long)n0 * plane_a) / g.Wq);  // first output row of the group (0 when ipg > 1)
+      const int r0 = (int)((p0 - (long)n0 * plane_a) / g.Wq);
       const int sy0 = r0 * g.SS + g.OFFY, sx0 = g.OFFX;
       const int phw = pg.ph * pg.pw;
-      // wave w stages channels w, w+4, ...; lanes walk the patch positions r (decoded once per r: three
-      // integer divisions) and issue 8 independent channel loads at a time
       for (int rb = 0; rb < pg.ps_raw; rb += 64) {
         const int r = rb + lane;
         const bool rv = r < pg.ps_raw;
@@ -400,7 +376,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_weight_grad_patch_kernel(
         const bool ok = rv && n < g.N && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
         const size_t off = (size_t)sy * g.Ws + sx;
         const float* s_n = src + (size_t)n * g.C * plane_s + off;
-        for (int cb = wave; cb < ctot; cb += 32) {
+        for (int cb = lw; cb < ctot; cb += 32) {
           float v[8];
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
@@ -418,38 +394,76 @@ __global__ __launch_bounds__(kConvThreads) void conv_weight_grad_patch_kernel(
         }
       }
     }
-    __syncthreads();
-    // ---- MFMA: D[co][c] += sum_pix A[co][pix] * patch[c][pix shifted by tap]
+  };
+
+  // ---- compute role state: this wave's column tiles (tile q = lw + 4 s -> tap q / nct, channel tile q % nct)
+  int cbase[kMaxQ];
+  int nsl = 0;
+#pragma unroll
+  for (int s = 0; s < kMaxQ; ++s) {
+    const int q = lw + 4 * s;
+    cbase[s] = -1;
+    if (q < nq) {
+      nsl = s + 1;
+      const int tap = q / nct, ct = q - tap * nct;
+      const int ty = tap / g.KW, tx = tap - ty * g.KW;
+      const int c = ct * 32 + il;
+      if (c < ctot) cbase[s] = c * pg.ps + ty * pg.pw + tx;
+    }
+  }
+  f32x16 acc[kMaxQ][NT];
+#pragma unroll
+  for (int s = 0; s < kMaxQ; ++s)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[s][j][r] = 0.f;
+
+  __syncthreads();  // pixtab
+  int cur = 1;      // iteration gbeg-1 only stages group gbeg into buffer 0 (single call site of stage())
+  for (long grp = gbeg - 1; grp < gend; ++grp) {
+    if (loader) {
+      if (grp + 1 < gend) stage(grp + 1, cur ^ 1);
+    } else if (grp >= gbeg) {
+      const float* a_lds = lds + (size_t)cur * buf_floats;
+      const float* patch = a_lds + TCO * kLDA;
 #pragma unroll 2
-    for (int step = 0; step < kGP / 2; ++step) {
-      const int pix = 2 * step + kl;
-      const int poff = pixtab[pix];
-      float av[NT];
+      for (int step = 0; step < kGP / 2; ++step) {
+        const int pix = 2 * step + kl;
+        const int poff = pixtab[pix];
+        float av[NT];
 #pragma unroll
-      for (int j = 0; j < NT; ++j) av[j] = a_lds[(j * 32 + il) * kLDA + pix];
+        for (int j = 0; j < NT; ++j) av[j] = a_lds[(j * 32 + il) * kLDA + pix];
 #pragma unroll
-      for (int s = 0; s < kMaxQ; ++s) {
-        if (s < nsl) {
-          const float b = cbase[s] >= 0 ? patch[cbase[s] + poff] : 0.f;
+        for (int s = 0; s < kMaxQ; ++s) {
+          if (s < nsl) {
+            const float b = cbase[s] >= 0 ? patch[cbase[s] + poff] : 0.f;
 #pragma unroll
-          for (int j = 0; j < NT; ++j) acc[s][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], b, acc[s][j], 0, 0, 0);
+            for (int j = 0; j < NT; ++j) acc[s][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], b, acc[s][j], 0, 0, 0);
+          }
         }
       }
     }
     __syncthreads();
+    cur ^= 1;
   }
 
-  // ---- epilogue: lanes il = consecutive c -> 128-byte atomic row segments
+  if (!loader) {
 #pragma unroll
-  for (int s = 0; s < kMaxQ; ++s) {
-    if (s < nsl && qc[s] < ctot) {
+    for (int s = 0; s < kMaxQ; ++s) {
+      const int q = lw + 4 * s;
+      if (q < nq) {
+        const int tap = q / nct, c = (q - tap * nct) * 32 + il;
+        if (c < ctot) {
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
+          for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int co = co0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
-          if (co < g.Cout) atomicAdd(&dwp[((size_t)co * taps + qtap[s]) * g.Cpad + qc[s]], acc[s][j][r]);
+            for (int r = 0; r < 16; ++r) {
+              const int co = co0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
+              if (co < g.Cout) atomicAdd(&dwp[((size_t)co * taps + tap) * g.Cpad + c], acc[s][j][r]);
+            }
         }
+      }
     }
   }
 }
@@ -872,7 +886,7 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
     const bool tiles = (g->Hq % pg.rpg == 0) || (pg.rpg % g->Hq == 0);
     const int nq = taps * ((ctot + 31) / 32);
     const int tco = g->Cout > 32 ? 64 : 32;
-    const size_t lds = ((size_t)tco * kLDA + (size_t)ctot * pg.ps + kGP) * sizeof(float);
+    const size_t lds = (2 * ((size_t)tco * kLDA + (size_t)ctot * pg.ps) + kGP) * sizeof(float);
     const int n_out = g->Cout * taps * ctot;
     const size_t lds_thin = ((size_t)g->Cout * kLDA + (size_t)ctot * pg.ps + kGP) * sizeof(float);
     if (tiles && n_out <= kThinOut * kConvThreads && lds_thin <= 64 * 1024) {  // thin layer: VALU reduction
@@ -882,19 +896,19 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
       { set_last_kernel("mtrssm::conv_weight_grad_thin_kernel"); hipLaunchKernelGGL(conv_weight_grad_thin_kernel, dim3((unsigned)splits), dim3(kConvThreads), lds_thin, stream, *g, a, src, src2, pre_act_a, dwp); }
       return launched("conv_weight_grad(thin)");
     }
-    if (tiles && nq <= 4 * kMaxQ && lds <= 96 * 1024) {
+    if (tiles && nq <= 4 * kMaxQ && lds <= 150 * 1024) {
       const long groups = (ptot + kGP - 1) / kGP;
       const int cotiles = g->Cout > 32 ? g->CoutPad / 64 : 1;
-      long splits = 512 / cotiles;  // ~2 workgroups per CU: enough to hide staging, few enough atomics
+      long splits = 256 / cotiles;  // one 8-wave workgroup per CU (loader waves hide the staging); few atomics
       if (splits > groups) splits = groups;
       if (splits < 1) splits = 1;
       dim3 grid((unsigned)splits, cotiles);
       if (g->Cout > 32) {
         if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(conv_weight_grad_patch_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        { set_last_kernel("mtrssm::conv_weight_grad_patch_kernel<2>"); hipLaunchKernelGGL(conv_weight_grad_patch_kernel<2>, grid, dim3(kConvThreads), lds, stream, *g, a, src, src2, pre_act_a, dwp); }
+        { set_last_kernel("mtrssm::conv_weight_grad_patch_kernel<2>"); hipLaunchKernelGGL(conv_weight_grad_patch_kernel<2>, grid, dim3(2 * kConvThreads), lds, stream, *g, a, src, src2, pre_act_a, dwp); }
       } else {
         if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(conv_weight_grad_patch_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        { set_last_kernel("mtrssm::conv_weight_grad_patch_kernel<1>"); hipLaunchKernelGGL(conv_weight_grad_patch_kernel<1>, grid, dim3(kConvThreads), lds, stream, *g, a, src, src2, pre_act_a, dwp); }
+        { set_last_kernel("mtrssm::conv_weight_grad_patch_kernel<1>"); hipLaunchKernelGGL(conv_weight_grad_patch_kernel<1>, grid, dim3(2 * kConvThreads), lds, stream, *g, a, src, src2, pre_act_a, dwp); }
       }
       return launched("conv_weight_grad(patch)");
     }

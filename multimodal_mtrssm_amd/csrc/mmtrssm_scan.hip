@@ -2,6 +2,8 @@
 // Same regime as mrssm_scan.hip: one workgroup owns RB rows for the whole sequence, state in LDS,
 // weights streamed from L2 every step, no grid-wide synchronisation.
 // Reference: mmtrssm/mopoe_mmtrssm/core.py:405-490 (posterior rollout), :496-544 (prior-only).
+#include <initializer_list>
+
 #include "scan_common.h"
 
 namespace mtrssm {
@@ -23,13 +25,14 @@ struct MmtLds {
   }
 };
 
-template <int RB, bool POST>
-__global__ void mmtrssm_fwd_kernel(const MtrssmMmtrssmDims dm, const MtrssmMmtrssmFwdWeights w, const MtrssmMmtrssmFwdIO io) {
+template <int RB, bool POST, bool VEC>
+__global__ __launch_bounds__(1024) void mmtrssm_fwd_kernel(const MtrssmMmtrssmDims dm, const MtrssmMmtrssmFwdWeights w, const MtrssmMmtrssmFwdIO io) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int LD = dm.LD, HD = dm.HD, H = dm.H, KL = dm.KL, CL = dm.CL, KH = dm.KH, CH = dm.CH;
   const int LS = KL * CL, HS = KH * CH, T = dm.T, act = dm.act;
   const int NL = POST ? 4 : 1, NHh = POST ? 2 : 1;
   const MmtLds L(LD, HD, H, LS, HS);
+  float* red = lds + RB * L.stride;  // split-K partial sums
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave, nwave = blockDim.x / kWave;
   const int row0 = blockIdx.x * RB;
   int brow[RB];
@@ -57,10 +60,10 @@ __global__ void mmtrssm_fwd_kernel(const MtrssmMmtrssmDims dm, const MtrssmMmtrs
     for (int rb = 0; rb < RB; ++rb) bt[rb] = (size_t)brow[rb] * T + t;
 
     // (1) both MTRNN cells (core.py:59-60): hidden = keep*hidden + (W_d d_prev + W_x x + b)/tau ; d = tanh(hidden)
-    gemv_t<RB>(w.wxl_s_t, LD, LS + HS, LD, lds + L.slh, L.stride,
+    gemv_sk<RB, VEC>(w.wxl_s_t, LD, LS + HS, LD, lds + L.slh, L.stride, red,
                [&](int rb, int o) { return io.xl[bt[rb] * LD + o]; },
                [&](int rb, int o, float a) { lds[rb * L.stride + L.tmp + o] = a; });
-    gemv_t<RB>(w.wdl_t, LD, LD, LD, lds + lcur, L.stride,
+    gemv_sk<RB, VEC>(w.wdl_t, LD, LD, LD, lds + lcur, L.stride, red,
                [&](int rb, int o) { return lds[rb * L.stride + L.tmp + o]; },
                [&](int rb, int o, float u) {
                  float* r = lds + rb * L.stride;
@@ -71,10 +74,10 @@ __global__ void mmtrssm_fwd_kernel(const MtrssmMmtrssmDims dm, const MtrssmMmtrs
                  if (valid[rb]) { io.deter_l[bt[rb] * LD + o] = d; io.hidden_l[bt[rb] * LD + o] = hid; }
                });
     __syncthreads();  // tmp is reused by the higher cell
-    gemv_t<RB>(w.wxh_t, HD, HS, HD, lds + L.slh + LS, L.stride,
+    gemv_sk<RB, VEC>(w.wxh_t, HD, HS, HD, lds + L.slh + LS, L.stride, red,
                [&](int, int o) { return w.bh[o]; },
                [&](int rb, int o, float a) { lds[rb * L.stride + L.tmp + o] = a; });
-    gemv_t<RB>(w.wdh_t, HD, HD, HD, lds + hcur, L.stride,
+    gemv_sk<RB, VEC>(w.wdh_t, HD, HD, HD, lds + hcur, L.stride, red,
                [&](int rb, int o) { return lds[rb * L.stride + L.tmp + o]; },
                [&](int rb, int o, float u) {
                  float* r = lds + rb * L.stride;
@@ -87,7 +90,7 @@ __global__ void mmtrssm_fwd_kernel(const MtrssmMmtrssmDims dm, const MtrssmMmtrs
     __syncthreads();
 
     // (2a) layer 0 of every head: on d_l -> [l_prior | audio | vision | h_posterior(l part, raw)], on d_h -> [h_prior | h_posterior(h part, raw)]
-    gemv_t<RB>(w.wl1_t, NL * H, LD, NL * H, lds + lnxt, L.stride,
+    gemv_sk<RB, VEC>(w.wl1_t, NL * H, LD, NL * H, lds + lnxt, L.stride, red,
                [&](int rb, int o) {
                  if (o < H) return w.bl1[o];
                  if (o < 2 * H) return io.pa[bt[rb] * H + (o - H)];
@@ -99,7 +102,7 @@ __global__ void mmtrssm_fwd_kernel(const MtrssmMmtrssmDims dm, const MtrssmMmtrs
                  lds[rb * L.stride + L.l1 + o] = h;
                  if (io.sv_l1 && valid[rb] && o < 3 * H) io.sv_l1[bt[rb] * 4 * H + o] = h;
                });
-    gemv_t<RB>(w.wh1_t, NHh * H, HD, NHh * H, lds + hnxt, L.stride,
+    gemv_sk<RB, VEC>(w.wh1_t, NHh * H, HD, NHh * H, lds + hnxt, L.stride, red,
                [&](int, int o) { return w.bh1[o]; },
                [&](int rb, int o, float a) {
                  const float h = o < H ? act_fwd(a, act) : a;
@@ -205,12 +208,13 @@ struct MmtBwdLds {
   }
 };
 
-template <int RB>
-__global__ void mmtrssm_bwd_kernel(const MtrssmMmtrssmDims dm, const MtrssmMmtrssmBwdWeights w, const MtrssmMmtrssmBwdIO io) {
+template <int RB, bool VEC>
+__global__ __launch_bounds__(1024) void mmtrssm_bwd_kernel(const MtrssmMmtrssmDims dm, const MtrssmMmtrssmBwdWeights w, const MtrssmMmtrssmBwdIO io) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int LD = dm.LD, HD = dm.HD, H = dm.H, KL = dm.KL, CL = dm.CL, KH = dm.KH, CH = dm.CH;
   const int LS = KL * CL, HS = KH * CH, T = dm.T, act = dm.act;
   const MmtBwdLds L(LD, HD, H, LS, HS);
+  float* red = lds + RB * L.stride;  // split-K partial sums
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave, nwave = blockDim.x / kWave;
   const int row0 = blockIdx.x * RB;
   int brow[RB];
@@ -287,7 +291,7 @@ __global__ void mmtrssm_bwd_kernel(const MtrssmMmtrssmDims dm, const MtrssmMmtrs
 
     // (c) layer 1 transposed -> pre-activation grads of layer 0
     auto head_bwd = [&](const float* W, int R, int vin_off, int act_off, int dst_off, int g_off, bool to_l, int dup_off) {
-      gemv_t<RB>(W, H, R, H, lds + vin_off, L.stride, [](int, int) { return 0.f; },
+      gemv_sk<RB, VEC>(W, H, R, H, lds + vin_off, L.stride, red, [](int, int) { return 0.f; },
                  [&](int rb, int o, float a) {
                    float* r = lds + rb * L.stride;
                    const float g = a * act_grad_from_out(r[act_off + o], act);
@@ -307,7 +311,7 @@ __global__ void mmtrssm_bwd_kernel(const MtrssmMmtrssmDims dm, const MtrssmMmtrs
     __syncthreads();
 
     // (d) grads at d_l / d_h, through tanh into the leaky integrators
-    gemv_t<RB>(w.wl1, LD, 4 * H, LD, lds + L.dzl, L.stride,
+    gemv_sk<RB, VEC>(w.wl1, LD, 4 * H, LD, lds + L.dzl, L.stride, red,
                [&](int rb, int o) { return (io.g_deter_l ? io.g_deter_l[bt[rb] * LD + o] : 0.f) + lds[rb * L.stride + L.c_dl + o]; },
                [&](int rb, int o, float dd) {
                  float* r = lds + rb * L.stride;
@@ -318,7 +322,7 @@ __global__ void mmtrssm_bwd_kernel(const MtrssmMmtrssmDims dm, const MtrssmMmtrs
                  r[L.c_hl + o] = dhid * dm.keep_l;
                  if (valid[rb]) io.d_ul[bt[rb] * LD + o] = du;
                });
-    gemv_t<RB>(w.wh1, HD, 2 * H, HD, lds + L.dzh, L.stride,
+    gemv_sk<RB, VEC>(w.wh1, HD, 2 * H, HD, lds + L.dzh, L.stride, red,
                [&](int rb, int o) { return (io.g_deter_h ? io.g_deter_h[bt[rb] * HD + o] : 0.f) + lds[rb * L.stride + L.c_dh + o]; },
                [&](int rb, int o, float dd) {
                  float* r = lds + rb * L.stride;
@@ -332,9 +336,9 @@ __global__ void mmtrssm_bwd_kernel(const MtrssmMmtrssmDims dm, const MtrssmMmtrs
     __syncthreads();
 
     // (e) carries into step t-1: d_prev via W_d^T ; [stoch_l ; stoch_h] via W_x^T (narrow outputs)
-    gemv_t<RB>(w.wdl, LD, LD, LD, lds + L.dul, L.stride, [](int, int) { return 0.f; },
+    gemv_sk<RB, VEC>(w.wdl, LD, LD, LD, lds + L.dul, L.stride, red, [](int, int) { return 0.f; },
                [&](int rb, int o, float a) { lds[rb * L.stride + L.c_dl + o] = a; });
-    gemv_t<RB>(w.wdh, HD, HD, HD, lds + L.duh, L.stride, [](int, int) { return 0.f; },
+    gemv_sk<RB, VEC>(w.wdh, HD, HD, HD, lds + L.duh, L.stride, red, [](int, int) { return 0.f; },
                [&](int rb, int o, float a) { lds[rb * L.stride + L.c_dh + o] = a; });
     for (int s = wave; s < LS + HS; s += nwave) {
       float acc[RB], acc2[RB];
@@ -396,15 +400,27 @@ static int check_mmt_dims(const MtrssmMmtrssmDims* d) {
     set_error("mmtrssm: unknown activation id %d", d->act);
     return MTRSSM_EINVAL;
   }
+  if (d->threads < 0 || d->threads > 1024 || d->threads % kWave) {
+    set_error("mmtrssm: threads must be a multiple of 64 in [64, 1024] (0 = default)");
+    return MTRSSM_EINVAL;
+  }
   return MTRSSM_OK;
 }
 
-static int mmt_rows(const MtrssmMmtrssmDims* d, int stride) {
+static size_t mmt_red_floats(int threads, int widest) { return (size_t)(4 * threads > widest + 3 ? 4 * threads : widest + 3); }
+
+static int mmt_rows(const MtrssmMmtrssmDims* d, size_t row_bytes, size_t red_bytes) {
   if (d->rows_per_block > 0) return d->rows_per_block;
   int rb = 1;
   while (rb < 4 && (d->B + rb - 1) / rb > 1024) rb *= 2;
-  while (rb > 1 && (size_t)rb * stride * sizeof(float) > 160 * 1024) rb /= 2;
+  while (rb > 1 && (size_t)rb * (row_bytes + red_bytes) > 160 * 1024) rb /= 2;
   return rb;
+}
+
+static bool mmt_aligned16(std::initializer_list<const void*> ptrs) {
+  for (const void* p : ptrs)
+    if (p && ((uintptr_t)p & 15)) return false;
+  return true;
 }
 
 int mmtrssm_fwd_launch(const MtrssmMmtrssmDims* d, const MtrssmMmtrssmFwdWeights* w, const MtrssmMmtrssmFwdIO* io, hipStream_t stream) {
@@ -424,15 +440,21 @@ int mmtrssm_fwd_launch(const MtrssmMmtrssmDims* d, const MtrssmMmtrssmFwdWeights
     return MTRSSM_EINVAL;
   }
   const MmtLds L(d->LD, d->HD, d->H, d->KL * d->CL, d->KH * d->CH);
-  const int threads = d->threads > 0 ? d->threads : 256;
-  const int rb = mmt_rows(d, L.stride);
+  const int threads = d->threads > 0 ? d->threads : 1024;
+  const int widest = 4 * d->H > d->LD ? (4 * d->H > d->HD ? 4 * d->H : d->HD) : (d->LD > d->HD ? d->LD : d->HD);
+  const size_t red = mmt_red_floats(threads, widest) * sizeof(float);
+  const int rb = mmt_rows(d, L.stride * sizeof(float), red);
   const int grid = (d->B + rb - 1) / rb;
-  const size_t lds = (size_t)rb * L.stride * sizeof(float);
+  const size_t lds = (size_t)rb * (L.stride * sizeof(float) + red);
   if (rb > threads / kWave) { set_error("rows_per_block %d exceeds waves per block %d", rb, threads / kWave); return MTRSSM_EINVAL; }
-#define MTRSSM_CASE(R)                                                                                 \
-  case R:                                                                                               \
-    return d->post ? launch_mmt("mtrssm::mmtrssm_fwd_kernel<" #R ", true>", mmtrssm_fwd_kernel<R, true>, grid, threads, lds, stream, *d, *w, *io)   \
-                   : launch_mmt("mtrssm::mmtrssm_fwd_kernel<" #R ", false>", mmtrssm_fwd_kernel<R, false>, grid, threads, lds, stream, *d, *w, *io);
+  const bool vec = d->LD % 4 == 0 && d->HD % 4 == 0 && d->H % 4 == 0 &&
+                   mmt_aligned16({w->wxl_s_t, w->wdl_t, w->wxh_t, w->wdh_t, w->wl1_t, w->wh1_t});
+#define MTRSSM_VARIANT(R, P, V) \
+  launch_mmt("mtrssm::mmtrssm_fwd_kernel<" #R ", " #P ", " #V ">", mmtrssm_fwd_kernel<R, P, V>, grid, threads, lds, stream, *d, *w, *io)
+#define MTRSSM_CASE(R)                                                                      \
+  case R:                                                                                    \
+    if (d->post) return vec ? MTRSSM_VARIANT(R, true, true) : MTRSSM_VARIANT(R, true, false); \
+    return vec ? MTRSSM_VARIANT(R, false, true) : MTRSSM_VARIANT(R, false, false);
   switch (rb) {
     MTRSSM_CASE(1)
     MTRSSM_CASE(2)
@@ -440,6 +462,7 @@ int mmtrssm_fwd_launch(const MtrssmMmtrssmDims* d, const MtrssmMmtrssmFwdWeights
     default: set_error("rows_per_block must be 1, 2 or 4 (got %d)", rb); return MTRSSM_EINVAL;
   }
 #undef MTRSSM_CASE
+#undef MTRSSM_VARIANT
 }
 
 int mmtrssm_bwd_launch(const MtrssmMmtrssmDims* d, const MtrssmMmtrssmBwdWeights* w, const MtrssmMmtrssmBwdIO* io, hipStream_t stream) {
@@ -452,17 +475,26 @@ int mmtrssm_bwd_launch(const MtrssmMmtrssmDims* d, const MtrssmMmtrssmBwdWeights
     return MTRSSM_EINVAL;
   }
   const MmtBwdLds L(d->LD, d->HD, d->H, d->KL * d->CL, d->KH * d->CH);
-  const int threads = d->threads > 0 ? d->threads : 256;
-  const int rb = mmt_rows(d, L.stride);
+  const int threads = d->threads > 0 ? d->threads : 1024;
+  const int widest = d->H > d->LD ? (d->H > d->HD ? d->H : d->HD) : (d->LD > d->HD ? d->LD : d->HD);
+  const size_t red = mmt_red_floats(threads, widest) * sizeof(float);
+  const int rb = mmt_rows(d, L.stride * sizeof(float), red);
   const int grid = (d->B + rb - 1) / rb;
-  const size_t lds = (size_t)rb * L.stride * sizeof(float);
+  const size_t lds = (size_t)rb * (L.stride * sizeof(float) + red);
   if (rb > threads / kWave) { set_error("rows_per_block %d exceeds waves per block %d", rb, threads / kWave); return MTRSSM_EINVAL; }
+  const bool vec = d->LD % 4 == 0 && d->HD % 4 == 0 && d->H % 4 == 0 &&
+                   mmt_aligned16({w->wdl, w->wdh, w->wl1, w->wh1, w->wlp2, w->wa2, w->wv2, w->whp2, w->whq2});
+#define MTRSSM_CASE(R)                                                                                                         \
+  case R:                                                                                                                       \
+    return vec ? launch_mmt("mtrssm::mmtrssm_bwd_kernel<" #R ", true>", mmtrssm_bwd_kernel<R, true>, grid, threads, lds, stream, *d, *w, *io) \
+               : launch_mmt("mtrssm::mmtrssm_bwd_kernel<" #R ", false>", mmtrssm_bwd_kernel<R, false>, grid, threads, lds, stream, *d, *w, *io);
   switch (rb) {
-    case 1: return launch_mmt("mtrssm::mmtrssm_bwd_kernel<1>", mmtrssm_bwd_kernel<1>, grid, threads, lds, stream, *d, *w, *io);
-    case 2: return launch_mmt("mtrssm::mmtrssm_bwd_kernel<2>", mmtrssm_bwd_kernel<2>, grid, threads, lds, stream, *d, *w, *io);
-    case 4: return launch_mmt("mtrssm::mmtrssm_bwd_kernel<4>", mmtrssm_bwd_kernel<4>, grid, threads, lds, stream, *d, *w, *io);
+    MTRSSM_CASE(1)
+    MTRSSM_CASE(2)
+    MTRSSM_CASE(4)
     default: set_error("rows_per_block must be 1, 2 or 4 (got %d)", rb); return MTRSSM_EINVAL;
   }
+#undef MTRSSM_CASE
 }
 
 }  // namespace mtrssm

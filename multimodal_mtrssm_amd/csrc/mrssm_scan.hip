@@ -6,6 +6,8 @@
 // in LDS; weights are re-streamed from L2 every step (1.7 MB fp32 at D=H=200); the only HBM traffic
 // is the per-step xa/pa/pv/u reads and the state / saved-activation writes.  The kernels are
 // latency-bound by the T-step dependency chain, not by a roofline.
+#include <initializer_list>
+
 #include "scan_common.h"
 
 namespace mtrssm {
@@ -25,12 +27,13 @@ struct MrssmLds {
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <int RB, bool POST>
-__global__ void mrssm_fwd_kernel(const MtrssmMrssmDims dm, const MtrssmMrssmFwdWeights w, const MtrssmMrssmFwdIO io) {
+template <int RB, bool POST, bool VEC>
+__global__ __launch_bounds__(1024) void mrssm_fwd_kernel(const MtrssmMrssmDims dm, const MtrssmMrssmFwdWeights w, const MtrssmMrssmFwdIO io) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int D = dm.D, H = dm.H, K = dm.K, C = dm.C, S = K * C, T = dm.T, act = dm.act;
   const int NH = POST ? 3 : 1;
   const MrssmLds L(D, H, S);
+  float* red = lds + RB * L.stride;  // split-K partial sums
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave, nwave = blockDim.x / kWave;
   const int row0 = blockIdx.x * RB;
   int brow[RB];
@@ -55,7 +58,7 @@ __global__ void mrssm_fwd_kernel(const MtrssmMrssmDims dm, const MtrssmMrssmFwdW
     for (int rb = 0; rb < RB; ++rb) bt[rb] = (size_t)brow[rb] * T + t;
 
     // (1) h1 = act(xa + W1s s)                                   networks.py:165-166 (first Linear + act)
-    gemv_t<RB>(w.w1s_t, H, S, H, lds + L.s, L.stride,
+    gemv_sk<RB, VEC>(w.w1s_t, H, S, H, lds + L.s, L.stride, red,
                [&](int rb, int o) { return io.xa[bt[rb] * H + o]; },
                [&](int rb, int o, float a) {
                  const float h = act_fwd(a, act);
@@ -64,7 +67,7 @@ __global__ void mrssm_fwd_kernel(const MtrssmMrssmDims dm, const MtrssmMrssmFwdW
                });
     __syncthreads();
     // (2) h2 = W2 h1 + b2                                         networks.py:166 (second Linear)
-    gemv_t<RB>(w.w2_t, H, H, H, lds + L.h1, L.stride,
+    gemv_sk<RB, VEC>(w.w2_t, H, H, H, lds + L.h1, L.stride, red,
                [&](int, int o) { return w.b2[o]; },
                [&](int rb, int o, float a) {
                  lds[rb * L.stride + L.h2 + o] = a;
@@ -72,10 +75,10 @@ __global__ void mrssm_fwd_kernel(const MtrssmMrssmDims dm, const MtrssmMrssmFwdW
                });
     __syncthreads();
     // (3) gi = W_ih h2 + b_ih ; gh = W_hh d_prev + b_hh           networks.py:170 (nn.GRUCell)
-    gemv_t<RB>(w.wih_t, 3 * D, H, 3 * D, lds + L.h2, L.stride,
+    gemv_sk<RB, VEC>(w.wih_t, 3 * D, H, 3 * D, lds + L.h2, L.stride, red,
                [&](int, int o) { return w.bih[o]; },
                [&](int rb, int o, float a) { lds[rb * L.stride + L.gi + o] = a; });
-    gemv_t<RB>(w.whh_t, 3 * D, D, 3 * D, lds + cur, L.stride,
+    gemv_sk<RB, VEC>(w.whh_t, 3 * D, D, 3 * D, lds + cur, L.stride, red,
                [&](int, int o) { return w.bhh[o]; },
                [&](int rb, int o, float a) { lds[rb * L.stride + L.gh + o] = a; });
     __syncthreads();
@@ -100,7 +103,7 @@ __global__ void mrssm_fwd_kernel(const MtrssmMrssmDims dm, const MtrssmMrssmFwdW
     }
     __syncthreads();
     // (5) head layer 0 on the new deter: prior | audio | vision   networks.py:171, 82 ; core.py:82
-    gemv_t<RB>(w.wh1_t, NH * H, D, NH * H, lds + nxt, L.stride,
+    gemv_sk<RB, VEC>(w.wh1_t, NH * H, D, NH * H, lds + nxt, L.stride, red,
                [&](int rb, int o) {
                  if (o < H) return w.b3[o];
                  if (o < 2 * H) return io.pa[bt[rb] * H + (o - H)];
@@ -174,11 +177,12 @@ struct MrssmBwdLds {
   }
 };
 
-template <int RB>
-__global__ void mrssm_bwd_kernel(const MtrssmMrssmDims dm, const MtrssmMrssmBwdWeights w, const MtrssmMrssmBwdIO io) {
+template <int RB, bool VEC>
+__global__ __launch_bounds__(1024) void mrssm_bwd_kernel(const MtrssmMrssmDims dm, const MtrssmMrssmBwdWeights w, const MtrssmMrssmBwdIO io) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int D = dm.D, H = dm.H, K = dm.K, C = dm.C, S = K * C, T = dm.T, act = dm.act;
   const MrssmBwdLds L(D, H, S);
+  float* red = lds + RB * L.stride;  // split-K partial sums
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave, nwave = blockDim.x / kWave;
   const int row0 = blockIdx.x * RB;
   int brow[RB];
@@ -241,19 +245,19 @@ __global__ void mrssm_bwd_kernel(const MtrssmMrssmDims dm, const MtrssmMrssmBwdW
     __syncthreads();
 
     // (c) head layer 1 transposed: dzh[which][j] = act'(hd) * sum_s W[s][j] dl[s]
-    gemv_t<RB>(w.w4, H, S, H, lds + L.dlp, L.stride, [](int, int) { return 0.f; },
+    gemv_sk<RB, VEC>(w.w4, H, S, H, lds + L.dlp, L.stride, red, [](int, int) { return 0.f; },
                [&](int rb, int o, float a) {
                  const float g = a * act_grad_from_out(lds[rb * L.stride + L.hd + o], act);
                  lds[rb * L.stride + L.dzh + o] = g;
                  if (valid[rb]) io.d_zh[bt[rb] * 3 * H + o] = g;
                });
-    gemv_t<RB>(w.wa2, H, S, H, lds + L.dla, L.stride, [](int, int) { return 0.f; },
+    gemv_sk<RB, VEC>(w.wa2, H, S, H, lds + L.dla, L.stride, red, [](int, int) { return 0.f; },
                [&](int rb, int o, float a) {
                  const float g = a * act_grad_from_out(lds[rb * L.stride + L.hd + H + o], act);
                  lds[rb * L.stride + L.dzh + H + o] = g;
                  if (valid[rb]) io.d_zh[bt[rb] * 3 * H + H + o] = g;
                });
-    gemv_t<RB>(w.wv2, H, S, H, lds + L.dlv, L.stride, [](int, int) { return 0.f; },
+    gemv_sk<RB, VEC>(w.wv2, H, S, H, lds + L.dlv, L.stride, red, [](int, int) { return 0.f; },
                [&](int rb, int o, float a) {
                  const float g = a * act_grad_from_out(lds[rb * L.stride + L.hd + 2 * H + o], act);
                  lds[rb * L.stride + L.dzh + 2 * H + o] = g;
@@ -262,7 +266,7 @@ __global__ void mrssm_bwd_kernel(const MtrssmMrssmDims dm, const MtrssmMrssmBwdW
     __syncthreads();
 
     // (d) dd = g_deter + carry + Wh1^T dzh ; then the GRU gate gradients
-    gemv_t<RB>(w.wh1, D, 3 * H, D, lds + L.dzh, L.stride,
+    gemv_sk<RB, VEC>(w.wh1, D, 3 * H, D, lds + L.dzh, L.stride, red,
                [&](int rb, int o) {
                  return (io.g_deter ? io.g_deter[bt[rb] * D + o] : 0.f) + lds[rb * L.stride + L.cd + o];
                },
@@ -289,17 +293,17 @@ __global__ void mrssm_bwd_kernel(const MtrssmMrssmDims dm, const MtrssmMrssmBwdW
     __syncthreads();
 
     // (e) carry_d = dd z + W_hh^T dgh ; dh2 = W_ih^T dgi
-    gemv_t<RB>(w.whh, D, 3 * D, D, lds + L.dgh, L.stride,
+    gemv_sk<RB, VEC>(w.whh, D, 3 * D, D, lds + L.dgh, L.stride, red,
                [&](int rb, int o) { return lds[rb * L.stride + L.dd + o]; },
                [&](int rb, int o, float a) { lds[rb * L.stride + L.cd + o] = a; });
-    gemv_t<RB>(w.wih, H, 3 * D, H, lds + L.dgi, L.stride, [](int, int) { return 0.f; },
+    gemv_sk<RB, VEC>(w.wih, H, 3 * D, H, lds + L.dgi, L.stride, red, [](int, int) { return 0.f; },
                [&](int rb, int o, float a) {
                  lds[rb * L.stride + L.dh2 + o] = a;
                  if (valid[rb]) io.d_h2[bt[rb] * H + o] = a;
                });
     __syncthreads();
     // (f) dz1 = act'(h1) * W2^T dh2
-    gemv_t<RB>(w.w2, H, H, H, lds + L.dh2, L.stride, [](int, int) { return 0.f; },
+    gemv_sk<RB, VEC>(w.w2, H, H, H, lds + L.dh2, L.stride, red, [](int, int) { return 0.f; },
                [&](int rb, int o, float a) {
                  const float g = a * act_grad_from_out(lds[rb * L.stride + L.h1 + o], act);
                  lds[rb * L.stride + L.dz1 + o] = g;
@@ -332,13 +336,19 @@ __global__ void mrssm_bwd_kernel(const MtrssmMrssmDims dm, const MtrssmMrssmBwdW
 void set_error(const char* fmt, ...);
 void set_last_kernel(const char* name);
 
-static int pick_rows(int B, int requested, int lds_floats_per_row) {
+static int pick_rows(int B, int requested, size_t bytes_per_row, size_t extra_bytes) {
   if (requested > 0) return requested;
   int rb = 1;
-  // keep ~2 workgroups per CU at most; grow the row tile only for big batches
+  // keep the grid near the CU count; grow the row tile only for big batches
   while (rb < 4 && (B + rb - 1) / rb > 1024) rb *= 2;
-  while (rb > 1 && (size_t)rb * lds_floats_per_row * sizeof(float) > 160 * 1024) rb /= 2;
+  while (rb > 1 && (size_t)rb * (bytes_per_row + extra_bytes) > 160 * 1024) rb /= 2;
   return rb;
+}
+
+static bool aligned16(std::initializer_list<const void*> ptrs) {
+  for (const void* p : ptrs)
+    if (p && ((uintptr_t)p & 15)) return false;
+  return true;
 }
 
 template <typename Kern, typename... Args>
@@ -373,8 +383,15 @@ static int check_dims(const MtrssmMrssmDims* d) {
     set_error("mrssm: unknown activation id %d", d->act);
     return MTRSSM_EINVAL;
   }
+  if (d->threads < 0 || d->threads > 1024 || d->threads % kWave) {
+    set_error("mrssm: threads must be a multiple of 64 in [64, 1024] (0 = default)");
+    return MTRSSM_EINVAL;
+  }
   return MTRSSM_OK;
 }
+
+// split-K scratch: KS * RB * padded O floats <= RB * max(4 * threads, widest output + 3)
+static size_t red_floats(int threads, int widest) { return (size_t)(4 * threads > widest + 3 ? 4 * threads : widest + 3); }
 
 int mrssm_fwd_launch(const MtrssmMrssmDims* d, const MtrssmMrssmFwdWeights* w, const MtrssmMrssmFwdIO* io, hipStream_t stream) {
   if (int rc = check_dims(d)) return rc;
@@ -391,18 +408,22 @@ int mrssm_fwd_launch(const MtrssmMrssmDims* d, const MtrssmMrssmFwdWeights* w, c
     return MTRSSM_EINVAL;
   }
   const MrssmLds L(d->D, d->H, d->K * d->C);
-  const int threads = d->threads > 0 ? d->threads : 256;
-  const int rb = pick_rows(d->B, d->rows_per_block, L.stride);
+  const int threads = d->threads > 0 ? d->threads : 1024;
+  const size_t red = red_floats(threads, 3 * (d->D > d->H ? d->D : d->H)) * sizeof(float);
+  const int rb = pick_rows(d->B, d->rows_per_block, L.stride * sizeof(float), red);
   const int grid = (d->B + rb - 1) / rb;
-  const size_t lds = (size_t)rb * L.stride * sizeof(float);
+  const size_t lds = (size_t)rb * (L.stride * sizeof(float) + red);
   if (rb > threads / kWave) {
     set_error("rows_per_block %d exceeds waves per block %d", rb, threads / kWave);
     return MTRSSM_EINVAL;
   }
-#define MTRSSM_FWD_CASE(R)                                                                          \
-  case R:                                                                                            \
-    return d->post ? launch("mtrssm::mrssm_fwd_kernel<" #R ", true>", mrssm_fwd_kernel<R, true>, grid, threads, lds, stream, *d, *w, *io)      \
-                   : launch("mtrssm::mrssm_fwd_kernel<" #R ", false>", mrssm_fwd_kernel<R, false>, grid, threads, lds, stream, *d, *w, *io);
+  const bool vec = d->D % 4 == 0 && d->H % 4 == 0 && aligned16({w->w1s_t, w->w2_t, w->wih_t, w->whh_t, w->wh1_t});
+#define MTRSSM_FWD_VARIANT(R, P, V) \
+  launch("mtrssm::mrssm_fwd_kernel<" #R ", " #P ", " #V ">", mrssm_fwd_kernel<R, P, V>, grid, threads, lds, stream, *d, *w, *io)
+#define MTRSSM_FWD_CASE(R)                                                                       \
+  case R:                                                                                         \
+    if (d->post) return vec ? MTRSSM_FWD_VARIANT(R, true, true) : MTRSSM_FWD_VARIANT(R, true, false); \
+    return vec ? MTRSSM_FWD_VARIANT(R, false, true) : MTRSSM_FWD_VARIANT(R, false, false);
   switch (rb) {
     MTRSSM_FWD_CASE(1)
     MTRSSM_FWD_CASE(2)
@@ -412,6 +433,7 @@ int mrssm_fwd_launch(const MtrssmMrssmDims* d, const MtrssmMrssmFwdWeights* w, c
       return MTRSSM_EINVAL;
   }
 #undef MTRSSM_FWD_CASE
+#undef MTRSSM_FWD_VARIANT
 }
 
 int mrssm_bwd_launch(const MtrssmMrssmDims* d, const MtrssmMrssmBwdWeights* w, const MtrssmMrssmBwdIO* io, hipStream_t stream) {
@@ -423,22 +445,29 @@ int mrssm_bwd_launch(const MtrssmMrssmDims* d, const MtrssmMrssmBwdWeights* w, c
     return MTRSSM_EINVAL;
   }
   const MrssmBwdLds L(d->D, d->H, d->K * d->C);
-  const int threads = d->threads > 0 ? d->threads : 256;
-  const int rb = pick_rows(d->B, d->rows_per_block, L.stride);
+  const int threads = d->threads > 0 ? d->threads : 1024;
+  const size_t red = red_floats(threads, d->D > d->H ? d->D : d->H) * sizeof(float);
+  const int rb = pick_rows(d->B, d->rows_per_block, L.stride * sizeof(float), red);
   const int grid = (d->B + rb - 1) / rb;
-  const size_t lds = (size_t)rb * L.stride * sizeof(float);
+  const size_t lds = (size_t)rb * (L.stride * sizeof(float) + red);
   if (rb > threads / kWave) {
     set_error("rows_per_block %d exceeds waves per block %d", rb, threads / kWave);
     return MTRSSM_EINVAL;
   }
+  const bool vec = d->D % 4 == 0 && d->H % 4 == 0 && aligned16({w->w2, w->wih, w->whh, w->wh1, w->w4, w->wa2, w->wv2});
+#define MTRSSM_BWD_CASE(R)                                                                                              \
+  case R:                                                                                                                \
+    return vec ? launch("mtrssm::mrssm_bwd_kernel<" #R ", true>", mrssm_bwd_kernel<R, true>, grid, threads, lds, stream, *d, *w, *io) \
+               : launch("mtrssm::mrssm_bwd_kernel<" #R ", false>", mrssm_bwd_kernel<R, false>, grid, threads, lds, stream, *d, *w, *io);
   switch (rb) {
-    case 1: return launch("mtrssm::mrssm_bwd_kernel<1>", mrssm_bwd_kernel<1>, grid, threads, lds, stream, *d, *w, *io);
-    case 2: return launch("mtrssm::mrssm_bwd_kernel<2>", mrssm_bwd_kernel<2>, grid, threads, lds, stream, *d, *w, *io);
-    case 4: return launch("mtrssm::mrssm_bwd_kernel<4>", mrssm_bwd_kernel<4>, grid, threads, lds, stream, *d, *w, *io);
+    MTRSSM_BWD_CASE(1)
+    MTRSSM_BWD_CASE(2)
+    MTRSSM_BWD_CASE(4)
     default:
       set_error("rows_per_block must be 1, 2 or 4 (got %d)", rb);
       return MTRSSM_EINVAL;
   }
+#undef MTRSSM_BWD_CASE
 }
 
 }  // namespace mtrssm

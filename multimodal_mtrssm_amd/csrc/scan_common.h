@@ -78,6 +78,73 @@ __device__ __forceinline__ void gemv_t(const float* __restrict__ M, int ld, int 
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Row-tile GEMV, split-K ("wide O", the scan's workhorse):
+//   out[rb][o] = init(rb, o) + sum_r M[r*ld + o] * vin[rb][r];   fin(rb, o, out)
+// The step is latency-bound (one workgroup streams ~1.7 MB of weights from L2 per timestep), so the point
+// is to have as many independent loads in flight as the CU takes: thread = (column group of W outputs,
+// K slice); a K slice walks rows r = ks, ks+KS, ... with 16-byte loads when VEC (W = 4), the KS partial
+// sums meet in LDS (`red`, >= blockDim.x * W * RB floats) and the first O threads finish.
+// Contains two barriers; callers need no barrier between the GEMV and a consumer of fin()'s LDS writes
+// other than their usual one.
+// ---------------------------------------------------------------------------------------
+template <int RB, bool VEC, typename Init, typename Fin>
+__device__ __forceinline__ void gemv_sk(const float* __restrict__ M, int ld, int R, int O, const float* vin,
+                                        int vin_stride, float* red, Init init, Fin fin) {
+  constexpr int W = VEC ? 4 : 1;
+  const int nthr = blockDim.x;
+  const int CG = (O + W - 1) / W;              // column groups of W outputs
+  const int CGP = CG < nthr ? CG : nthr;       // column groups per pass
+  int KS = nthr / CGP;                         // K slices
+  if (KS > R) KS = R;
+  const int OP = CG * W;                       // padded output extent (row length of `red`)
+  const int t = threadIdx.x;
+  const int lcg = t % CGP, ks = t / CGP;
+  for (int base = 0; base < CG; base += CGP) {  // a single pass unless O/W exceeds the block
+    const int cg = base + lcg;
+    if (cg < CG && ks < KS) {
+      float acc[RB][W];
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int j = 0; j < W; ++j) acc[rb][j] = 0.f;
+      const float* m = M + (size_t)cg * W;
+#pragma unroll 4
+      for (int r = ks; r < R; r += KS) {
+        float w[W];
+        if constexpr (VEC) {
+          const float4 q = *reinterpret_cast<const float4*>(m + (size_t)r * ld);
+          w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
+        } else {
+          w[0] = m[(size_t)r * ld];
+        }
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+          const float v = vin[rb * vin_stride + r];
+#pragma unroll
+          for (int j = 0; j < W; ++j) acc[rb][j] = fmaf(w[j], v, acc[rb][j]);
+        }
+      }
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int j = 0; j < W; ++j) red[((size_t)ks * RB + rb) * OP + cg * W + j] = acc[rb][j];
+    }
+    __syncthreads();
+    const int o_lo = base * W;
+    const int o_hi = (base + CGP) * W < O ? (base + CGP) * W : O;
+    for (int o = o_lo + t; o < o_hi; o += nthr) {
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        float sum = init(rb, o);
+        for (int k = 0; k < KS; ++k) sum += red[((size_t)k * RB + rb) * OP + o];
+        fin(rb, o, sum);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // Wave-per-output dot products ("narrow O"): acc[rb] = sum_r wrow[r] * vin[rb][r], all lanes return the sum.
 // wrow is one contiguous weight row in global memory; lanes stride r (coalesced), butterfly reduce.
 template <int RB>
