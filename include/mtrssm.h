@@ -335,7 +335,8 @@ int mtrssm_mmtrssm_rollout_bwd(const MtrssmMmtrssmDims* dims, const MtrssmMmtrss
  *
  * mtrssm_conv_weight_grad accumulates (atomically; the caller zeroes dwp)
  *   dwp[co][ty*KW+tx][c] += sum_{n, y<Hq, x<Wq} preA(a[n,co,y,x]) * pre(S[n,c,y*SS+ty*TS+OFFY,x*SS+tx*TS+OFFX])
- * with a of shape [N, Cout, Hq, Wq] (geometry must have OS=1, QY=QX=0).
+ * with a of shape [N, Cout, Hq, Wq] (geometry must have OS=1, QY=QX=0).  When dbias != NULL (allowed only with
+ * pre_act_a == 0) it also accumulates the bias gradient dbias[co] += sum_{n,y,x} a[n,co,y,x] in the same pass.
  * ------------------------------------------------------------------------------------------ */
 typedef struct MtrssmConvGeom {
   int32_t N;                    /* frames (B*T) */
@@ -355,7 +356,7 @@ typedef struct MtrssmConvGeom {
 int mtrssm_conv_gather_gemm(const MtrssmConvGeom* g, const float* src, const float* src2, const float* wp,
                             const float* bias, const float* actgrad_in, float* out, void* stream);
 int mtrssm_conv_weight_grad(const MtrssmConvGeom* g, const float* a, const float* src, const float* src2,
-                            int32_t pre_act_a, float* dwp, void* stream);
+                            int32_t pre_act_a, float* dwp, float* dbias, void* stream);
 /* out[c] += sum_{n, i<HW} x[n, c, i]   (bias gradients; the caller zeroes out) */
 int mtrssm_channel_sum(const float* x, int32_t N, int32_t C, int32_t HW, float* out, void* stream);
 

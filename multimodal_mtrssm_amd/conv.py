@@ -107,22 +107,26 @@ def _conv_transposed_gather(y: Tensor, w: Tensor, bias: Tensor | None, stride: i
 
 
 def _weight_grad(a: Tensor, src: Tensor, coords: Tensor | None, kh: int, kw: int, stride: int, pad: int, pre_act_a: bool,
-                 pre_act_src: bool, act: int) -> Tensor:  # noqa: FBT001
-    """``dw[o][i][ky][kx] = sum preA(a)[n,o,y,x] * pre(src ++ coords)[n,i,y*s-p+ky,x*s-p+kx]`` -> ``[O][I][kh][kw]``."""
+                 pre_act_src: bool, act: int, *, want_bias: bool = False) -> tuple[Tensor, Tensor | None]:  # noqa: FBT001
+    """``dw[o][i][ky][kx] = sum preA(a)[n,o,y,x] * pre(src ++ coords)[n,i,y*s-p+ky,x*s-p+kx]`` -> ``[O][I][kh][kw]``.
+
+    With ``want_bias`` (only when ``a`` is the raw output gradient) the same pass also returns ``sum_{n,y,x} a``."""
     lib = _lib.load()
     n, o, hq, wq = a.shape
     _, c, hs, ws = src.shape
     c2 = 0 if coords is None else coords.shape[0]
     opad, ipad = _pads(o, c + c2)
     dwp = torch.zeros(opad, kh * kw, ipad, device=a.device, dtype=torch.float32)
+    dbias = torch.zeros(o, device=a.device, dtype=torch.float32) if want_bias else None
     geom = _geom(N=n, C=c, Hs=hs, Ws=ws, C2=c2, Cpad=ipad, KH=kh, KW=kw, SS=stride, TS=1, OFFY=-pad, OFFX=-pad, Hq=hq, Wq=wq,
                  OS=1, QY=0, QX=0, Ho=hq, Wo=wq, Cout=o, CoutPad=opad, pre_act=int(pre_act_src), act=act)
     flops = 2.0 * n * hq * wq * o * kh * kw * (c + c2)
     nbytes = 4.0 * (a.numel() + src.numel())
     _lib.check(_lib.TIMERS.call(
         "mtrssm_conv_weight_grad", lib.mtrssm_conv_weight_grad, C.byref(geom), _lib.ptr(a), _lib.ptr(src), _lib.ptr(coords),
-        int(pre_act_a), _lib.ptr(dwp), _lib.stream_ptr(a.device), flops=flops, nbytes=nbytes), "mtrssm_conv_weight_grad")
-    return dwp[:o, :, : c + c2].reshape(o, kh, kw, c + c2).permute(0, 3, 1, 2)
+        int(pre_act_a), _lib.ptr(dwp), _lib.ptr(dbias), _lib.stream_ptr(a.device), flops=flops, nbytes=nbytes),
+        "mtrssm_conv_weight_grad")
+    return dwp[:o, :, : c + c2].reshape(o, kh, kw, c + c2).permute(0, 3, 1, 2), dbias
 
 
 def _channel_sum(x: Tensor) -> Tensor:
@@ -157,8 +161,12 @@ class _Conv2d(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             g_x = _conv_transposed_gather(g_out, weight[:, :c], None, stride, pad, (x.shape[2], x.shape[3]), False, act,
                                           actgrad_in=x if pre_act else None)
-        g_w = _weight_grad(g_out, x, coords, kh, kw, stride, pad, False, pre_act, act) if ctx.needs_input_grad[1] else None
-        g_b = _channel_sum(g_out) if has_bias and ctx.needs_input_grad[2] else None
+        g_w = g_b = None
+        want_b = has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1]:
+            g_w, g_b = _weight_grad(g_out, x, coords, kh, kw, stride, pad, False, pre_act, act, want_bias=want_b)
+        elif want_b:
+            g_b = _channel_sum(g_out)
         return g_x, g_w, g_b, None, None, None, None, None
 
 
@@ -188,7 +196,7 @@ class _ConvTranspose2d(torch.autograd.Function):
         g_w = None
         if ctx.needs_input_grad[1]:
             # dW[ci][co][ky][kx] = sum pre(x)[n,ci,y,x] dOut[n,co,y*s-p+ky,x*s-p+kx]
-            g_w = _weight_grad(x, g_out, None, kh, kw, stride, pad, pre_act, False, act)
+            g_w, _ = _weight_grad(x, g_out, None, kh, kw, stride, pad, pre_act, False, act)
         g_b = _channel_sum(g_out) if has_bias and ctx.needs_input_grad[2] else None
         return g_x, g_w, g_b, None, None, None, None, None
 

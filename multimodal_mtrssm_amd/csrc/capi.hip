@@ -23,7 +23,7 @@ int mrssm_bwd_launch(const MtrssmMrssmDims*, const MtrssmMrssmBwdWeights*, const
 int mmtrssm_fwd_launch(const MtrssmMmtrssmDims*, const MtrssmMmtrssmFwdWeights*, const MtrssmMmtrssmFwdIO*, hipStream_t);
 int mmtrssm_bwd_launch(const MtrssmMmtrssmDims*, const MtrssmMmtrssmBwdWeights*, const MtrssmMmtrssmBwdIO*, hipStream_t);
 int conv_gather_gemm_launch(const MtrssmConvGeom*, const float*, const float*, const float*, const float*, const float*, float*, hipStream_t);
-int conv_weight_grad_launch(const MtrssmConvGeom*, const float*, const float*, const float*, int, float*, hipStream_t);
+int conv_weight_grad_launch(const MtrssmConvGeom*, const float*, const float*, const float*, int, float*, float*, hipStream_t);
 int channel_sum_launch(const float*, int, int, int, float*, hipStream_t);
 int nll_fwd_launch(const float*, const float*, int64_t, int64_t, float*, hipStream_t);
 int nll_bwd_launch(const float*, const float*, const float*, int64_t, int64_t, float*, hipStream_t);
@@ -71,8 +71,8 @@ MTRSSM_API int mtrssm_conv_gather_gemm(const MtrssmConvGeom* g, const float* src
   return conv_gather_gemm_launch(g, src, src2, wp, bias, actgrad_in, out, static_cast<hipStream_t>(stream));
 }
 MTRSSM_API int mtrssm_conv_weight_grad(const MtrssmConvGeom* g, const float* a, const float* src, const float* src2, int32_t pre_act_a,
-                                       float* dwp, void* stream) {
-  return conv_weight_grad_launch(g, a, src, src2, pre_act_a, dwp, static_cast<hipStream_t>(stream));
+                                       float* dwp, float* dbias, void* stream) {
+  return conv_weight_grad_launch(g, a, src, src2, pre_act_a, dwp, dbias, static_cast<hipStream_t>(stream));
 }
 MTRSSM_API int mtrssm_channel_sum(const float* x, int32_t N, int32_t C, int32_t HW, float* out, void* stream) {
   return channel_sum_launch(x, N, C, HW, out, static_cast<hipStream_t>(stream));

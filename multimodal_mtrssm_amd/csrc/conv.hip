@@ -304,7 +304,7 @@ struct PatchGeom {
 template <int NT>
 __global__ __launch_bounds__(2 * kConvThreads) void conv_weight_grad_patch_kernel(
     const MtrssmConvGeom g, const float* __restrict__ a, const float* __restrict__ src, const float* __restrict__ src2,
-    const int pre_act_a, float* __restrict__ dwp) {
+    const int pre_act_a, float* __restrict__ dwp, float* __restrict__ dbias) {
   // 8 waves: waves 0-3 issue MFMAs on LDS buffer `cur`, waves 4-7 stage the next group into the other buffer
   // (wave specialisation: each SIMD holds one compute wave and one loader wave), one barrier per group.
   constexpr int TCO = 32 * NT;
@@ -418,6 +418,10 @@ __global__ __launch_bounds__(2 * kConvThreads) void conv_weight_grad_patch_kerne
     for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[s][j][r] = 0.f;
+  float bsum[NT];  // bias gradient = row sums of the A tile (raw a, never pre-activated); kept by compute wave 0
+#pragma unroll
+  for (int j = 0; j < NT; ++j) bsum[j] = 0.f;
+  const bool do_bias = dbias != nullptr && wave == 0;
 
   __syncthreads();  // pixtab
   int cur = 1;      // iteration gbeg-1 only stages group gbeg into buffer 0 (single call site of stage())
@@ -434,6 +438,10 @@ __global__ __launch_bounds__(2 * kConvThreads) void conv_weight_grad_patch_kerne
         float av[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) av[j] = a_lds[(j * 32 + il) * kLDA + pix];
+        if (do_bias) {
+#pragma unroll
+          for (int j = 0; j < NT; ++j) bsum[j] += av[j];
+        }
 #pragma unroll
         for (int s = 0; s < kMaxQ; ++s) {
           if (s < nsl) {
@@ -446,6 +454,14 @@ __global__ __launch_bounds__(2 * kConvThreads) void conv_weight_grad_patch_kerne
     }
     __syncthreads();
     cur ^= 1;
+  }
+  if (do_bias) {  // lanes il and il+32 hold the even / odd pixels of row il
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const float tot = bsum[j] + __shfl_xor(bsum[j], 32, kWave);
+      const int co = co0 + j * 32 + il;
+      if (kl == 0 && co < g.Cout) atomicAdd(&dbias[co], tot);
+    }
   }
 
   if (!loader) {
@@ -671,7 +687,7 @@ constexpr int kThinOut = 5;
 
 __global__ __launch_bounds__(kConvThreads) void conv_weight_grad_thin_kernel(
     const MtrssmConvGeom g, const float* __restrict__ a, const float* __restrict__ src, const float* __restrict__ src2,
-    const int pre_act_a, float* __restrict__ dwp) {
+    const int pre_act_a, float* __restrict__ dwp, float* __restrict__ dbias) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const PatchGeom pg(g, kGP);
   const int ctot = g.C + g.C2;
@@ -709,6 +725,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_weight_grad_thin_kernel(
     }
   }
   const int apix = tid & (kGP - 1), arow0 = tid >> 6;
+  float bsum = 0.f;  // thread t < Cout: bias gradient of channel t
   for (long grp = gbeg; grp < gend; ++grp) {
     const long p0 = grp * kGP;
     {
@@ -748,6 +765,13 @@ __global__ __launch_bounds__(kConvThreads) void conv_weight_grad_thin_kernel(
       }
     }
     __syncthreads();
+    if (dbias && tid < g.Cout) {
+      const float* ar = a_lds + tid * kLDA;
+      float t = 0.f;
+#pragma unroll 8
+      for (int pix = 0; pix < kGP; ++pix) t += ar[pix];
+      bsum += t;
+    }
 #pragma unroll
     for (int s = 0; s < kThinOut; ++s) {
       if (arow[s] >= 0) {
@@ -770,6 +794,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_weight_grad_thin_kernel(
       atomicAdd(&dwp[((size_t)co * taps + tap) * g.Cpad + c], acc[s]);
     }
   }
+  if (dbias && tid < g.Cout) atomicAdd(&dbias[tid], bsum);
 }
 
 // per-channel sum over (N, H*W): out[c] += sum x[n, c, :]
@@ -835,7 +860,7 @@ int conv_gather_gemm_launch(const MtrssmConvGeom* g, const float* src, const flo
   if (!src || !wp || !out || (g->C2 > 0 && !src2)) { set_error("conv_gather_gemm: null pointer"); return MTRSSM_EINVAL; }
   if ((uintptr_t)wp & 15) { set_error("conv_gather_gemm: packed weights must be 16-byte aligned"); return MTRSSM_EINVAL; }
   const long ptot = (long)g->N * g->Hq * g->Wq;
-  if (g->Cout <= 16 && g->KH * g->KW * (g->C + g->C2) <= kThinMaxK) {  // thin layer: VALU kernel
+  if ((g->Cout <= 8 || g->C + g->C2 <= 2) && g->Cout <= 16 && g->KH * g->KW * (g->C + g->C2) <= kThinMaxK) {  // thin layer: VALU kernel
     const dim3 grid((unsigned)((ptot + kConvThreads - 1) / kConvThreads));
     if (g->Cout <= 2)
       { set_last_kernel("mtrssm::conv_gather_thin_kernel<2>"); hipLaunchKernelGGL(conv_gather_thin_kernel<2>, grid, dim3(kConvThreads), 0, stream, *g, src, src2, wp, bias, actgrad_in, out); }
@@ -872,10 +897,13 @@ int conv_gather_gemm_launch(const MtrssmConvGeom* g, const float* src, const flo
   return launched("conv_gather_gemm");
 }
 
+int channel_sum_launch(const float* x, int N, int C, int HW, float* out, hipStream_t stream);
+
 int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float* src, const float* src2, int pre_act_a,
-                            float* dwp, hipStream_t stream) {
+                            float* dwp, float* dbias, hipStream_t stream) {
   if (int rc = check_geom(g, "conv_weight_grad")) return rc;
   if (!a || !src || !dwp || (g->C2 > 0 && !src2)) { set_error("conv_weight_grad: null pointer"); return MTRSSM_EINVAL; }
+  if (dbias && pre_act_a) { set_error("conv_weight_grad: the fused bias gradient sums the RAW a tensor; pass dbias only with pre_act_a = 0"); return MTRSSM_EINVAL; }
   if (g->OS != 1 || g->QY != 0 || g->QX != 0 || g->KH * g->KW <= 0) { set_error("conv_weight_grad: needs a plain (OS=1) geometry with taps"); return MTRSSM_EINVAL; }
   const long ptot = (long)g->N * g->Hq * g->Wq;
   const int taps = g->KH * g->KW;
@@ -893,7 +921,7 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
       const long groups = (ptot + kGP - 1) / kGP;
       long splits = 1024;
       if (splits > groups) splits = groups;
-      { set_last_kernel("mtrssm::conv_weight_grad_thin_kernel"); hipLaunchKernelGGL(conv_weight_grad_thin_kernel, dim3((unsigned)splits), dim3(kConvThreads), lds_thin, stream, *g, a, src, src2, pre_act_a, dwp); }
+      { set_last_kernel("mtrssm::conv_weight_grad_thin_kernel"); hipLaunchKernelGGL(conv_weight_grad_thin_kernel, dim3((unsigned)splits), dim3(kConvThreads), lds_thin, stream, *g, a, src, src2, pre_act_a, dwp, dbias); }
       return launched("conv_weight_grad(thin)");
     }
     if (tiles && nq <= 4 * kMaxQ && lds <= 150 * 1024) {
@@ -905,10 +933,10 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
       dim3 grid((unsigned)splits, cotiles);
       if (g->Cout > 32) {
         if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(conv_weight_grad_patch_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        { set_last_kernel("mtrssm::conv_weight_grad_patch_kernel<2>"); hipLaunchKernelGGL(conv_weight_grad_patch_kernel<2>, grid, dim3(2 * kConvThreads), lds, stream, *g, a, src, src2, pre_act_a, dwp); }
+        { set_last_kernel("mtrssm::conv_weight_grad_patch_kernel<2>"); hipLaunchKernelGGL(conv_weight_grad_patch_kernel<2>, grid, dim3(2 * kConvThreads), lds, stream, *g, a, src, src2, pre_act_a, dwp, dbias); }
       } else {
         if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(conv_weight_grad_patch_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        { set_last_kernel("mtrssm::conv_weight_grad_patch_kernel<1>"); hipLaunchKernelGGL(conv_weight_grad_patch_kernel<1>, grid, dim3(2 * kConvThreads), lds, stream, *g, a, src, src2, pre_act_a, dwp); }
+        { set_last_kernel("mtrssm::conv_weight_grad_patch_kernel<1>"); hipLaunchKernelGGL(conv_weight_grad_patch_kernel<1>, grid, dim3(2 * kConvThreads), lds, stream, *g, a, src, src2, pre_act_a, dwp, dbias); }
       }
       return launched("conv_weight_grad(patch)");
     }
@@ -922,6 +950,9 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
   if (want > groups) want = groups;
   if (want > 512) want = 512;
   dim3 grid(ctiles, taps, (int)want);
+  if (dbias) {  // the general kernel has no fused bias reduction
+    if (int rc = channel_sum_launch(a, g->N, g->Cout, g->Hq * g->Wq, dbias, stream)) return rc;
+  }
   if (g->Cout > 32)
     { set_last_kernel("mtrssm::conv_weight_grad_kernel<2>"); hipLaunchKernelGGL(conv_weight_grad_kernel<2>, grid, dim3(kConvThreads), 0, stream, *g, a, src, src2, pre_act_a, dwp); }
   else
