@@ -319,8 +319,7 @@ __global__ __launch_bounds__(2 * kConvThreads) void conv_weight_grad_patch_kerne
   const int lw = wave & 3, ltid = tid & (kConvThreads - 1);
   const int kl = lane >> 5, il = lane & 31;
   const int taps = g.KH * g.KW;
-  const int nct = (ctot + 31) / 32;
-  const int nq = taps * nct;
+  const int nq = (taps * ctot + 31) / 32;
   const int co0 = blockIdx.y * TCO;
   const int plane_s = g.Hs * g.Ws, plane_a = g.Hq * g.Wq;
   const long ptot = (long)g.N * plane_a;
@@ -396,7 +395,8 @@ __global__ __launch_bounds__(2 * kConvThreads) void conv_weight_grad_patch_kerne
     }
   };
 
-  // ---- compute role state: this wave's column tiles (tile q = lw + 4 s -> tap q / nct, channel tile q % nct)
+  // ---- compute role state: this wave's column tiles.  Columns are the FLATTENED (tap, channel) index
+  // f = tap * ctot + c, cut into tiles of 32 (tile q = lw + 4 s): a 5-channel 3x3 layer needs 2 tiles, not 9.
   int cbase[kMaxQ];
   int nsl = 0;
 #pragma unroll
@@ -405,10 +405,12 @@ __global__ __launch_bounds__(2 * kConvThreads) void conv_weight_grad_patch_kerne
     cbase[s] = -1;
     if (q < nq) {
       nsl = s + 1;
-      const int tap = q / nct, ct = q - tap * nct;
-      const int ty = tap / g.KW, tx = tap - ty * g.KW;
-      const int c = ct * 32 + il;
-      if (c < ctot) cbase[s] = c * pg.ps + ty * pg.pw + tx;
+      const int f = q * 32 + il;
+      if (f < taps * ctot) {
+        const int tap = f / ctot, c = f - tap * ctot;
+        const int ty = tap / g.KW, tx = tap - ty * g.KW;
+        cbase[s] = c * pg.ps + ty * pg.pw + tx;
+      }
     }
   }
   f32x16 acc[kMaxQ][NT];
@@ -467,18 +469,16 @@ __global__ __launch_bounds__(2 * kConvThreads) void conv_weight_grad_patch_kerne
   if (!loader) {
 #pragma unroll
     for (int s = 0; s < kMaxQ; ++s) {
-      const int q = lw + 4 * s;
-      if (q < nq) {
-        const int tap = q / nct, c = (q - tap * nct) * 32 + il;
-        if (c < ctot) {
+      const int f = (lw + 4 * s) * 32 + il;
+      if (lw + 4 * s < nq && f < taps * ctot) {
+        const int tap = f / ctot, c = f - tap * ctot;
 #pragma unroll
-          for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int co = co0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
-              if (co < g.Cout) atomicAdd(&dwp[((size_t)co * taps + tap) * g.Cpad + c], acc[s][j][r]);
-            }
-        }
+          for (int r = 0; r < 16; ++r) {
+            const int co = co0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
+            if (co < g.Cout) atomicAdd(&dwp[((size_t)co * taps + tap) * g.Cpad + c], acc[s][j][r]);
+          }
       }
     }
   }
@@ -912,12 +912,14 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
   if (g->TS == 1 && g->Wq <= kGP && kGP % g->Wq == 0) {
     const PatchGeom pg(*g, kGP);
     const bool tiles = (g->Hq % pg.rpg == 0) || (pg.rpg % g->Hq == 0);
-    const int nq = taps * ((ctot + 31) / 32);
+    const int nq = (taps * ctot + 31) / 32;
     const int tco = g->Cout > 32 ? 64 : 32;
     const size_t lds = (2 * ((size_t)tco * kLDA + (size_t)ctot * pg.ps) + kGP) * sizeof(float);
     const int n_out = g->Cout * taps * ctot;
     const size_t lds_thin = ((size_t)g->Cout * kLDA + (size_t)ctot * pg.ps + kGP) * sizeof(float);
-    if (tiles && n_out <= kThinOut * kConvThreads && lds_thin <= 64 * 1024) {  // thin layer: VALU reduction
+    const bool mfma_ok = nq <= 4 * kMaxQ && lds <= 150 * 1024;
+    (void)mfma_ok;
+    if (tiles && n_out <= kThinOut * kConvThreads && lds_thin <= 64 * 1024) {  // thin layer: staging-bound, VALU reduction is faster
       const long groups = (ptot + kGP - 1) / kGP;
       long splits = 1024;
       if (splits > groups) splits = groups;
