@@ -38,13 +38,21 @@ WORKLOAD = dict(batch_per_gpu=64, steps=50, deter=200, hidden=200, classes=5, ca
                 vision=(1, 64, 64), audio=(1, 128, 32))
 
 
-def build_model(device: str):  # noqa: ANN201
+def build_model(device: str, kind: str = "mrssm"):  # noqa: ANN201
     import multimodal_mtrssm_amd as mt
     from multimodal_mtrssm_amd.factory import decoder_config, encoder_config
 
     w = WORKLOAD
-    feat = w["deter"] + w["classes"] * w["cats"]
     torch.manual_seed(42)  # yaml: seed_everything: 42
+    if kind == "mmtrssm":  # BASELINE configs[2]: two-timescale MTState variant, same dims (ld = hd = 200, ls = hs = 30)
+        feat = 2 * (w["deter"] + w["classes"] * w["cats"])
+        model = mt.make_mmtrssm(
+            hd=w["deter"], hs=(w["classes"], w["cats"]), ld=w["deter"], ls=(w["classes"], w["cats"]), hidden=w["hidden"],
+            action=w["action"], embed=w["embed"], enc_audio=encoder_config(w["audio"], w["embed"]),
+            enc_vision=encoder_config(w["vision"], w["embed"]), dec_audio=decoder_config(feat, w["audio"]),
+            dec_vision=decoder_config(feat, w["vision"]))
+        return model.to(device)
+    feat = w["deter"] + w["classes"] * w["cats"]
     model = mt.make_mrssm(
         deter=w["deter"], hidden=w["hidden"], classes=w["classes"], cats=w["cats"], action=w["action"], embed=w["embed"],
         enc_audio=encoder_config(w["audio"], w["embed"]), enc_vision=encoder_config(w["vision"], w["embed"]),
@@ -141,6 +149,9 @@ def main() -> None:  # noqa: PLR0914, PLR0915
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--model", choices=("mrssm", "mmtrssm"), default="mrssm",
+                    help="mrssm = BASELINE configs[1] (the metric's config); mmtrssm = configs[2] (MTState variant)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even for one rank (exercises the N>1 code path)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -152,8 +163,10 @@ def main() -> None:  # noqa: PLR0914, PLR0915
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
 
     import multimodal_mtrssm_amd as mt
@@ -161,27 +174,26 @@ def main() -> None:  # noqa: PLR0914, PLR0915
     from multimodal_mtrssm_amd.optim import FlatParameters
 
     w = WORKLOAD
-    model = build_model(device)
+    model = build_model(device, args.model)
     flat = FlatParameters(model, extra=8)
     dp = mt.FlatDataParallel(flat)
     dp.broadcast_parameters(0)
     opt = mt.FlatAdamW(flat, lr=1e-3, clip_norm=10.0)
     b = w["batch_per_gpu"]
     batch = synthetic_batch(b, device, seed=1000 + rank)  # each rank owns its own 64 sequences (weak scaling)
-    gnoise = torch.Generator(device=device).manual_seed(7 + rank)
+    torch.manual_seed(7 + rank)
 
     def train_step() -> dict[str, torch.Tensor]:
-        noise = {"u_init": torch.rand(b, w["cats"], device=device, generator=gnoise),
-                 "u_post": torch.rand(b, w["steps"], w["cats"], device=device, generator=gnoise)}
+        noise = None  # uniforms are drawn on the device inside shared_step (torch.rand), as in training
         opt.zero_grad()
         out = model.shared_step(batch, noise)
         out["loss"].backward()
-        scalars = dp.sync({k: out[k] for k in ("loss", "recon", "kl")})
+        scalars = dp.sync({k: out[k] for k in out})
         opt.step(grad_scale=dp.grad_scale)
         return scalars
 
     def barrier() -> None:
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -197,7 +209,7 @@ def main() -> None:  # noqa: PLR0914, PLR0915
     kernel_ms = scan.KERNEL_TIMERS.summary()
     scan.KERNEL_TIMERS.disable()
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -227,7 +239,7 @@ def main() -> None:  # noqa: PLR0914, PLR0915
                                "tflops": round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 2) if v["total_ms"] else None}
                            for k, v in sorted(kernel_ms.items(), key=lambda kv: -kv[1]["total_ms"])}
         line = {
-            "metric": "seq-steps/s (BxT) MoPoE-MRSSM train step",
+            "metric": "seq-steps/s (BxT) MoPoE-MRSSM train step" if args.model == "mrssm" else "seq-steps/s (BxT) MoPoE-MMTRSSM train step",
             "value": seq_steps / (elapsed / args.steps),
             "unit": "seq-steps/s",
             "n_gpus": world,
@@ -240,7 +252,9 @@ def main() -> None:  # noqa: PLR0914, PLR0915
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[1]: MoPoE-MRSSM train step, B=64/GPU T=50 deter=200 stoch=30, vision 1x64x64 + audio 1x128x32 + action 4",
+                "workload": ("BASELINE configs[1]: MoPoE-MRSSM train step, B=64/GPU T=50 deter=200 stoch=30, vision 1x64x64 + audio 1x128x32 + action 4"
+                             if args.model == "mrssm" else
+                             "BASELINE configs[2]: MoPoE-MMTRSSM (MTState, tau 2/4) train step, B=64/GPU T=50 ld=hd=200 ls=hs=30, same frames"),
                 "global_batch": b * world, "seq_len": w["steps"], "parallelism": f"dp{world}",
                 "hidden": w["hidden"], "embed": w["embed"], "categoricals_x_classes": f"{w['cats']}x{w['classes']}",
                 "enc_channels": [8, 16, 32], "dec_channels": [32, 16, 1], "residual_blocks": 3, "activation": "ELU",
@@ -252,7 +266,7 @@ def main() -> None:  # noqa: PLR0914, PLR0915
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -23,12 +23,13 @@ class FlatDataParallel:
     def __init__(self, flat: FlatParameters, process_group: dist.ProcessGroup | None = None) -> None:
         self.flat = flat
         self.group = process_group
-        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        self.active = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(process_group) if self.active else 1
+        self.rank = dist.get_rank(process_group) if self.active else 0
 
     def broadcast_parameters(self, src: int = 0) -> None:
         """Make every rank start from rank ``src``'s weights (one broadcast of the flat buffer)."""
-        if self.world > 1:
+        if self.active:
             dist.broadcast(self.flat.param, src=src, group=self.group)
 
     def shard(self, batch: tuple[Tensor, ...]) -> tuple[Tensor, ...]:
@@ -54,6 +55,6 @@ class FlatDataParallel:
             raise ValueError(msg)
         for i, k in enumerate(keys):
             self.flat.tail[i].copy_(scalars[k].detach().reshape(()))  # type: ignore[index]
-        if self.world > 1:
+        if self.active:  # also with one rank: same code path, the collective is then a no-op copy
             dist.all_reduce(self.flat.grad_full, op=dist.ReduceOp.SUM, group=self.group)
         return {k: self.flat.tail[i] / self.world for i, k in enumerate(keys)}

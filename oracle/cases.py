@@ -149,7 +149,19 @@ CASES: dict[str, Case] = {
         "mmtrssm_cfg3dims", "mmtrssm",
         _mmtrssm_dims(200, (5, 6), 200, (5, 6), 200, 4, 256, (1, 16, 8), (1, 8, 8), **_SMALL), 4, 8, (1, 16, 8), (1, 8, 8), query=4,
     ),
+    # BASELINE "Large" core dims (deter=1024 stoch=128=8x16, hidden=1024, embed=1024) at a tiny B, T: exercises the
+    # > 64 KiB dynamic-LDS path of the scan kernels.  Not a golden fixture (weights too large): GPU-vs-oracle only.
+    "mrssm_large": Case(
+        "mrssm_large", "mrssm",
+        _mrssm_dims(1024, 1024, 8, 16, 4, 1024, (1, 16, 8), (1, 8, 8), **_SMALL), 3, 4, (1, 16, 8), (1, 8, 8), query=2,
+    ),
+    "mmtrssm_large": Case(
+        "mmtrssm_large", "mmtrssm",
+        _mmtrssm_dims(512, (8, 16), 512, (8, 16), 512, 4, 512, (1, 16, 8), (1, 8, 8), **_SMALL), 3, 4, (1, 16, 8), (1, 8, 8), query=2,
+    ),
 }
+
+GOLDEN_CASES = ("mrssm_default", "mrssm_nonsquare", "mrssm_cfg2dims", "mmtrssm_default", "mmtrssm_cfg3dims")
 
 
 def build_model(case: Case) -> torch.nn.Module:

@@ -41,7 +41,7 @@ GOLDEN = ROOT / "tests" / "golden"
 sys.path.insert(0, str(ROOT))
 
 from oracle import ref_dists  # noqa: E402
-from oracle.cases import CASES, MARGIN, Case, build_batch, build_model, build_noise, min_margin  # noqa: E402
+from oracle.cases import CASES, GOLDEN_CASES, MARGIN, Case, build_batch, build_model, build_noise, min_margin  # noqa: E402
 
 
 def _mount_reference() -> None:
@@ -303,7 +303,7 @@ def main() -> None:
     _mount_reference()
     cls = _ref_classes()
     GOLDEN.mkdir(parents=True, exist_ok=True)
-    for name in (sys.argv[1:] or list(CASES)):
+    for name in (sys.argv[1:] or list(GOLDEN_CASES)):
         fx = _run_case(CASES[name], cls)
         path = GOLDEN / f"{name}.npz"
         np.savez_compressed(path, **fx)

@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 import torch
 
-from oracle.cases import CASES, build_batch, build_model, build_noise, with_sizes
+from oracle.cases import CASES, GOLDEN_CASES, build_batch, build_model, build_noise, with_sizes
 from tests.conftest import check_weight_sums, golden_batch, golden_noise, load_golden, product_from_case
 
 pytestmark = pytest.mark.gpu
@@ -51,7 +51,7 @@ def lib_loaded() -> None:
 # ---------------------------------------------------------------------------------------------
 # shared_step: losses + gradients
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("name", list(GOLDEN_CASES))
 def test_shared_step_matches_golden_and_oracle(name: str, lib_loaded: None) -> None:
     case = CASES[name]
     fx = load_golden(name)
@@ -89,7 +89,7 @@ def test_shared_step_matches_golden_and_oracle(name: str, lib_loaded: None) -> N
 # ---------------------------------------------------------------------------------------------
 # rollout_representation / rollout_transition / State API
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", [n for n in CASES if CASES[n].kind == "mrssm"])
+@pytest.mark.parametrize("name", [n for n in GOLDEN_CASES if CASES[n].kind == "mrssm"])
 def test_mrssm_rollout_matches_golden(name: str, lib_loaded: None) -> None:
     import multimodal_mtrssm_amd as mt
 
@@ -134,7 +134,7 @@ def test_mrssm_rollout_matches_golden(name: str, lib_loaded: None) -> None:
         model.rollout_representation(actions=batch[0], observations=batch[1], prev_state=state0)
 
 
-@pytest.mark.parametrize("name", [n for n in CASES if CASES[n].kind == "mmtrssm"])
+@pytest.mark.parametrize("name", [n for n in GOLDEN_CASES if CASES[n].kind == "mmtrssm"])
 def test_mmtrssm_rollout_matches_golden(name: str, lib_loaded: None) -> None:
     import multimodal_mtrssm_amd as mt
 
@@ -173,6 +173,31 @@ def test_mmtrssm_rollout_matches_golden(name: str, lib_loaded: None) -> None:
         assert (_index(trans.stoch_h, d.hs_cats, d.hs_classes) == fx["trans/index_h"]).all()
         joined = mt.cat_mtstates([post[:, :q], trans], dim=1)
         assert joined.feature.shape == post.feature.shape
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE "Large" core dims: the > 64 KiB dynamic-LDS path of the scan kernels (GPU vs oracle, no fixture)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["mrssm_large", "mmtrssm_large"])
+def test_large_dims_match_oracle(name: str, lib_loaded: None) -> None:
+    torch.set_num_threads(8)
+    case = CASES[name]
+    oracle = build_model(case)
+    batch, noise = build_batch(case), build_noise(case)
+    ref = oracle.shared_step(batch, noise)
+    ref["loss"].backward()
+    model = product_from_case(case, oracle, DEV)
+    out = model.shared_step(tuple(b.to(DEV) for b in batch), _to(noise, DEV))
+    out["loss"].backward()
+    for k in out:
+        np.testing.assert_allclose(float(out[k]), float(ref[k]), rtol=1e-4, err_msg=k)
+    names = ("transition.rnn_cell.weight_hh", "representation.rnn_to_post_projector.0.weight") if case.kind == "mrssm" else (
+        "l_rnn._d2h.weight", "h_posterior.0.weight")
+    got = dict(model.named_parameters())
+    want = dict(oracle.named_parameters())
+    for k in names:
+        g = want[k].grad
+        np.testing.assert_allclose(_np(got[k].grad), g.numpy(), rtol=1e-3, atol=1e-3 * float(g.abs().max()), err_msg=k)
 
 
 # ---------------------------------------------------------------------------------------------
