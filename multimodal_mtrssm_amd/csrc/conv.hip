@@ -489,6 +489,9 @@ __global__ __launch_bounds__(2 * kConvThreads) void conv_weight_grad_patch_kerne
 // small frames) x 32*NT output channels.  Per 16-channel chunk the zero-haloed source patch is staged ONCE
 // (activation applied once per element) and every tap reads it at a shifted offset; v1 re-gathers and
 // re-activates the same pixels for each of the KH*KW taps, which made it VALU/L1-bound.
+// (A wave-specialised persistent variant -- 4 MFMA + 4 loader waves, one workgroup per CU, as the weight-gradient
+// kernel uses -- was measured 2x SLOWER here: with only two accumulators per wave a single MFMA wave per SIMD does not
+// keep the pipe fed; six co-resident workgroups of this kernel do.  rocprof: profiles/round1_notes.md.)
 // ------------------------------------------------------------------------------------------------
 template <int NT>
 __global__ __launch_bounds__(kConvThreads) void conv_gather_gemm_patch_kernel(
