@@ -334,60 +334,68 @@ __global__ __launch_bounds__(2 * kConvThreads) void conv_weight_grad_patch_kerne
     pixtab[tid] = ip * pg.ph * pg.pw + lr * g.SS * pg.pw + ox * g.SS;
   }
 
-  // ---- loader role: stage one group (A tile + zero-haloed patch) into buffer `buf`
+  // ---- loader role: stage one group (A tile + zero-haloed patch) into buffer `buf`.
+  // LDS-DMA (global_load_lds_dword: global -> LDS, no VGPR staging): a loader wave keeps ALL of its ~48 row loads of
+  // the group in flight at once -- with register staging next to 160 accumulator registers it could hold 8, and the
+  // MFMA waves spent half their time at the barrier waiting for it (SQ_WAIT_ANY 52 %, profiles/round1_notes.md).
+  // One DMA instruction writes 64 consecutive floats at a wave-uniform LDS base: rows of the A tile (lane = pixel) and
+  // 64-position runs of one patch channel (lane = patch position).  Lanes with nothing to fetch (padding halo, tail)
+  // are exec-masked out of the DMA and store a zero instead; the fused activation runs in place once the data landed.
+  auto dma = [&](const float* gsrc, float* ldst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)ldst, 4, 0, 0);
+  };
   auto stage = [&](long grp, int buf) {
     float* a_lds = lds + (size_t)buf * buf_floats;
     float* patch = a_lds + TCO * kLDA;
     const long p0 = grp * kGP;
-    {
-      const int apix = ltid & (kGP - 1), arow0 = ltid >> 6;
-      const long p = p0 + apix;
+    {  // A tile: loader wave lw owns rows lw, lw+4, ...; lane = pixel
+      const long p = p0 + lane;
       const bool pv = p < ptot;
       int n = 0, rem = 0;
       if (pv) { n = (int)(p / plane_a); rem = (int)(p - (long)n * plane_a); }
       const float* a_n = a + (size_t)n * g.Cout * plane_a + rem;
-#pragma unroll
-      for (int ib = 0; ib < TCO / 4; ib += 8) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int co = co0 + arow0 + 4 * (ib + u);
-          v[u] = (pv && co < g.Cout) ? a_n[(size_t)co * plane_a] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int row = arow0 + 4 * (ib + u);
-          a_lds[row * kLDA + apix] = pre_act_a ? act_fwd(v[u], g.act) : v[u];
-        }
+      for (int row = lw; row < TCO; row += 4) {
+        const int co = co0 + row;
+        if (co >= g.Cout) break;  // rows beyond Cout feed MFMA rows that are never stored
+        float* dst = a_lds + row * kLDA;
+        if (pv) dma(a_n + (size_t)co * plane_a, dst);
+        else dst[lane] = 0.f;
       }
     }
-    {
-      const int n0 = (int)(p0 / plane_a);
-      const int r0 = (int)((p0 - (long)n0 * plane_a) / g.Wq);
-      const int sy0 = r0 * g.SS + g.OFFY, sx0 = g.OFFX;
-      const int phw = pg.ph * pg.pw;
-      for (int rb = 0; rb < pg.ps_raw; rb += 64) {
-        const int r = rb + lane;
-        const bool rv = r < pg.ps_raw;
-        const int ip = r / phw, q = r - ip * phw;
-        const int pr = q / pg.pw, pcn = q - pr * pg.pw;
-        const int n = n0 + ip, sy = sy0 + pr, sx = sx0 + pcn;
-        const bool ok = rv && n < g.N && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
-        const size_t off = (size_t)sy * g.Ws + sx;
-        const float* s_n = src + (size_t)n * g.C * plane_s + off;
-        for (int cb = lw; cb < ctot; cb += 32) {
-          float v[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int c = cb + 4 * u;
-            v[u] = 0.f;
-            if (ok && c < ctot) v[u] = c < g.C ? s_n[(size_t)c * plane_s] : src2[(size_t)(c - g.C) * plane_s + off];
-          }
-          if (rv) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-              const int c = cb + 4 * u;
-              if (c < ctot) patch[c * pg.ps + r] = (g.pre_act && ok) ? act_fwd(v[u], g.act) : v[u];
+    const int n0 = (int)(p0 / plane_a);
+    const int r0 = (int)((p0 - (long)n0 * plane_a) / g.Wq);
+    const int sy0 = r0 * g.SS + g.OFFY, sx0 = g.OFFX;
+    const int phw = pg.ph * pg.pw;
+    for (int rb = 0; rb < pg.ps_raw; rb += 64) {
+      const int r = rb + lane;
+      const bool rv = r < pg.ps_raw;
+      const int ip = r / phw, q = r - ip * phw;
+      const int pr = q / pg.pw, pcn = q - pr * pg.pw;
+      const int n = n0 + ip, sy = sy0 + pr, sx = sx0 + pcn;
+      const bool ok = rv && n < g.N && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
+      const size_t off = (size_t)sy * g.Ws + sx;
+      const float* s_n = src + (size_t)n * g.C * plane_s + off;
+      for (int c = lw; c < ctot; c += 4) {
+        float* dst = patch + c * pg.ps + rb;
+        if (ok) dma(c < g.C ? s_n + (size_t)c * plane_s : src2 + (size_t)(c - g.C) * plane_s + off, dst);
+        else if (rv) dst[lane] = 0.f;
+      }
+    }
+    if (g.pre_act || pre_act_a) {  // in-place activation once the DMA data has landed (this wave's own rows only)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (pre_act_a) {
+        for (int row = lw; row < TCO && co0 + row < g.Cout; row += 4) {
+          float* d = a_lds + row * kLDA + lane;
+          *d = act_fwd(*d, g.act);
+        }
+      }
+      if (g.pre_act) {
+        for (int rb = 0; rb < pg.ps_raw; rb += 64) {
+          if (rb + lane < pg.ps_raw) {
+            for (int c = lw; c < ctot; c += 4) {
+              float* d = patch + c * pg.ps + rb + lane;
+              *d = act_fwd(*d, g.act);
             }
           }
         }
