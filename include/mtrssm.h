@@ -323,10 +323,11 @@ int mtrssm_mmtrssm_rollout_bwd(const MtrssmMmtrssmDims* dims, const MtrssmMmtrss
  * (mrssm/mopoe_mrssm/configs/default.yaml:31-92; called at mrssm core.py:179-180,215-216,272-273).
  *
  * mtrssm_conv_gather_gemm computes, for every frame n and output channel co,
- *   out[n, co, oy*OS+QY, ox*OS+QX] = (bias[co] + sum_{ty<KH, tx<KW} sum_{c<C+C2} wp[co][ty*KW+tx][c] * pre(S[n,c,sy,sx])) * egrad
+ *   out[n, co, oy*OS+QY, ox*OS+QX] = (bias[co] + sum_{ty<KH, tx<KW} sum_{c<C+C2} wp[co][ty*KW+tx][c] * pre(S[n,c,sy,sx])) * egrad + add
  *   sy = oy*SS + ty*TS + OFFY, sx = ox*SS + tx*TS + OFFX (zero outside [0,Hs)x[0,Ws)),  oy < Hq, ox < Wq
  * where S = src for c < C and the frame-independent src2 (coordinate channels) for C <= c < C+C2,
- * pre() = act() if pre_act, and egrad = act'(actgrad_in[same element as out]) when actgrad_in != NULL.
+ * pre() = act() if pre_act, egrad = act'(actgrad_in[same element as out]) when actgrad_in != NULL, and
+ * add = add_in[same element as out] when add_in != NULL (residual skip connection forward; its gradient backward).
  *   Conv2d forward (k,s,p):            KH=KW=k, SS=s, TS=+1, OFF=-p, OS=1, Hq=Ho
  *   Conv2d backward-data / ConvTranspose2d forward: one call per output parity class (qy,qx) in [0,s)^2 with
  *     the taps ky = ky0 + s*ty (ky0 = (qy+p) mod s): SS=1, TS=-1, OFFY=(qy+p-ky0)/s, OS=s, QY=qy.
@@ -354,7 +355,7 @@ typedef struct MtrssmConvGeom {
 } MtrssmConvGeom;
 
 int mtrssm_conv_gather_gemm(const MtrssmConvGeom* g, const float* src, const float* src2, const float* wp,
-                            const float* bias, const float* actgrad_in, float* out, void* stream);
+                            const float* bias, const float* actgrad_in, const float* add_in, float* out, void* stream);
 int mtrssm_conv_weight_grad(const MtrssmConvGeom* g, const float* a, const float* src, const float* src2,
                             int32_t pre_act_a, float* dwp, float* dbias, void* stream);
 /* out[c] += sum_{n, i<HW} x[n, c, i]   (bias gradients; the caller zeroes out) */

@@ -30,7 +30,7 @@ import torch
 from torch import Tensor, nn
 
 from multimodal_mtrssm_amd import _lib
-from multimodal_mtrssm_amd.conv import conv2d, conv_transpose2d
+from multimodal_mtrssm_amd.conv import conv2d, conv_transpose2d, residual_block
 
 
 def _act(name: str) -> nn.Module:
@@ -60,7 +60,7 @@ class ResidualBlock(nn.Module):
         self.act_id = _lib.ACT_IDS[activation_name]
 
     def forward(self, x: Tensor) -> Tensor:
-        return x + _conv(_conv(x, self.conv3, pre_act=True, act=self.act_id), self.conv1, pre_act=True, act=self.act_id)
+        return residual_block(x, self.conv3.weight, self.conv3.bias, self.conv1.weight, self.conv1.bias, act=self.act_id)
 
 
 class Encoder(nn.Module):

@@ -29,11 +29,22 @@ def _pads(cout: int, cin: int) -> tuple[int, int]:
     return _pad_to(cout, 64 if cout > 32 else 32), _pad_to(cin, 16)
 
 
+_PACK_BUFFERS: dict[tuple, Tensor] = {}
+
+
 def pack_weight(w: Tensor) -> Tensor:
-    """``w[O][I][kh][kw]`` -> zero-padded ``wp[OPad][kh*kw][IPad]`` (channel fastest)."""
+    """``w[O][I][kh][kw]`` -> zero-padded ``wp[OPad][kh*kw][IPad]`` (channel fastest).
+
+    The padded buffer is cached per (shape, device, stream) and only its valid region is rewritten: every use is
+    "pack, then enqueue the kernel that reads it" on one stream, so a later pack of another same-shaped layer cannot
+    overtake the earlier kernel; the padding stays zero from the first fill.
+    """
     o, i, kh, kw = w.shape
     opad, ipad = _pads(o, i)
-    wp = torch.zeros(opad, kh * kw, ipad, device=w.device, dtype=torch.float32)
+    key = (o, i, kh, kw, w.device, torch.cuda.current_stream(w.device).cuda_stream if w.is_cuda else 0)
+    wp = _PACK_BUFFERS.get(key)
+    if wp is None:
+        wp = _PACK_BUFFERS[key] = torch.zeros(opad, kh * kw, ipad, device=w.device, dtype=torch.float32)
     if kh * kw > 0:
         wp[:o, :, :i] = w.permute(0, 2, 3, 1).reshape(o, kh * kw, i)
     return wp
@@ -47,7 +58,7 @@ def _geom(**kw: int) -> C.Structure:
 
 
 def _gather_gemm(geom: C.Structure, src: Tensor, src2: Tensor | None, wp: Tensor, bias: Tensor | None,
-                 actgrad_in: Tensor | None, out: Tensor) -> None:
+                 actgrad_in: Tensor | None, out: Tensor, add_in: Tensor | None = None) -> None:
     lib = _lib.load()
     # algorithmic work of this launch: 2 FLOPs per (output element, tap, real channel); bytes = source read once + output written once
     pixels = geom.N * geom.Hq * geom.Wq
@@ -55,12 +66,12 @@ def _gather_gemm(geom: C.Structure, src: Tensor, src2: Tensor | None, wp: Tensor
     nbytes = 4.0 * (geom.N * geom.C * geom.Hs * geom.Ws + pixels * geom.Cout * (2 if actgrad_in is not None else 1))
     _lib.check(_lib.TIMERS.call(
         "mtrssm_conv_gather_gemm", lib.mtrssm_conv_gather_gemm, C.byref(geom), _lib.ptr(src), _lib.ptr(src2), _lib.ptr(wp),
-        _lib.ptr(bias), _lib.ptr(actgrad_in), _lib.ptr(out), _lib.stream_ptr(src.device), flops=flops, nbytes=nbytes),
-        "mtrssm_conv_gather_gemm")
+        _lib.ptr(bias), _lib.ptr(actgrad_in), _lib.ptr(add_in), _lib.ptr(out), _lib.stream_ptr(src.device), flops=flops,
+        nbytes=nbytes), "mtrssm_conv_gather_gemm")
 
 
-def _conv_forward_gather(x: Tensor, coords: Tensor | None, w: Tensor, bias: Tensor | None, stride: int, pad: int,
-                         pre_act: bool, act: int, actgrad_in: Tensor | None = None) -> Tensor:  # noqa: FBT001
+def _conv_forward_gather(x: Tensor, coords: Tensor | None, w: Tensor, bias: Tensor | None, stride: int, pad: int,  # noqa: PLR0913
+                         pre_act: bool, act: int, actgrad_in: Tensor | None = None, add_in: Tensor | None = None) -> Tensor:  # noqa: FBT001
     """``out = (bias + Conv2d_{w}(pre(x ++ coords))) * act'(actgrad_in)``; ``w[O][I][k][k]``."""
     n, c, hs, ws = x.shape
     o, i, kh, kw = w.shape
@@ -74,12 +85,12 @@ def _conv_forward_gather(x: Tensor, coords: Tensor | None, w: Tensor, bias: Tens
     out = torch.empty(n, o, ho, wo, device=x.device, dtype=torch.float32)
     geom = _geom(N=n, C=c, Hs=hs, Ws=ws, C2=c2, Cpad=wp.shape[2], KH=kh, KW=kw, SS=stride, TS=1, OFFY=-pad, OFFX=-pad,
                  Hq=ho, Wq=wo, OS=1, QY=0, QX=0, Ho=ho, Wo=wo, Cout=o, CoutPad=wp.shape[0], pre_act=int(pre_act), act=act)
-    _gather_gemm(geom, x, coords, wp, bias, actgrad_in, out)
+    _gather_gemm(geom, x, coords, wp, bias, actgrad_in, out, add_in)
     return out
 
 
-def _conv_transposed_gather(y: Tensor, w: Tensor, bias: Tensor | None, stride: int, pad: int, out_hw: tuple[int, int],
-                            pre_act: bool, act: int, actgrad_in: Tensor | None = None) -> Tensor:  # noqa: FBT001
+def _conv_transposed_gather(y: Tensor, w: Tensor, bias: Tensor | None, stride: int, pad: int, out_hw: tuple[int, int],  # noqa: PLR0913
+                            pre_act: bool, act: int, actgrad_in: Tensor | None = None, add_in: Tensor | None = None) -> Tensor:  # noqa: FBT001
     """``out[n,c,iy,ix] = (bias[c] + sum_{o,ky,kx} w[o][c][ky][kx] pre(y)[n,o,(iy+p-ky)/s,(ix+p-kx)/s]) * act'(actgrad_in)``.
 
     = Conv2d backward-data (``y`` = dOut, ``w`` the conv weight) = ConvTranspose2d forward (``y`` = input, ``w`` its weight).
@@ -102,7 +113,7 @@ def _conv_transposed_gather(y: Tensor, w: Tensor, bias: Tensor | None, stride: i
                          OFFY=(qy + pad - ky0) // stride, OFFX=(qx + pad - kx0) // stride,
                          Hq=(ho - qy + stride - 1) // stride, Wq=(wo - qx + stride - 1) // stride, OS=stride, QY=qy, QX=qx,
                          Ho=ho, Wo=wo, Cout=c, CoutPad=wp.shape[0], pre_act=int(pre_act), act=act)
-            _gather_gemm(geom, y, None, wp, bias, actgrad_in, out)
+            _gather_gemm(geom, y, None, wp, bias, actgrad_in, out, add_in)
     return out
 
 
@@ -199,6 +210,39 @@ class _ConvTranspose2d(torch.autograd.Function):
             g_w, _ = _weight_grad(x, g_out, None, kh, kw, stride, pad, pre_act, False, act)
         g_b = _channel_sum(g_out) if has_bias and ctx.needs_input_grad[2] else None
         return g_x, g_w, g_b, None, None, None, None, None
+
+
+class _ResidualBlock(torch.autograd.Function):
+    """``y = x + Conv1x1(act(Conv3x3(act(x))))`` as ONE node: the skip add rides in the second conv's epilogue and the
+    skip's gradient in the epilogue of the first conv's backward-data (``oracle/ref_cnn.py:ResidualBlock``)."""
+
+    @staticmethod
+    def forward(ctx, x, w3, b3, w1, b1, act):  # noqa: ANN001, PLR0913
+        x, w3, b3, w1, b1 = (t.contiguous() for t in (x, w3, b3, w1, b1))
+        p3, p1 = w3.shape[2] // 2, w1.shape[2] // 2
+        h = _conv_forward_gather(x, None, w3, b3, 1, p3, True, act)
+        y = _conv_forward_gather(h, None, w1, b1, 1, p1, True, act, add_in=x)
+        ctx.save_for_backward(x, h, w3, w1)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, g_y):  # noqa: ANN001, ANN205
+        x, h, w3, w1 = ctx.saved_tensors
+        act = ctx.act
+        g_y = g_y.contiguous()
+        p3, p1 = w3.shape[2] // 2, w1.shape[2] // 2
+        g_h = _conv_transposed_gather(g_y, w1, None, 1, p1, (h.shape[2], h.shape[3]), False, act, actgrad_in=h)
+        g_w1, g_b1 = _weight_grad(g_y, h, None, w1.shape[2], w1.shape[3], 1, p1, False, True, act, want_bias=True)
+        g_x = None
+        if ctx.needs_input_grad[0]:
+            g_x = _conv_transposed_gather(g_h, w3, None, 1, p3, (x.shape[2], x.shape[3]), False, act, actgrad_in=x, add_in=g_y)
+        g_w3, g_b3 = _weight_grad(g_h, x, None, w3.shape[2], w3.shape[3], 1, p3, False, True, act, want_bias=True)
+        return g_x, g_w3, g_b3, g_w1, g_b1, None
+
+
+def residual_block(x: Tensor, w3: Tensor, b3: Tensor, w1: Tensor, b1: Tensor, *, act: int) -> Tensor:
+    return _ResidualBlock.apply(x, w3, b3, w1, b1, int(act))
 
 
 def conv2d(x: Tensor, weight: Tensor, bias: Tensor | None, *, stride: int, padding: int, pre_act: bool, act: int,  # noqa: PLR0913

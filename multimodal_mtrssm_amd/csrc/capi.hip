@@ -22,7 +22,7 @@ int mrssm_fwd_launch(const MtrssmMrssmDims*, const MtrssmMrssmFwdWeights*, const
 int mrssm_bwd_launch(const MtrssmMrssmDims*, const MtrssmMrssmBwdWeights*, const MtrssmMrssmBwdIO*, hipStream_t);
 int mmtrssm_fwd_launch(const MtrssmMmtrssmDims*, const MtrssmMmtrssmFwdWeights*, const MtrssmMmtrssmFwdIO*, hipStream_t);
 int mmtrssm_bwd_launch(const MtrssmMmtrssmDims*, const MtrssmMmtrssmBwdWeights*, const MtrssmMmtrssmBwdIO*, hipStream_t);
-int conv_gather_gemm_launch(const MtrssmConvGeom*, const float*, const float*, const float*, const float*, const float*, float*, hipStream_t);
+int conv_gather_gemm_launch(const MtrssmConvGeom*, const float*, const float*, const float*, const float*, const float*, const float*, float*, hipStream_t);
 int conv_weight_grad_launch(const MtrssmConvGeom*, const float*, const float*, const float*, int, float*, float*, hipStream_t);
 int channel_sum_launch(const float*, int, int, int, float*, hipStream_t);
 int nll_fwd_launch(const float*, const float*, int64_t, int64_t, float*, hipStream_t);
@@ -67,8 +67,8 @@ MTRSSM_API int mtrssm_adamw_step(float* param, const float* grad, float* exp_avg
                       static_cast<hipStream_t>(stream));
 }
 MTRSSM_API int mtrssm_conv_gather_gemm(const MtrssmConvGeom* g, const float* src, const float* src2, const float* wp, const float* bias,
-                                       const float* actgrad_in, float* out, void* stream) {
-  return conv_gather_gemm_launch(g, src, src2, wp, bias, actgrad_in, out, static_cast<hipStream_t>(stream));
+                                       const float* actgrad_in, const float* add_in, float* out, void* stream) {
+  return conv_gather_gemm_launch(g, src, src2, wp, bias, actgrad_in, add_in, out, static_cast<hipStream_t>(stream));
 }
 MTRSSM_API int mtrssm_conv_weight_grad(const MtrssmConvGeom* g, const float* a, const float* src, const float* src2, int32_t pre_act_a,
                                        float* dwp, float* dbias, void* stream) {

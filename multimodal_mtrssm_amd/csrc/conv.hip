@@ -51,7 +51,7 @@ __device__ __forceinline__ float act_grad_from_in(float x, int act) {
 template <int NT>  // NT = number of 32-channel output tiles per workgroup (1 or 2)
 __global__ __launch_bounds__(kConvThreads) void conv_gather_gemm_kernel(
     const MtrssmConvGeom g, const float* __restrict__ src, const float* __restrict__ src2, const float* __restrict__ wp,
-    const float* __restrict__ bias, const float* __restrict__ actgrad_in, float* __restrict__ out) {
+    const float* __restrict__ bias, const float* __restrict__ actgrad_in, const float* __restrict__ add_in, float* __restrict__ out) {
   constexpr int TCO = 32 * NT;
   constexpr int LDW = kKC + 1;
   __shared__ float g_lds[2][kKC][kTP];
@@ -159,6 +159,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_gather_gemm_kernel(
           float v = acc[j][r] + (bias ? bias[co] : 0.f);
           const size_t o = base + (size_t)co * plane_o;
           if (actgrad_in) v *= act_grad_from_in(actgrad_in[o], g.act);
+          if (add_in) v += add_in[o];
           out[o] = v;
         }
       }
@@ -504,7 +505,7 @@ __global__ __launch_bounds__(2 * kConvThreads) void conv_weight_grad_patch_kerne
 template <int NT>
 __global__ __launch_bounds__(kConvThreads) void conv_gather_gemm_patch_kernel(
     const MtrssmConvGeom g, const float* __restrict__ src, const float* __restrict__ src2, const float* __restrict__ wp,
-    const float* __restrict__ bias, const float* __restrict__ actgrad_in, float* __restrict__ out) {
+    const float* __restrict__ bias, const float* __restrict__ actgrad_in, const float* __restrict__ add_in, float* __restrict__ out) {
   constexpr int TCO = 32 * NT;
   constexpr int LDW = kKC + 1;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -624,6 +625,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_gather_gemm_patch_kernel(
           float v = acc[j][r] + (bias ? bias[co] : 0.f);
           const size_t o = base + (size_t)co * plane_o;
           if (actgrad_in) v *= act_grad_from_in(actgrad_in[o], g.act);
+          if (add_in) v += add_in[o];
           out[o] = v;
         }
       }
@@ -641,7 +643,7 @@ constexpr int kThinMaxK = 256;  // taps * channels
 template <int COT>
 __global__ __launch_bounds__(kConvThreads) void conv_gather_thin_kernel(
     const MtrssmConvGeom g, const float* __restrict__ src, const float* __restrict__ src2, const float* __restrict__ wp,
-    const float* __restrict__ bias, const float* __restrict__ actgrad_in, float* __restrict__ out) {
+    const float* __restrict__ bias, const float* __restrict__ actgrad_in, const float* __restrict__ add_in, float* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) float w_lds[kThinMaxK * COT];
   const int tid = threadIdx.x;
   const int taps = g.KH * g.KW, ctot = g.C + g.C2;
@@ -687,6 +689,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_gather_thin_kernel(
       const size_t o = base + (size_t)j * plane_o;
       float v = acc[j];
       if (actgrad_in) v *= act_grad_from_in(actgrad_in[o], g.act);
+      if (add_in) v += add_in[o];
       out[o] = v;
     }
   }
@@ -866,7 +869,7 @@ static int launched(const char* who) {
 }
 
 int conv_gather_gemm_launch(const MtrssmConvGeom* g, const float* src, const float* src2, const float* wp, const float* bias,
-                            const float* actgrad_in, float* out, hipStream_t stream) {
+                            const float* actgrad_in, const float* add_in, float* out, hipStream_t stream) {
   if (int rc = check_geom(g, "conv_gather_gemm")) return rc;
   if (!src || !wp || !out || (g->C2 > 0 && !src2)) { set_error("conv_gather_gemm: null pointer"); return MTRSSM_EINVAL; }
   if ((uintptr_t)wp & 15) { set_error("conv_gather_gemm: packed weights must be 16-byte aligned"); return MTRSSM_EINVAL; }
@@ -874,11 +877,11 @@ int conv_gather_gemm_launch(const MtrssmConvGeom* g, const float* src, const flo
   if ((g->Cout <= 8 || g->C + g->C2 <= 2) && g->Cout <= 16 && g->KH * g->KW * (g->C + g->C2) <= kThinMaxK) {  // thin layer: VALU kernel
     const dim3 grid((unsigned)((ptot + kConvThreads - 1) / kConvThreads));
     if (g->Cout <= 2)
-      { set_last_kernel("mtrssm::conv_gather_thin_kernel<2>"); hipLaunchKernelGGL(conv_gather_thin_kernel<2>, grid, dim3(kConvThreads), 0, stream, *g, src, src2, wp, bias, actgrad_in, out); }
+      { set_last_kernel("mtrssm::conv_gather_thin_kernel<2>"); hipLaunchKernelGGL(conv_gather_thin_kernel<2>, grid, dim3(kConvThreads), 0, stream, *g, src, src2, wp, bias, actgrad_in, add_in, out); }
     else if (g->Cout <= 8)
-      { set_last_kernel("mtrssm::conv_gather_thin_kernel<8>"); hipLaunchKernelGGL(conv_gather_thin_kernel<8>, grid, dim3(kConvThreads), 0, stream, *g, src, src2, wp, bias, actgrad_in, out); }
+      { set_last_kernel("mtrssm::conv_gather_thin_kernel<8>"); hipLaunchKernelGGL(conv_gather_thin_kernel<8>, grid, dim3(kConvThreads), 0, stream, *g, src, src2, wp, bias, actgrad_in, add_in, out); }
     else
-      { set_last_kernel("mtrssm::conv_gather_thin_kernel<16>"); hipLaunchKernelGGL(conv_gather_thin_kernel<16>, grid, dim3(kConvThreads), 0, stream, *g, src, src2, wp, bias, actgrad_in, out); }
+      { set_last_kernel("mtrssm::conv_gather_thin_kernel<16>"); hipLaunchKernelGGL(conv_gather_thin_kernel<16>, grid, dim3(kConvThreads), 0, stream, *g, src, src2, wp, bias, actgrad_in, add_in, out); }
     return launched("conv_gather_gemm(thin)");
   }
   const int gx = (int)((ptot + kTP - 1) / kTP);
@@ -890,20 +893,20 @@ int conv_gather_gemm_launch(const MtrssmConvGeom* g, const float* src, const flo
     if (tiles && pg.ipg < 32 && lds <= 64 * 1024) {
       if (g->Cout > 32) {
         dim3 grid(gx, g->CoutPad / 64);
-        { set_last_kernel("mtrssm::conv_gather_gemm_patch_kernel<2>"); hipLaunchKernelGGL(conv_gather_gemm_patch_kernel<2>, grid, dim3(kConvThreads), lds, stream, *g, src, src2, wp, bias, actgrad_in, out); }
+        { set_last_kernel("mtrssm::conv_gather_gemm_patch_kernel<2>"); hipLaunchKernelGGL(conv_gather_gemm_patch_kernel<2>, grid, dim3(kConvThreads), lds, stream, *g, src, src2, wp, bias, actgrad_in, add_in, out); }
       } else {
         dim3 grid(gx, 1);
-        { set_last_kernel("mtrssm::conv_gather_gemm_patch_kernel<1>"); hipLaunchKernelGGL(conv_gather_gemm_patch_kernel<1>, grid, dim3(kConvThreads), lds, stream, *g, src, src2, wp, bias, actgrad_in, out); }
+        { set_last_kernel("mtrssm::conv_gather_gemm_patch_kernel<1>"); hipLaunchKernelGGL(conv_gather_gemm_patch_kernel<1>, grid, dim3(kConvThreads), lds, stream, *g, src, src2, wp, bias, actgrad_in, add_in, out); }
       }
       return launched("conv_gather_gemm(patch)");
     }
   }
   if (g->Cout > 32) {
     dim3 grid(gx, g->CoutPad / 64);
-    { set_last_kernel("mtrssm::conv_gather_gemm_kernel<2>"); hipLaunchKernelGGL(conv_gather_gemm_kernel<2>, grid, dim3(kConvThreads), 0, stream, *g, src, src2, wp, bias, actgrad_in, out); }
+    { set_last_kernel("mtrssm::conv_gather_gemm_kernel<2>"); hipLaunchKernelGGL(conv_gather_gemm_kernel<2>, grid, dim3(kConvThreads), 0, stream, *g, src, src2, wp, bias, actgrad_in, add_in, out); }
   } else {
     dim3 grid(gx, 1);
-    { set_last_kernel("mtrssm::conv_gather_gemm_kernel<1>"); hipLaunchKernelGGL(conv_gather_gemm_kernel<1>, grid, dim3(kConvThreads), 0, stream, *g, src, src2, wp, bias, actgrad_in, out); }
+    { set_last_kernel("mtrssm::conv_gather_gemm_kernel<1>"); hipLaunchKernelGGL(conv_gather_gemm_kernel<1>, grid, dim3(kConvThreads), 0, stream, *g, src, src2, wp, bias, actgrad_in, add_in, out); }
   }
   return launched("conv_gather_gemm");
 }
