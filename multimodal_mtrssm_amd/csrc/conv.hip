@@ -597,12 +597,18 @@ __global__ __launch_bounds__(kConvThreads) void conv_gather_gemm_patch_kernel(
       const int tapoff = g.TS > 0 ? ty * pg.pw + tx : (g.KH - 1 - ty) * pg.pw + (g.KW - 1 - tx);
       const float* pb = patch + pixoff + tapoff + kl * pg.ps;
       const float* wb = w_lds + ((size_t)wbuf * TCO + il) * LDW + kl;
+      // all operands of the tap first (8 + 8*NT LDS reads in flight), then the MFMAs: one wait per tap, not per pair
+      float bb[kKC / 2], aa[NT][kKC / 2];
 #pragma unroll
       for (int step = 0; step < kKC / 2; ++step) {
-        const float b = pb[2 * step * pg.ps];
+        bb[step] = pb[2 * step * pg.ps];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[j * 32 * LDW + 2 * step], b, acc[j], 0, 0, 0);
+        for (int j = 0; j < NT; ++j) aa[j][step] = wb[j * 32 * LDW + 2 * step];
       }
+#pragma unroll
+      for (int step = 0; step < kKC / 2; ++step)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[j][step], bb[step], acc[j], 0, 0, 0);
       if (tap + 1 < taps) store_w(wbuf ^ 1);
       __syncthreads();
       wbuf ^= 1;
