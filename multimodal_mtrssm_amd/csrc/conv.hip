@@ -502,14 +502,15 @@ __global__ __launch_bounds__(2 * kConvThreads) void conv_weight_grad_patch_kerne
 // kernel uses -- was measured 2x SLOWER here: with only two accumulators per wave a single MFMA wave per SIMD does not
 // keep the pipe fed; six co-resident workgroups of this kernel do.  rocprof: profiles/round1_notes.md.)
 // ------------------------------------------------------------------------------------------------
-template <int NT>
+template <int NT, int NP>  // NT 32-channel tiles x NP 32-pixel tiles per wave; workgroup tile = 128*NP pixels x 32*NT channels
 __global__ __launch_bounds__(kConvThreads) void conv_gather_gemm_patch_kernel(
     const MtrssmConvGeom g, const float* __restrict__ src, const float* __restrict__ src2, const float* __restrict__ wp,
     const float* __restrict__ bias, const float* __restrict__ actgrad_in, const float* __restrict__ add_in, float* __restrict__ out) {
   constexpr int TCO = 32 * NT;
+  constexpr int TPX = kTP * NP;
   constexpr int LDW = kKC + 1;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const PatchGeom pg(g, kTP);
+  const PatchGeom pg(g, TPX);
   float* patch = lds;                                            // [kKC][ps]
   float* w_lds = patch + (size_t)kKC * pg.ps;                    // [2][TCO][LDW]
   int* rtab = reinterpret_cast<int*>(w_lds + 2 * TCO * LDW);     // [ps_raw]: (frame-in-group << 26) | plane offset, or -1
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_gather_gemm_patch_kernel(
   const int ctot = g.C + g.C2;
   const int plane_s = g.Hs * g.Ws, plane_q = g.Hq * g.Wq;
   const long ptot = (long)g.N * plane_q;
-  const long p0 = (long)blockIdx.x * kTP;
+  const long p0 = (long)blockIdx.x * TPX;
   const int co0 = blockIdx.y * TCO;
   const int n0 = (int)(p0 / plane_q);
   const int r0 = (int)((p0 - (long)n0 * plane_q) / g.Wq);
@@ -538,13 +539,14 @@ __global__ __launch_bounds__(kConvThreads) void conv_gather_gemm_patch_kernel(
       rtab[r] = ok ? ((ip << 26) | (sy * g.Ws + sx)) : -1;
     }
   }
-  // this lane's pixel -> patch offset (B operand: lane il = pixel)
-  int pixoff;
-  {
-    const int pix = wave * 32 + il;
+  // this lane's pixels -> patch offsets (B operand: lane il = pixel); wave w owns pixels [w*32*NP, (w+1)*32*NP)
+  int pixoff[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int pix = (wave * NP + i) * 32 + il;
     const int row = pix / g.Wq, ox = pix - row * g.Wq;
     const int ip = row / pg.rp, lr = row - ip * pg.rp;
-    pixoff = ip * pg.ph * pg.pw + lr * g.SS * pg.pw + ox * g.SS;
+    pixoff[i] = ip * pg.ph * pg.pw + lr * g.SS * pg.pw + ox * g.SS + kl * pg.ps;
   }
   const int wrow = tid >> 2, wcol = (tid & 3) * 4;
   float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -558,11 +560,13 @@ __global__ __launch_bounds__(kConvThreads) void conv_gather_gemm_patch_kernel(
     }
   };
 
-  f32x16 acc[NT];
+  f32x16 acc[NP][NT];
 #pragma unroll
-  for (int j = 0; j < NT; ++j)
+  for (int i = 0; i < NP; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const float* src_n0 = src + (size_t)n0 * g.C * plane_s;
   __syncthreads();  // rtab
@@ -595,44 +599,50 @@ __global__ __launch_bounds__(kConvThreads) void conv_gather_gemm_patch_kernel(
       if (tap + 1 < taps) load_w(tap + 1, c0);
       const int ty = tap / g.KW, tx = tap - ty * g.KW;
       const int tapoff = g.TS > 0 ? ty * pg.pw + tx : (g.KH - 1 - ty) * pg.pw + (g.KW - 1 - tx);
-      const float* pb = patch + pixoff + tapoff + kl * pg.ps;
       const float* wb = w_lds + ((size_t)wbuf * TCO + il) * LDW + kl;
-      // all operands of the tap first (8 + 8*NT LDS reads in flight), then the MFMAs: one wait per tap, not per pair
-      float bb[kKC / 2], aa[NT][kKC / 2];
+      // all operands of the tap first (LDS reads in flight), then the MFMAs: one wait per tap, not per MFMA pair
+      float bb[NP][kKC / 2], aa[NT][kKC / 2];
 #pragma unroll
       for (int step = 0; step < kKC / 2; ++step) {
-        bb[step] = pb[2 * step * pg.ps];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) bb[i][step] = patch[pixoff[i] + tapoff + 2 * step * pg.ps];
 #pragma unroll
         for (int j = 0; j < NT; ++j) aa[j][step] = wb[j * 32 * LDW + 2 * step];
       }
 #pragma unroll
       for (int step = 0; step < kKC / 2; ++step)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[j][step], bb[step], acc[j], 0, 0, 0);
+        for (int i = 0; i < NP; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[j][step], bb[i][step], acc[i][j], 0, 0, 0);
       if (tap + 1 < taps) store_w(wbuf ^ 1);
       __syncthreads();
       wbuf ^= 1;
     }
   }
 
-  const long pe = p0 + wave * 32 + il;
-  if (pe < ptot) {
-    const int n = (int)(pe / plane_q);
-    const int rem = (int)(pe - (long)n * plane_q);
-    const int oy = rem / g.Wq, ox = rem - oy * g.Wq;
-    const size_t plane_o = (size_t)g.Ho * g.Wo;
-    const size_t base = (size_t)n * g.Cout * plane_o + (size_t)(oy * g.OS + g.QY) * g.Wo + (ox * g.OS + g.QX);
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
+  for (int i = 0; i < NP; ++i) {
+    const long pe = p0 + (wave * NP + i) * 32 + il;
+    if (pe < ptot) {
+      const int n = (int)(pe / plane_q);
+      const int rem = (int)(pe - (long)n * plane_q);
+      const int oy = rem / g.Wq, ox = rem - oy * g.Wq;
+      const size_t plane_o = (size_t)g.Ho * g.Wo;
+      const size_t base = (size_t)n * g.Cout * plane_o + (size_t)(oy * g.OS + g.QY) * g.Wo + (ox * g.OS + g.QX);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = co0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
-        if (co < g.Cout) {
-          float v = acc[j][r] + (bias ? bias[co] : 0.f);
-          const size_t o = base + (size_t)co * plane_o;
-          if (actgrad_in) v *= act_grad_from_in(actgrad_in[o], g.act);
-          if (add_in) v += add_in[o];
-          out[o] = v;
+      for (int j = 0; j < NT; ++j) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
+          if (co < g.Cout) {
+            float v = acc[i][j][r] + (bias ? bias[co] : 0.f);
+            const size_t o = base + (size_t)co * plane_o;
+            if (actgrad_in) v *= act_grad_from_in(actgrad_in[o], g.act);
+            if (add_in) v += add_in[o];
+            out[o] = v;
+          }
         }
       }
     }
@@ -891,18 +901,25 @@ int conv_gather_gemm_launch(const MtrssmConvGeom* g, const float* src, const flo
     return launched("conv_gather_gemm(thin)");
   }
   const int gx = (int)((ptot + kTP - 1) / kTP);
-  if ((g->TS == 1 || g->TS == -1) && g->Wq <= kTP && kTP % g->Wq == 0 && g->KH * g->KW > 0 && plane_fits_26bit(g)) {
-    const PatchGeom pg(*g, kTP);
-    const bool tiles = (g->Hq % pg.rpg == 0) || (pg.rpg % g->Hq == 0);
+  if ((g->TS == 1 || g->TS == -1) && g->KH * g->KW > 0 && plane_fits_26bit(g)) {
+    // Tile choice is occupancy-driven (measured, profiles/round1_notes.md): this kernel's MFMA pipe is fed by MANY
+    // co-resident waves, not by big register tiles.  On the 64-channel 3x3 layers: 128 px x 64 ch workgroup tiles
+    // (32 x 64 per wave) 177 us; 256 x 64 (64 x 64 per wave, NP = 2) 235 us; 128 x 32 (twice the workgroups) 176 us.
     const int tco = g->Cout > 32 ? 64 : 32;
-    const size_t lds = ((size_t)kKC * pg.ps + 2 * (size_t)tco * (kKC + 1) + pg.ps_raw) * sizeof(float);
-    if (tiles && pg.ipg < 32 && lds <= 64 * 1024) {
-      if (g->Cout > 32) {
-        dim3 grid(gx, g->CoutPad / 64);
-        { set_last_kernel("mtrssm::conv_gather_gemm_patch_kernel<2>"); hipLaunchKernelGGL(conv_gather_gemm_patch_kernel<2>, grid, dim3(kConvThreads), lds, stream, *g, src, src2, wp, bias, actgrad_in, add_in, out); }
+    const int ny = g->CoutPad / tco;
+    for (int np = 1; np >= 1; --np) {
+      const int tpx = kTP * np;
+      if (g->Wq > tpx || tpx % g->Wq) continue;
+      const PatchGeom pg(*g, tpx);
+      const bool tiles = (g->Hq % pg.rpg == 0) || (pg.rpg % g->Hq == 0);
+      const size_t lds = ((size_t)kKC * pg.ps + 2 * (size_t)tco * (kKC + 1) + pg.ps_raw) * sizeof(float);
+      const long nx = (ptot + tpx - 1) / tpx;
+      if (!tiles || pg.ipg >= 32 || lds > 64 * 1024) continue;
+      const dim3 grid((unsigned)nx, ny);
+      if (tco == 64) {
+        { set_last_kernel("mtrssm::conv_gather_gemm_patch_kernel<2, 1>"); hipLaunchKernelGGL((conv_gather_gemm_patch_kernel<2, 1>), grid, dim3(kConvThreads), lds, stream, *g, src, src2, wp, bias, actgrad_in, add_in, out); }
       } else {
-        dim3 grid(gx, 1);
-        { set_last_kernel("mtrssm::conv_gather_gemm_patch_kernel<1>"); hipLaunchKernelGGL(conv_gather_gemm_patch_kernel<1>, grid, dim3(kConvThreads), lds, stream, *g, src, src2, wp, bias, actgrad_in, add_in, out); }
+        { set_last_kernel("mtrssm::conv_gather_gemm_patch_kernel<1, 1>"); hipLaunchKernelGGL((conv_gather_gemm_patch_kernel<1, 1>), grid, dim3(kConvThreads), lds, stream, *g, src, src2, wp, bias, actgrad_in, add_in, out); }
       }
       return launched("conv_gather_gemm(patch)");
     }
