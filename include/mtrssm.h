@@ -358,6 +358,11 @@ int mtrssm_conv_gather_gemm(const MtrssmConvGeom* g, const float* src, const flo
                             const float* bias, const float* actgrad_in, const float* add_in, float* out, void* stream);
 int mtrssm_conv_weight_grad(const MtrssmConvGeom* g, const float* a, const float* src, const float* src2,
                             int32_t pre_act_a, float* dwp, float* dbias, void* stream);
+/* Last decoder layer (default.yaml:70-74, channels [.., 1]): out[N, Cout<=2, 2Hs, 2Ws] = bias + ConvTranspose2d_{k=4,s=2,p=1}(pre(src[N,C,Hs,Ws]))
+ * with w in the ConvTranspose2d layout [C][Cout][4][4].  All four output parity classes in one pass, one activation per
+ * source element. */
+int mtrssm_convt_k4s2_thin(int32_t N, int32_t C, int32_t Hs, int32_t Ws, int32_t Cout, const float* src, const float* w,
+                           const float* bias, int32_t pre_act, int32_t act, float* out, void* stream);
 /* out[c] += sum_{n, i<HW} x[n, c, i]   (bias gradients; the caller zeroes out) */
 int mtrssm_channel_sum(const float* x, int32_t N, int32_t C, int32_t HW, float* out, void* stream);
 

@@ -103,6 +103,16 @@ def _conv_transposed_gather(y: Tensor, w: Tensor, bias: Tensor | None, stride: i
         raise ValueError(msg)
     ho, wo = out_hw
     out = torch.empty(n, c, ho, wo, device=y.device, dtype=torch.float32)
+    if (stride == 2 and kh == 4 and kw == 4 and pad == 1 and c <= 2 and (ho, wo) == (2 * hs, 2 * ws) and actgrad_in is None
+            and add_in is None and o * ((8 + 2) * (32 + 2) + 1) * 4 <= 64 * 1024):
+        # the decoders' last layer: all four parity classes in one pass (csrc/conv.hip: convt_k4s2_thin_kernel)
+        lib = _lib.load()
+        wc = w.contiguous()
+        _lib.check(_lib.TIMERS.call(
+            "mtrssm_convt_k4s2_thin", lib.mtrssm_convt_k4s2_thin, n, o, hs, ws, c, _lib.ptr(y), _lib.ptr(wc), _lib.ptr(bias),
+            int(pre_act), act, _lib.ptr(out), _lib.stream_ptr(y.device), flops=2.0 * n * ho * wo * c * 4 * o,
+            nbytes=4.0 * (y.numel() + out.numel())), "mtrssm_convt_k4s2_thin")
+        return out
     for qy in range(min(stride, ho)):
         ky0 = (qy + pad) % stride
         for qx in range(min(stride, wo)):

@@ -25,6 +25,7 @@ int mmtrssm_bwd_launch(const MtrssmMmtrssmDims*, const MtrssmMmtrssmBwdWeights*,
 int conv_gather_gemm_launch(const MtrssmConvGeom*, const float*, const float*, const float*, const float*, const float*, const float*, float*, hipStream_t);
 int conv_weight_grad_launch(const MtrssmConvGeom*, const float*, const float*, const float*, int, float*, float*, hipStream_t);
 int channel_sum_launch(const float*, int, int, int, float*, hipStream_t);
+int convt_k4s2_thin_launch(int, int, int, int, int, const float*, const float*, const float*, int, int, float*, hipStream_t);
 int nll_fwd_launch(const float*, const float*, int64_t, int64_t, float*, hipStream_t);
 int nll_bwd_launch(const float*, const float*, const float*, int64_t, int64_t, float*, hipStream_t);
 int sumsq_launch(const float*, int64_t, float*, hipStream_t);
@@ -76,4 +77,8 @@ MTRSSM_API int mtrssm_conv_weight_grad(const MtrssmConvGeom* g, const float* a, 
 }
 MTRSSM_API int mtrssm_channel_sum(const float* x, int32_t N, int32_t C, int32_t HW, float* out, void* stream) {
   return channel_sum_launch(x, N, C, HW, out, static_cast<hipStream_t>(stream));
+}
+MTRSSM_API int mtrssm_convt_k4s2_thin(int32_t N, int32_t C, int32_t Hs, int32_t Ws, int32_t Cout, const float* src, const float* w,
+                                      const float* bias, int32_t pre_act, int32_t act, float* out, void* stream) {
+  return convt_k4s2_thin_launch(N, C, Hs, Ws, Cout, src, w, bias, pre_act, act, out, static_cast<hipStream_t>(stream));
 }

@@ -711,6 +711,75 @@ __global__ __launch_bounds__(kConvThreads) void conv_gather_thin_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Last decoder layer: ConvTranspose2d(k = 4, s = 2, p = 1) to <= 2 output channels with the preceding activation
+// fused.  The generic thin kernel runs one launch per output parity class and re-activates every source value once
+// per tap (expm1f dominates its instruction stream).  Here a workgroup stages act(x) for an 8 x 32 tile of INPUT
+// positions (+1 halo) in LDS once -- one activation per element -- and each thread produces the 2 x 2 output block
+// of its input position from the 3 x 3 neighbourhood: 9 LDS reads + 16 fmas per channel, weights through the
+// scalar cache (wave-uniform addresses).
+// ------------------------------------------------------------------------------------------------
+constexpr int kCtTH = 8, kCtTW = 32, kCtPW = kCtTW + 2, kCtPS = (kCtTH + 2) * kCtPW + 1;
+
+template <int COT>
+__global__ __launch_bounds__(kConvThreads) void convt_k4s2_thin_kernel(
+    const int N, const int C, const int Hs, const int Ws, const int Cout, const float* __restrict__ src,
+    const float* __restrict__ w, const float* __restrict__ bias, const int pre_act, const int act, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [C][kCtPS]
+  const int tid = threadIdx.x;
+  const int x0 = blockIdx.x * kCtTW, y0 = blockIdx.y * kCtTH, n = blockIdx.z;
+  const int plane = Hs * Ws;
+  const float* src_n = src + (size_t)n * C * plane;
+  for (int e = tid; e < (kCtTH + 2) * kCtPW; e += kConvThreads) {
+    const int py = e / kCtPW, px = e - py * kCtPW;
+    const int sy = y0 + py - 1, sx = x0 + px - 1;
+    const bool ok = sy >= 0 && sy < Hs && sx >= 0 && sx < Ws;
+    const int off = sy * Ws + sx;
+    for (int c0 = 0; c0 < C; c0 += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = (ok && c0 + u < C) ? src_n[(size_t)(c0 + u) * plane + off] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (c0 + u < C) lds[(c0 + u) * kCtPS + e] = (pre_act && ok) ? act_fwd(v[u], act) : v[u];
+    }
+  }
+  __syncthreads();
+  const int ty = tid / kCtTW, tx = tid - ty * kCtTW;
+  const int iy = y0 + ty, ix = x0 + tx;
+  if (iy >= Hs || ix >= Ws) return;
+  float o00[COT], o01[COT], o10[COT], o11[COT];
+#pragma unroll
+  for (int j = 0; j < COT; ++j) o00[j] = o01[j] = o10[j] = o11[j] = (bias && j < Cout) ? bias[j] : 0.f;
+  const float* t = lds + (ty + 1) * kCtPW + (tx + 1);
+  for (int c = 0; c < C; ++c, t += kCtPS) {
+    const float v00 = t[-kCtPW - 1], v01 = t[-kCtPW], v02 = t[-kCtPW + 1];
+    const float v10 = t[-1], v11 = t[0], v12 = t[1];
+    const float v20 = t[kCtPW - 1], v21 = t[kCtPW], v22 = t[kCtPW + 1];
+#pragma unroll
+    for (int j = 0; j < COT; ++j) {
+      if (j < Cout) {
+        const float* q = w + ((size_t)c * Cout + j) * 16;  // [ky][kx], wave-uniform
+        // y[2i+0] = x[i] w[ky=1] + x[i-1] w[ky=3] ; y[2i+1] = x[i+1] w[ky=0] + x[i] w[ky=2]   (same along x)
+        o00[j] += v11 * q[5] + v10 * q[7] + v01 * q[13] + v00 * q[15];
+        o01[j] += v12 * q[4] + v11 * q[6] + v02 * q[12] + v01 * q[14];
+        o10[j] += v21 * q[1] + v20 * q[3] + v11 * q[9] + v10 * q[11];
+        o11[j] += v22 * q[0] + v21 * q[2] + v12 * q[8] + v11 * q[10];
+      }
+    }
+  }
+  const int Wo = 2 * Ws;
+  const size_t plane_o = (size_t)4 * plane;
+#pragma unroll
+  for (int j = 0; j < COT; ++j) {
+    if (j < Cout) {
+      float* o = out + ((size_t)n * Cout + j) * plane_o + (size_t)(2 * iy) * Wo + 2 * ix;
+      *reinterpret_cast<float2*>(o) = make_float2(o00[j], o01[j]);
+      *reinterpret_cast<float2*>(o + Wo) = make_float2(o10[j], o11[j]);
+    }
+  }
+}
+
 // weight gradient of a thin layer: same group / patch staging as the patch kernel, but each thread owns up to
 // kThinOut output elements (co, tap, c) and reduces over the group's 64 pixels with VALU fmas.
 constexpr int kThinOut = 5;
@@ -754,20 +823,25 @@ __global__ __launch_bounds__(kConvThreads) void conv_weight_grad_thin_kernel(
       pbase[s] = c * pg.ps + ty * pg.pw + tx;
     }
   }
-  const int apix = tid & (kGP - 1), arow0 = tid >> 6;
   float bsum = 0.f;  // thread t < Cout: bias gradient of channel t
+  auto dma = [&](const float* gsrc, float* ldst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)ldst, 4, 0, 0);
+  };
   for (long grp = gbeg; grp < gend; ++grp) {
     const long p0 = grp * kGP;
+    // staging by LDS-DMA: every row load of the group is in flight at once (the register-staged loop paid one memory
+    // round trip per row: 6 us per 64-pixel group on the first encoder layer)
     {
-      const long p = p0 + apix;
+      const long p = p0 + lane;
       const bool pv = p < ptot;
       int n = 0, rem = 0;
       if (pv) { n = (int)(p / plane_a); rem = (int)(p - (long)n * plane_a); }
       const float* a_n = a + (size_t)n * g.Cout * plane_a + rem;
-      for (int row = arow0; row < g.Cout; row += 4) {
-        float v = pv ? a_n[(size_t)row * plane_a] : 0.f;
-        if (pre_act_a) v = act_fwd(v, g.act);
-        a_lds[row * kLDA + apix] = v;
+      for (int row = wave; row < g.Cout; row += 4) {
+        float* dst = a_lds + row * kLDA;
+        if (pv) dma(a_n + (size_t)row * plane_a, dst);
+        else dst[lane] = 0.f;
       }
     }
     {
@@ -785,12 +859,28 @@ __global__ __launch_bounds__(kConvThreads) void conv_weight_grad_thin_kernel(
         const size_t off = (size_t)sy * g.Ws + sx;
         const float* s_n = src + (size_t)n * g.C * plane_s + off;
         for (int c = wave; c < ctot; c += 4) {
-          float v = 0.f;
-          if (ok) {
-            v = c < g.C ? s_n[(size_t)c * plane_s] : src2[(size_t)(c - g.C) * plane_s + off];
-            if (g.pre_act) v = act_fwd(v, g.act);
+          float* dst = patch + c * pg.ps + rb;
+          if (ok) dma(c < g.C ? s_n + (size_t)c * plane_s : src2 + (size_t)(c - g.C) * plane_s + off, dst);
+          else if (rv) dst[lane] = 0.f;
+        }
+      }
+    }
+    if (g.pre_act || pre_act_a) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (pre_act_a) {
+        for (int row = wave; row < g.Cout; row += 4) {
+          float* d = a_lds + row * kLDA + lane;
+          *d = act_fwd(*d, g.act);
+        }
+      }
+      if (g.pre_act) {
+        for (int rb = 0; rb < pg.ps_raw; rb += 64) {
+          if (rb + lane < pg.ps_raw) {
+            for (int c = wave; c < ctot; c += 4) {
+              float* d = patch + c * pg.ps + rb + lane;
+              *d = act_fwd(*d, g.act);
+            }
           }
-          if (rv) patch[c * pg.ps + r] = v;
         }
       }
     }
@@ -997,6 +1087,24 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
   else
     { set_last_kernel("mtrssm::conv_weight_grad_kernel<1>"); hipLaunchKernelGGL(conv_weight_grad_kernel<1>, grid, dim3(kConvThreads), 0, stream, *g, a, src, src2, pre_act_a, dwp); }
   return launched("conv_weight_grad");
+}
+
+int convt_k4s2_thin_launch(int N, int C, int Hs, int Ws, int Cout, const float* src, const float* w, const float* bias, int pre_act,
+                           int act, float* out, hipStream_t stream) {
+  if (N <= 0 || C <= 0 || Hs <= 0 || Ws <= 0 || Cout <= 0 || Cout > 2 || !src || !w || !out) {
+    set_error("convt_k4s2_thin: bad argument (needs 1 <= Cout <= 2)");
+    return MTRSSM_EINVAL;
+  }
+  if (act < MTRSSM_ACT_IDENTITY || act > MTRSSM_ACT_TANH) { set_error("convt_k4s2_thin: unknown activation id %d", act); return MTRSSM_EINVAL; }
+  if ((uintptr_t)out & 7) { set_error("convt_k4s2_thin: out must be 8-byte aligned"); return MTRSSM_EINVAL; }
+  const size_t lds = (size_t)C * kCtPS * sizeof(float);
+  if (lds > 64 * 1024) { set_error("convt_k4s2_thin: %d input channels do not fit the LDS tile", C); return MTRSSM_ELDS; }
+  const dim3 grid((Ws + kCtTW - 1) / kCtTW, (Hs + kCtTH - 1) / kCtTH, N);
+  if (Cout == 1)
+    { set_last_kernel("mtrssm::convt_k4s2_thin_kernel<1>"); hipLaunchKernelGGL(convt_k4s2_thin_kernel<1>, grid, dim3(kConvThreads), lds, stream, N, C, Hs, Ws, Cout, src, w, bias, pre_act, act, out); }
+  else
+    { set_last_kernel("mtrssm::convt_k4s2_thin_kernel<2>"); hipLaunchKernelGGL(convt_k4s2_thin_kernel<2>, grid, dim3(kConvThreads), lds, stream, N, C, Hs, Ws, Cout, src, w, bias, pre_act, act, out); }
+  return launched("convt_k4s2_thin");
 }
 
 int channel_sum_launch(const float* x, int N, int C, int HW, float* out, hipStream_t stream) {

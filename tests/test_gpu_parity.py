@@ -341,6 +341,9 @@ DECONV_CASES = [
     (2, 32, 16, 16, 16, 4, 2, 1, 0, True),
     (2, 16, 32, 32, 1, 4, 2, 1, 0, True),
     (5, 64, 16, 4, 32, 4, 2, 1, 0, True),  # audio decoder plane
+    (3, 16, 13, 37, 1, 4, 2, 1, 0, True),  # last-layer kernel (convt_k4s2_thin): ragged tile edges
+    (2, 5, 8, 40, 2, 4, 2, 1, 0, False),   # two output channels, no activation
+    (2, 16, 64, 16, 1, 4, 2, 1, 0, True),  # audio plane 128 x 32 output
 ]
 
 
