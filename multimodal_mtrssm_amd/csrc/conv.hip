@@ -1048,7 +1048,7 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
     (void)mfma_ok;
     if (tiles && n_out <= kThinOut * kConvThreads && lds_thin <= 64 * 1024) {  // thin layer: staging-bound, VALU reduction is faster
       const long groups = (ptot + kGP - 1) / kGP;
-      long splits = 1024;
+      long splits = 2048;  // 8 small workgroups per CU: the kernel is staging-latency-bound, occupancy hides it
       if (splits > groups) splits = groups;
       { set_last_kernel("mtrssm::conv_weight_grad_thin_kernel"); hipLaunchKernelGGL(conv_weight_grad_thin_kernel, dim3((unsigned)splits), dim3(kConvThreads), lds_thin, stream, *g, a, src, src2, pre_act_a, dwp, dbias); }
       return launched("conv_weight_grad(thin)");
