@@ -73,7 +73,7 @@ __global__ __launch_bounds__(1024) void mmtrssm_fwd_kernel(const MtrssmMmtrssmDi
                  r[lnxt + o] = d;
                  if (valid[rb]) { io.deter_l[bt[rb] * LD + o] = d; io.hidden_l[bt[rb] * LD + o] = hid; }
                });
-    __syncthreads();  // tmp is reused by the higher cell
+    // (no barrier: gemv_sk ends with one)  // tmp is reused by the higher cell
     gemv_sk<RB, VEC>(w.wxh_t, HD, HS, HD, lds + L.slh + LS, L.stride, red,
                [&](int, int o) { return w.bh[o]; },
                [&](int rb, int o, float a) { lds[rb * L.stride + L.tmp + o] = a; });
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(1024) void mmtrssm_fwd_kernel(const MtrssmMmtrssmDi
                  r[hnxt + o] = d;
                  if (valid[rb]) { io.deter_h[bt[rb] * HD + o] = d; io.hidden_h[bt[rb] * HD + o] = hid; }
                });
-    __syncthreads();
+    // (no barrier: gemv_sk ends with one)
 
     // (2a) layer 0 of every head: on d_l -> [l_prior | audio | vision | h_posterior(l part, raw)], on d_h -> [h_prior | h_posterior(h part, raw)]
     gemv_sk<RB, VEC>(w.wl1_t, NL * H, LD, NL * H, lds + lnxt, L.stride, red,
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(1024) void mmtrssm_fwd_kernel(const MtrssmMmtrssmDi
                  lds[rb * L.stride + L.h1 + o] = h;
                  if (io.sv_h1 && valid[rb] && o < H) io.sv_h1[bt[rb] * H + o] = h;
                });
-    __syncthreads();
+    // (no barrier: gemv_sk ends with one)
     // (2b) h_posterior layer 0 = act(l part + h part)   (core.py:315-316: cat([l_deter, h_deter]))
     if (POST) {
       for (int rb = 0; rb < RB; ++rb) {
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(1024) void mmtrssm_bwd_kernel(const MtrssmMmtrssmDi
                  r[L.c_hh + o] = dhid * dm.keep_h;
                  if (valid[rb]) io.d_uh[bt[rb] * HD + o] = du;
                });
-    __syncthreads();
+    // (no barrier: gemv_sk ends with one)
 
     // (e) carries into step t-1: d_prev via W_d^T ; [stoch_l ; stoch_h] via W_x^T (narrow outputs)
     gemv_sk<RB, VEC>(w.wdl, LD, LD, LD, lds + L.dul, L.stride, red, [](int, int) { return 0.f; },

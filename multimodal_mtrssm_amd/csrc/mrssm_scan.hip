@@ -65,7 +65,7 @@ __global__ __launch_bounds__(1024) void mrssm_fwd_kernel(const MtrssmMrssmDims d
                  lds[rb * L.stride + L.h1 + o] = h;
                  if (io.sv_h1 && valid[rb]) io.sv_h1[bt[rb] * H + o] = h;
                });
-    __syncthreads();
+    // (no barrier: gemv_sk ends with one)
     // (2) h2 = W2 h1 + b2                                         networks.py:166 (second Linear)
     gemv_sk<RB, VEC>(w.w2_t, H, H, H, lds + L.h1, L.stride, red,
                [&](int, int o) { return w.b2[o]; },
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(1024) void mrssm_fwd_kernel(const MtrssmMrssmDims d
                  lds[rb * L.stride + L.h2 + o] = a;
                  if (io.sv_h2 && valid[rb]) io.sv_h2[bt[rb] * H + o] = a;
                });
-    __syncthreads();
+    // (no barrier: gemv_sk ends with one)
     // (3) gi = W_ih h2 + b_ih ; gh = W_hh d_prev + b_hh           networks.py:170 (nn.GRUCell)
     gemv_sk<RB, VEC>(w.wih_t, 3 * D, H, 3 * D, lds + L.h2, L.stride, red,
                [&](int, int o) { return w.bih[o]; },
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(1024) void mrssm_fwd_kernel(const MtrssmMrssmDims d
     gemv_sk<RB, VEC>(w.whh_t, 3 * D, D, 3 * D, lds + cur, L.stride, red,
                [&](int, int o) { return w.bhh[o]; },
                [&](int rb, int o, float a) { lds[rb * L.stride + L.gh + o] = a; });
-    __syncthreads();
+    // (no barrier: gemv_sk ends with one)
     // (4) gates: r, z, n ; d = (d_prev - n) z + n
     for (int rb = 0; rb < RB; ++rb) {
       float* r_ = lds + rb * L.stride;
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(1024) void mrssm_fwd_kernel(const MtrssmMrssmDims d
                  lds[rb * L.stride + L.hd + o] = h;
                  if (io.sv_heads && valid[rb]) io.sv_heads[bt[rb] * 3 * H + o] = h;
                });
-    __syncthreads();
+    // (no barrier: gemv_sk ends with one)
     // (6) head layer 1: three narrow [S x H] products, one wave per output
     for (int o = wave; o < NH * S; o += nwave) {
       const int which = o / S, s = o - which * S;
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(1024) void mrssm_bwd_kernel(const MtrssmMrssmDims d
                  lds[rb * L.stride + L.dzh + 2 * H + o] = g;
                  if (valid[rb]) io.d_zh[bt[rb] * 3 * H + 2 * H + o] = g;
                });
-    __syncthreads();
+    // (no barrier: gemv_sk ends with one)
 
     // (d) dd = g_deter + carry + Wh1^T dzh ; then the GRU gate gradients
     gemv_sk<RB, VEC>(w.wh1, D, 3 * H, D, lds + L.dzh, L.stride, red,
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(1024) void mrssm_bwd_kernel(const MtrssmMrssmDims d
                    gh[o] = dr_pre; gh[D + o] = dz_pre; gh[2 * D + o] = dn_pre * rg;
                  }
                });
-    __syncthreads();
+    // (no barrier: gemv_sk ends with one)
 
     // (e) carry_d = dd z + W_hh^T dgh ; dh2 = W_ih^T dgi
     gemv_sk<RB, VEC>(w.whh, D, 3 * D, D, lds + L.dgh, L.stride, red,
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(1024) void mrssm_bwd_kernel(const MtrssmMrssmDims d
                  lds[rb * L.stride + L.dh2 + o] = a;
                  if (valid[rb]) io.d_h2[bt[rb] * H + o] = a;
                });
-    __syncthreads();
+    // (no barrier: gemv_sk ends with one)
     // (f) dz1 = act'(h1) * W2^T dh2
     gemv_sk<RB, VEC>(w.w2, H, H, H, lds + L.dh2, L.stride, red, [](int, int) { return 0.f; },
                [&](int rb, int o, float a) {
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(1024) void mrssm_bwd_kernel(const MtrssmMrssmDims d
                  lds[rb * L.stride + L.dz1 + o] = g;
                  if (valid[rb]) io.d_z1[bt[rb] * H + o] = g;
                });
-    __syncthreads();
+    // (no barrier: gemv_sk ends with one)
     // (g) carry_s[s] = sum_j W1s[j][s] dz1[j]  (narrow output: one wave per s, rows of W1s^T)
     for (int s = wave; s < S; s += nwave) {
       float acc[RB];
