@@ -332,7 +332,7 @@ int mtrssm_mmtrssm_rollout_bwd(const MtrssmMmtrssmDims* dims, const MtrssmMmtrss
  *   Conv2d backward-data / ConvTranspose2d forward: one call per output parity class (qy,qx) in [0,s)^2 with
  *     the taps ky = ky0 + s*ty (ky0 = (qy+p) mod s): SS=1, TS=-1, OFFY=(qy+p-ky0)/s, OS=s, QY=qy.
  * wp is the packed weight matrix [CoutPad][KH*KW][Cpad], zero padded (Cpad % 16 == 0, CoutPad % 32 == 0,
- * CoutPad % 64 == 0 when Cout > 32), 16-byte aligned.
+ * CoutPad % 64 == 0 when Cout > 32), 16-byte aligned; wq: its bf16 pieces (see mtrssm_pack_conv_weight), 16-byte aligned, or NULL.
  *
  * mtrssm_conv_weight_grad accumulates (atomically; the caller zeroes dwp)
  *   dwp[co][ty*KW+tx][c] += sum_{n, y<Hq, x<Wq} preA(a[n,co,y,x]) * pre(S[n,c,y*SS+ty*TS+OFFY,x*SS+tx*TS+OFFX])
@@ -352,10 +352,21 @@ typedef struct MtrssmConvGeom {
   int32_t Cout, CoutPad;
   int32_t pre_act;              /* apply act() to gathered values */
   int32_t act;                  /* MTRSSM_ACT_* */
+  int32_t mfma_split;           /* MFMA operand format of the patch-staged kernels: 0 = fp32 (v_mfma_f32_32x32x2_f32, exact);
+                                   3 = three bf16 pieces per operand, six v_mfma_f32_32x32x16_bf16 products (fp32-grade, ~2^-24);
+                                   2 = two pieces, three products (~2^-16); 1 = plain bf16 operands.  Accumulation is fp32. */
 } MtrssmConvGeom;
 
-int mtrssm_conv_gather_gemm(const MtrssmConvGeom* g, const float* src, const float* src2, const float* wp,
+int mtrssm_conv_gather_gemm(const MtrssmConvGeom* g, const float* src, const float* src2, const float* wp, const uint16_t* wq,
                             const float* bias, const float* actgrad_in, const float* add_in, float* out, void* stream);
+/* Packs a conv weight view w[O][I][KH][KW] (element strides so, si, sh, sw: any permuted / strided view of the module's
+ * parameter, e.g. the per-parity-class tap subset of a ConvTranspose2d weight) into the kernels' layout:
+ *   wp fp32 [OPad][KH*KW][IPad], zero padded;
+ *   wq (pieces = mfma_split > 0) bf16 bit patterns [pieces][OPad][KH*KW][IPad]: piece s of each wp element, wp = sum_s wq_s
+ *   up to 2^-(8 pieces) relative.  mtrssm_conv_gather_gemm reads wq when g->mfma_split > 0 and wq != NULL, wp otherwise
+ *   (thin / odd-geometry layers always read wp). */
+int mtrssm_pack_conv_weight(const float* w, int32_t O, int32_t I, int32_t KH, int32_t KW, int64_t so, int64_t si, int64_t sh,
+                            int64_t sw, int32_t OPad, int32_t IPad, int32_t pieces, float* wp, uint16_t* wq, void* stream);
 int mtrssm_conv_weight_grad(const MtrssmConvGeom* g, const float* a, const float* src, const float* src2,
                             int32_t pre_act_a, float* dwp, float* dbias, void* stream);
 /* Last decoder layer (default.yaml:70-74, channels [.., 1]): out[N, Cout<=2, 2Hs, 2Ws] = bias + ConvTranspose2d_{k=4,s=2,p=1}(pre(src[N,C,Hs,Ws]))

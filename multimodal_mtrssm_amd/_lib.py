@@ -74,7 +74,7 @@ MmtrssmBwdIO = _struct("MtrssmMmtrssmBwdIO", _ptrs(
 
 ConvGeom = _struct("MtrssmConvGeom", [(n, _i) for n in (
     "N", "C", "Hs", "Ws", "C2", "Cpad", "KH", "KW", "SS", "TS", "OFFY", "OFFX", "Hq", "Wq", "OS", "QY", "QX", "Ho", "Wo",
-    "Cout", "CoutPad", "pre_act", "act")])
+    "Cout", "CoutPad", "pre_act", "act", "mfma_split")])
 
 # every symbol include/mtrssm.h declares (tests/test_capi.py checks the header against this list)
 SYMBOLS: dict[str, tuple[type | None, list[type]]] = {
@@ -85,7 +85,8 @@ SYMBOLS: dict[str, tuple[type | None, list[type]]] = {
     "mtrssm_mrssm_rollout_bwd": (C.c_int, [C.POINTER(MrssmDims), C.POINTER(MrssmBwdWeights), C.POINTER(MrssmBwdIO), _p]),
     "mtrssm_mmtrssm_rollout_fwd": (C.c_int, [C.POINTER(MmtrssmDims), C.POINTER(MmtrssmFwdWeights), C.POINTER(MmtrssmFwdIO), _p]),
     "mtrssm_mmtrssm_rollout_bwd": (C.c_int, [C.POINTER(MmtrssmDims), C.POINTER(MmtrssmBwdWeights), C.POINTER(MmtrssmBwdIO), _p]),
-    "mtrssm_conv_gather_gemm": (C.c_int, [C.POINTER(ConvGeom), _p, _p, _p, _p, _p, _p, _p, _p]),
+    "mtrssm_conv_gather_gemm": (C.c_int, [C.POINTER(ConvGeom), _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "mtrssm_pack_conv_weight": (C.c_int, [_p, _i, _i, _i, _i, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _i, _i, _i, _p, _p, _p]),
     "mtrssm_conv_weight_grad": (C.c_int, [C.POINTER(ConvGeom), _p, _p, _p, _i, _p, _p, _p]),
     "mtrssm_channel_sum": (C.c_int, [_p, _i, _i, _i, _p, _p]),
     "mtrssm_convt_k4s2_thin": (C.c_int, [_i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _p, _p]),
@@ -137,6 +138,16 @@ def ptr(t: Tensor | None) -> int | None:
         raise MtrssmLibraryError(msg)
     if t.dtype != torch.float32 or not t.is_contiguous():
         msg = f"expected a contiguous float32 tensor, got {t.dtype} contiguous={t.is_contiguous()}"
+        raise MtrssmLibraryError(msg)
+    return t.data_ptr()
+
+
+def raw_ptr(t: Tensor | None) -> int | None:
+    """Device pointer of a GPU tensor of any dtype / stride (the callee is given the strides separately)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        msg = "multimodal_mtrssm_amd kernels run on MI355X only: got a CPU tensor (there is no CPU fallback)"
         raise MtrssmLibraryError(msg)
     return t.data_ptr()
 

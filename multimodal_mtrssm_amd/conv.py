@@ -14,6 +14,7 @@ permutes -- a few KB per layer.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 from torch import Tensor
@@ -29,36 +30,64 @@ def _pads(cout: int, cin: int) -> tuple[int, int]:
     return _pad_to(cout, 64 if cout > 32 else 32), _pad_to(cin, 16)
 
 
-_PACK_BUFFERS: dict[tuple, Tensor] = {}
+_PACK_BUFFERS: dict[tuple, tuple[Tensor, Tensor | None]] = {}
 
 
-def pack_weight(w: Tensor) -> Tensor:
-    """``w[O][I][kh][kw]`` -> zero-padded ``wp[OPad][kh*kw][IPad]`` (channel fastest).
+def pack_weight(w: Tensor) -> tuple[Tensor, Tensor | None]:
+    """``w[O][I][kh][kw]`` (any strided view) -> zero-padded fp32 ``wp[OPad][kh*kw][IPad]`` (channel fastest) and, in a
+    bf16 MFMA mode, its bf16 pieces ``wq[pieces][OPad][kh*kw][IPad]`` (one ``mtrssm_pack_conv_weight`` launch).
 
-    The padded buffer is cached per (shape, device, stream) and only its valid region is rewritten: every use is
-    "pack, then enqueue the kernel that reads it" on one stream, so a later pack of another same-shaped layer cannot
-    overtake the earlier kernel; the padding stays zero from the first fill.
+    The buffers are cached per (shape, device, stream): every use is "pack, then enqueue the kernel that reads it" on
+    one stream, so a later pack of another same-shaped layer cannot overtake the earlier kernel.
     """
     o, i, kh, kw = w.shape
     opad, ipad = _pads(o, i)
-    key = (o, i, kh, kw, w.device, torch.cuda.current_stream(w.device).cuda_stream if w.is_cuda else 0)
-    wp = _PACK_BUFFERS.get(key)
-    if wp is None:
-        wp = _PACK_BUFFERS[key] = torch.zeros(opad, kh * kw, ipad, device=w.device, dtype=torch.float32)
+    key = (o, i, kh, kw, _MFMA_SPLIT, w.device, torch.cuda.current_stream(w.device).cuda_stream if w.is_cuda else 0)
+    bufs = _PACK_BUFFERS.get(key)
+    if bufs is None:
+        wp = torch.zeros(opad, kh * kw, ipad, device=w.device, dtype=torch.float32)
+        wq = torch.zeros(_MFMA_SPLIT, opad, kh * kw, ipad, device=w.device, dtype=torch.int16) if _MFMA_SPLIT else None
+        bufs = _PACK_BUFFERS[key] = (wp, wq)
+    wp, wq = bufs
     if kh * kw > 0:
-        wp[:o, :, :i] = w.permute(0, 2, 3, 1).reshape(o, kh * kw, i)
-    return wp
+        so, si, sh, sw = w.stride()
+        _lib.check(_lib.TIMERS.call("mtrssm_pack_conv_weight", _lib.load().mtrssm_pack_conv_weight, _lib.raw_ptr(w), o, i, kh, kw, so, si,
+                                    sh, sw, opad, ipad, _MFMA_SPLIT, _lib.ptr(wp), _lib.raw_ptr(wq), _lib.stream_ptr(w.device)),
+                   "mtrssm_pack_conv_weight")
+    return wp, wq
+
+
+# MFMA operand format of the patch-staged kernels (``MtrssmConvGeom.mfma_split``, include/mtrssm.h)
+MFMA_MODES = {"f32": 0, "bf16x3": 3, "bf16x2": 2, "bf16": 1}
+_MFMA_SPLIT = MFMA_MODES[os.environ.get("MTRSSM_CONV_MFMA", "f32")]
+
+
+def set_mfma_mode(mode: str) -> None:
+    """``"f32"``: exact fp32 MFMA.  ``"bf16x3"``: operands as three bf16 pieces, six bf16-MFMA products with fp32
+    accumulation (fp32-grade, ~2^-24).  ``"bf16x2"``: two pieces, three products (~2^-16).  ``"bf16"``: plain bf16
+    operands (tensors, accumulation, bias and activations stay fp32)."""
+    global _MFMA_SPLIT  # noqa: PLW0603
+    if mode not in MFMA_MODES:
+        msg = f"unknown MFMA mode {mode!r}; choose from {sorted(MFMA_MODES)}"
+        raise ValueError(msg)
+    _MFMA_SPLIT = MFMA_MODES[mode]
+
+
+def mfma_mode() -> str:
+    return next(k for k, v in MFMA_MODES.items() if v == _MFMA_SPLIT)
 
 
 def _geom(**kw: int) -> C.Structure:
     g = _lib.ConvGeom()
     for k, v in kw.items():
         setattr(g, k, int(v))
+    g.mfma_split = _MFMA_SPLIT
     return g
 
 
-def _gather_gemm(geom: C.Structure, src: Tensor, src2: Tensor | None, wp: Tensor, bias: Tensor | None,
+def _gather_gemm(geom: C.Structure, src: Tensor, src2: Tensor | None, wpq: tuple[Tensor, Tensor | None], bias: Tensor | None,
                  actgrad_in: Tensor | None, out: Tensor, add_in: Tensor | None = None) -> None:
+    wp, wq = wpq
     lib = _lib.load()
     # algorithmic work of this launch: 2 FLOPs per (output element, tap, real channel); bytes = source read once + output written once
     pixels = geom.N * geom.Hq * geom.Wq
@@ -66,7 +95,7 @@ def _gather_gemm(geom: C.Structure, src: Tensor, src2: Tensor | None, wp: Tensor
     nbytes = 4.0 * (geom.N * geom.C * geom.Hs * geom.Ws + pixels * geom.Cout * (2 if actgrad_in is not None else 1))
     _lib.check(_lib.TIMERS.call(
         "mtrssm_conv_gather_gemm", lib.mtrssm_conv_gather_gemm, C.byref(geom), _lib.ptr(src), _lib.ptr(src2), _lib.ptr(wp),
-        _lib.ptr(bias), _lib.ptr(actgrad_in), _lib.ptr(add_in), _lib.ptr(out), _lib.stream_ptr(src.device), flops=flops,
+        _lib.raw_ptr(wq), _lib.ptr(bias), _lib.ptr(actgrad_in), _lib.ptr(add_in), _lib.ptr(out), _lib.stream_ptr(src.device), flops=flops,
         nbytes=nbytes), "mtrssm_conv_gather_gemm")
 
 
@@ -81,11 +110,12 @@ def _conv_forward_gather(x: Tensor, coords: Tensor | None, w: Tensor, bias: Tens
         raise ValueError(msg)
     ho = (hs + 2 * pad - kh) // stride + 1
     wo = (ws + 2 * pad - kw) // stride + 1
-    wp = pack_weight(w)
+    wpq = pack_weight(w)
+    wp = wpq[0]
     out = torch.empty(n, o, ho, wo, device=x.device, dtype=torch.float32)
     geom = _geom(N=n, C=c, Hs=hs, Ws=ws, C2=c2, Cpad=wp.shape[2], KH=kh, KW=kw, SS=stride, TS=1, OFFY=-pad, OFFX=-pad,
                  Hq=ho, Wq=wo, OS=1, QY=0, QX=0, Ho=ho, Wo=wo, Cout=o, CoutPad=wp.shape[0], pre_act=int(pre_act), act=act)
-    _gather_gemm(geom, x, coords, wp, bias, actgrad_in, out, add_in)
+    _gather_gemm(geom, x, coords, wpq, bias, actgrad_in, out, add_in)
     return out
 
 
@@ -118,12 +148,13 @@ def _conv_transposed_gather(y: Tensor, w: Tensor, bias: Tensor | None, stride: i
         for qx in range(min(stride, wo)):
             kx0 = (qx + pad) % stride
             wsub = w[:, :, ky0::stride, kx0::stride].permute(1, 0, 2, 3)  # [c][o][nty][ntx]
-            wp = pack_weight(wsub)
+            wpq = pack_weight(wsub)
+            wp = wpq[0]
             geom = _geom(N=n, C=o, Hs=hs, Ws=ws, C2=0, Cpad=wp.shape[2], KH=wsub.shape[2], KW=wsub.shape[3], SS=1, TS=-1,
                          OFFY=(qy + pad - ky0) // stride, OFFX=(qx + pad - kx0) // stride,
                          Hq=(ho - qy + stride - 1) // stride, Wq=(wo - qx + stride - 1) // stride, OS=stride, QY=qy, QX=qx,
                          Ho=ho, Wo=wo, Cout=c, CoutPad=wp.shape[0], pre_act=int(pre_act), act=act)
-            _gather_gemm(geom, y, None, wp, bias, actgrad_in, out, add_in)
+            _gather_gemm(geom, y, None, wpq, bias, actgrad_in, out, add_in)
     return out
 
 

@@ -22,7 +22,8 @@ int mrssm_fwd_launch(const MtrssmMrssmDims*, const MtrssmMrssmFwdWeights*, const
 int mrssm_bwd_launch(const MtrssmMrssmDims*, const MtrssmMrssmBwdWeights*, const MtrssmMrssmBwdIO*, hipStream_t);
 int mmtrssm_fwd_launch(const MtrssmMmtrssmDims*, const MtrssmMmtrssmFwdWeights*, const MtrssmMmtrssmFwdIO*, hipStream_t);
 int mmtrssm_bwd_launch(const MtrssmMmtrssmDims*, const MtrssmMmtrssmBwdWeights*, const MtrssmMmtrssmBwdIO*, hipStream_t);
-int conv_gather_gemm_launch(const MtrssmConvGeom*, const float*, const float*, const float*, const float*, const float*, const float*, float*, hipStream_t);
+int conv_gather_gemm_launch(const MtrssmConvGeom*, const float*, const float*, const float*, const unsigned short*, const float*, const float*, const float*, float*, hipStream_t);
+int pack_conv_weight_launch(const float*, int, int, int, int, long, long, long, long, int, int, int, float*, unsigned short*, hipStream_t);
 int conv_weight_grad_launch(const MtrssmConvGeom*, const float*, const float*, const float*, int, float*, float*, hipStream_t);
 int channel_sum_launch(const float*, int, int, int, float*, hipStream_t);
 int convt_k4s2_thin_launch(int, int, int, int, int, const float*, const float*, const float*, int, int, float*, hipStream_t);
@@ -67,9 +68,13 @@ MTRSSM_API int mtrssm_adamw_step(float* param, const float* grad, float* exp_avg
   return adamw_launch(param, grad, exp_avg, exp_avg_sq, n, sumsq, clip_norm, grad_scale, lr, beta1, beta2, eps, weight_decay, step,
                       static_cast<hipStream_t>(stream));
 }
-MTRSSM_API int mtrssm_conv_gather_gemm(const MtrssmConvGeom* g, const float* src, const float* src2, const float* wp, const float* bias,
-                                       const float* actgrad_in, const float* add_in, float* out, void* stream) {
-  return conv_gather_gemm_launch(g, src, src2, wp, bias, actgrad_in, add_in, out, static_cast<hipStream_t>(stream));
+MTRSSM_API int mtrssm_conv_gather_gemm(const MtrssmConvGeom* g, const float* src, const float* src2, const float* wp, const uint16_t* wq,
+                                       const float* bias, const float* actgrad_in, const float* add_in, float* out, void* stream) {
+  return conv_gather_gemm_launch(g, src, src2, wp, wq, bias, actgrad_in, add_in, out, static_cast<hipStream_t>(stream));
+}
+MTRSSM_API int mtrssm_pack_conv_weight(const float* w, int32_t O, int32_t I, int32_t KH, int32_t KW, int64_t so, int64_t si, int64_t sh,
+                                       int64_t sw, int32_t OPad, int32_t IPad, int32_t pieces, float* wp, uint16_t* wq, void* stream) {
+  return pack_conv_weight_launch(w, O, I, KH, KW, so, si, sh, sw, OPad, IPad, pieces, wp, wq, static_cast<hipStream_t>(stream));
 }
 MTRSSM_API int mtrssm_conv_weight_grad(const MtrssmConvGeom* g, const float* a, const float* src, const float* src2, int32_t pre_act_a,
                                        float* dwp, float* dbias, void* stream) {

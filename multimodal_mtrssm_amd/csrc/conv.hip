@@ -649,6 +649,10 @@ __global__ __launch_bounds__(kConvThreads) void conv_gather_gemm_patch_kernel(
   }
 }
 
+}  // namespace mtrssm
+#include "conv_split.h"
+namespace mtrssm {
+
 // ------------------------------------------------------------------------------------------------
 // Thin layers (few channels on big planes: first encoder conv 3->8, last decoder deconv 16->1 ...):
 // a 32x32 MFMA tile would be >90 % padding and the layers are HBM-bound anyway, so they run on the VALU.
@@ -962,6 +966,10 @@ static int check_geom(const MtrssmConvGeom* g, const char* who) {
     set_error("%s: unknown activation id %d", who, g->act);
     return MTRSSM_EINVAL;
   }
+  if (g->mfma_split < 0 || g->mfma_split > 3) {
+    set_error("%s: mfma_split must be 0 (fp32 MFMA) or 1..3 bf16 pieces, got %d", who, g->mfma_split);
+    return MTRSSM_EINVAL;
+  }
   return MTRSSM_OK;
 }
 
@@ -974,8 +982,22 @@ static int launched(const char* who) {
   return MTRSSM_OK;
 }
 
-int conv_gather_gemm_launch(const MtrssmConvGeom* g, const float* src, const float* src2, const float* wp, const float* bias,
-                            const float* actgrad_in, const float* add_in, float* out, hipStream_t stream) {
+int pack_conv_weight_launch(const float* w, int O, int I, int KH, int KW, long so, long si, long sh, long sw, int OPad, int IPad,
+                            int pieces, float* wp, unsigned short* wq, hipStream_t stream) {
+  if (!w || !wp || O <= 0 || I <= 0 || KH < 0 || KW < 0 || OPad < O || IPad < I || pieces < 0 || pieces > 3 || (pieces > 0 && !wq)) {
+    set_error("pack_conv_weight: bad argument");
+    return MTRSSM_EINVAL;
+  }
+  const long total = (long)OPad * KH * KW * IPad;
+  if (total == 0) return MTRSSM_OK;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  { set_last_kernel("mtrssm::pack_conv_weight_kernel"); hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(blocks), dim3(256), 0, stream, w, O, I, KH, KW, so, si, sh, sw, OPad, IPad, pieces, wp, wq); }
+  return launched("pack_conv_weight");
+}
+
+int conv_gather_gemm_launch(const MtrssmConvGeom* g, const float* src, const float* src2, const float* wp, const unsigned short* wq,
+                            const float* bias, const float* actgrad_in, const float* add_in, float* out, hipStream_t stream) {
   if (int rc = check_geom(g, "conv_gather_gemm")) return rc;
   if (!src || !wp || !out || (g->C2 > 0 && !src2)) { set_error("conv_gather_gemm: null pointer"); return MTRSSM_EINVAL; }
   if ((uintptr_t)wp & 15) { set_error("conv_gather_gemm: packed weights must be 16-byte aligned"); return MTRSSM_EINVAL; }
@@ -1004,8 +1026,46 @@ int conv_gather_gemm_launch(const MtrssmConvGeom* g, const float* src, const flo
       const bool tiles = (g->Hq % pg.rpg == 0) || (pg.rpg % g->Hq == 0);
       const size_t lds = ((size_t)kKC * pg.ps + 2 * (size_t)tco * (kKC + 1) + pg.ps_raw) * sizeof(float);
       const long nx = (ptot + tpx - 1) / tpx;
-      if (!tiles || pg.ipg >= 32 || lds > 64 * 1024) continue;
+      if (!tiles || pg.ipg >= 32) continue;
       const dim3 grid((unsigned)nx, ny);
+      if (g->mfma_split > 0 && wq) {
+        const int sp = g->mfma_split;
+        const int taps = g->KH * g->KW;
+        static const int tg_env = getenv("MTRSSM_SPLIT_TG") ? atoi(getenv("MTRSSM_SPLIT_TG")) : 99;
+        const int tg_cap = tg_env < split_tg(sp) ? tg_env : split_tg(sp);
+        auto lds_of = [&](int t) { return (size_t)sp * ((size_t)pg.ps_raw * kRowB + (size_t)t * tco * kRowB) + (size_t)pg.ps_raw * sizeof(int); };
+        int tgs = 1;  // largest divisor of taps within the register / LDS budget
+        for (int t = 1; t <= tg_cap && t <= taps; ++t)
+          if (taps % t == 0 && lds_of(t) <= 80 * 1024) tgs = t;
+        const int ngroups = taps / tgs;
+        const size_t lds_s = lds_of(tgs);
+        const int pit = pg.ps_raw <= 384 ? 3 : 5;
+        if (lds_s <= 80 * 1024 && pg.ps_raw <= 640 && (sp == 1 || sp == 3) && (long)pg.ipg * g->C * g->Hs * g->Ws < (1L << 31) &&
+            (long)g->N * g->Cout * g->Ho * g->Wo < (1L << 31) && (long)sp * g->CoutPad * taps * g->Cpad < (1L << 31)) {
+#define MTRSSM_SPLIT_LAUNCH(NT_, SP_, PIT_)                                                                                     \
+  {                                                                                                                             \
+    static bool attr_done = false;                                                                                              \
+    if (!attr_done) {                                                                                                           \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gather_split_kernel<NT_, SP_, PIT_>),                        \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);                                         \
+      attr_done = true;                                                                                                         \
+    }                                                                                                                           \
+    set_last_kernel("mtrssm::conv_gather_split_kernel<" #NT_ ", " #SP_ ", " #PIT_ ">");                                          \
+    hipLaunchKernelGGL((conv_gather_split_kernel<NT_, SP_, PIT_>), grid, dim3(kConvThreads), lds_s, stream, *g, src, src2, wq,   \
+                       bias, actgrad_in, add_in, out, tgs, ngroups);                                                            \
+  }
+          if (tco == 64) {
+            if (sp == 3) { if (pit == 3) MTRSSM_SPLIT_LAUNCH(2, 3, 3) else MTRSSM_SPLIT_LAUNCH(2, 3, 5) }
+            else { if (pit == 3) MTRSSM_SPLIT_LAUNCH(2, 1, 3) else MTRSSM_SPLIT_LAUNCH(2, 1, 5) }
+          } else {
+            if (sp == 3) { if (pit == 3) MTRSSM_SPLIT_LAUNCH(1, 3, 3) else MTRSSM_SPLIT_LAUNCH(1, 3, 5) }
+            else { if (pit == 3) MTRSSM_SPLIT_LAUNCH(1, 1, 3) else MTRSSM_SPLIT_LAUNCH(1, 1, 5) }
+          }
+#undef MTRSSM_SPLIT_LAUNCH
+          return launched("conv_gather_gemm(split)");
+        }
+      }
+      if (lds > 64 * 1024) continue;
       if (tco == 64) {
         { set_last_kernel("mtrssm::conv_gather_gemm_patch_kernel<2, 1>"); hipLaunchKernelGGL((conv_gather_gemm_patch_kernel<2, 1>), grid, dim3(kConvThreads), lds, stream, *g, src, src2, wp, bias, actgrad_in, add_in, out); }
       } else {

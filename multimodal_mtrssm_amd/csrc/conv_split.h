@@ -1,0 +1,334 @@
+// Split-bf16 MFMA variants of the patch-staged conv kernels (included by conv.hip).
+//
+// v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 MFMA rate (MI355X_MICROARCH.md "Matrix cores").  An fp32 value
+// is the exact sum of three bf16 pieces (8 significant bits each, round-to-nearest): x = p0 + p1 + p2.  The product
+// of two such sums keeps the six terms pi*qj with i + j <= 2 (the dropped ones are below 2^-24 of |x||y|), each term
+// one v_mfma_f32_32x32x16_bf16 with fp32 accumulation: fp32-grade results at 6/16 of the fp32-MFMA cost, and 8x fewer
+// LDS operand reads per FLOP (one ds_read_b128 carries 8 k-values).  SPLIT = 1 is plain bf16 operands.
+// Activation pieces are made ONCE per element while staging (after the fused activation), never per tap; weight pieces
+// once per layer call by pack_conv_weight_kernel.
+//
+// LDS images are channel-innermost: [position][16 channels] bf16 = 32-byte rows, so a tap shift moves whole rows and
+// every operand read stays 16-byte aligned.  The two 16-byte halves of a row are swapped on odd 8-row groups
+// (half ^ ((row >> 3) & 1)): the 16 lanes one ds_read_b128 cycle serves ({0-3,12-15,20-27} ...) then fall on 16
+// different 16-byte slots of the 256-byte bank row for any run of consecutive rows.
+#pragma once
+
+namespace mtrssm {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u16x8 = __attribute__((ext_vector_type(8))) unsigned short;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+
+constexpr int kRowB = 32;      // bytes per LDS row: 16 bf16 channels
+// taps whose weights are resident in LDS at once: bounded by the register-prefetch budget (2 waves / SIMD need <= 256 VGPRs)
+__host__ __device__ constexpr int split_tg(int split) { return split == 3 ? 5 : 9; }
+
+template <int SPLIT>
+__device__ __forceinline__ void split_bf16(float x, unsigned short (&p)[SPLIT]) {
+  float r = x;
+#pragma unroll
+  for (int s = 0; s < SPLIT; ++s) {
+    const __bf16 h = (__bf16)r;
+    p[s] = __builtin_bit_cast(unsigned short, h);
+    r -= (float)h;  // exact in fp32
+  }
+}
+
+// Branch-free activations for the staging loops (a libm expm1f per element costs more VALU time than the MFMAs it feeds).
+// ELU: v_exp_f32 - 1 on the negative side: absolute error < 1.2e-7, the rounding grain of the O(1) activations it joins
+// in the dot product.
+__device__ __forceinline__ float elu_fast(float x) { return x > 0.f ? x : __expf(x) - 1.f; }
+template <int N>
+__device__ __forceinline__ void act_inplace(float (&v)[N], int act) {
+  if (act == MTRSSM_ACT_ELU) {
+#pragma unroll
+    for (int u = 0; u < N; ++u) v[u] = elu_fast(v[u]);
+  } else if (act == MTRSSM_ACT_RELU) {
+#pragma unroll
+    for (int u = 0; u < N; ++u) v[u] = v[u] > 0.f ? v[u] : 0.f;
+  } else if (act == MTRSSM_ACT_TANH) {
+#pragma unroll
+    for (int u = 0; u < N; ++u) v[u] = tanhf(v[u]);
+  }
+}
+
+__device__ __forceinline__ unsigned swz_row(int row, int half) { return (unsigned)row * kRowB + (unsigned)((half ^ ((row >> 3) & 1)) << 4); }
+
+// w[o][i][ky][kx] (any element strides) -> wp fp32 [OPad][taps][IPad] zero padded, and (pieces > 0) the bf16 pieces
+// wq [pieces][OPad][taps][IPad] of the same values.
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, int O, int I, int KH, int KW, long so, long si, long sh, long sw,
+                                        int OPad, int IPad, int pieces, float* __restrict__ wp, unsigned short* __restrict__ wq) {
+  const int taps = KH * KW;
+  const long total = (long)OPad * taps * IPad;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int i = (int)(idx % IPad);
+    const long ot = idx / IPad;
+    const int tap = (int)(ot % taps), o = (int)(ot / taps);
+    float v = 0.f;
+    if (o < O && i < I) v = w[o * so + i * si + (tap / KW) * sh + (tap % KW) * sw];
+    wp[idx] = v;
+    float r = v;
+    for (int s = 0; s < pieces; ++s) {
+      const __bf16 h = (__bf16)r;
+      wq[(long)s * total + idx] = __builtin_bit_cast(unsigned short, h);
+      r -= (float)h;
+    }
+  }
+}
+
+// Epilogue of the gather kernels: out = (acc + bias) * act'(actgrad_in) + add_in for one lane's pixel x 32*NT channels.
+// All global loads are issued first (clamped addresses, no branch around a load), then the arithmetic, then the
+// stores: written as "load, wait, use" per element the 3 x 32 dependent loads cost ~60 us of latency per workgroup.
+// Offsets are 32-bit (host checks the output tensor has < 2^31 elements).
+template <int NT>
+__device__ __forceinline__ void conv_epilogue(const MtrssmConvGeom& g, const f32x16 (&acc)[NT], long pe, long ptot, int plane_q, int co0,
+                                              int kl, const float* __restrict__ bias, const float* __restrict__ actgrad_in,
+                                              const float* __restrict__ add_in, float* __restrict__ out) {
+  const bool pv = pe < ptot;
+  const long pc = pv ? pe : ptot - 1;
+  const int n = (int)(pc / plane_q);
+  const int rem = (int)(pc - (long)n * plane_q);
+  const int oy = rem / g.Wq, ox = rem - oy * g.Wq;
+  const unsigned plane_o = (unsigned)(g.Ho * g.Wo);
+  const unsigned base = (unsigned)n * (unsigned)g.Cout * plane_o + (unsigned)((oy * g.OS + g.QY) * g.Wo + (ox * g.OS + g.QX));
+  const bool full = co0 + 32 * NT <= g.Cout;  // workgroup-uniform: no channel clamping needed
+  const int cb = co0 + 4 * kl;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {  // one 32-channel tile at a time: 64 live registers instead of 64 NT
+    unsigned off[16];
+    float bv[16], gv[16], av[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int co = cb + j * 32 + (r & 3) + 8 * (r >> 2);
+      if (!full) co = co < g.Cout ? co : g.Cout - 1;
+      off[r] = base + (unsigned)co * plane_o;
+      bv[r] = bias ? bias[co] : 0.f;
+    }
+    if (actgrad_in) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gv[r] = actgrad_in[off[r]];
+    }
+    if (add_in) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) av[r] = add_in[off[r]];
+    }
+    if (actgrad_in) {
+      if (g.act == MTRSSM_ACT_ELU) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gv[r] = gv[r] > 0.f ? 1.f : __expf(gv[r]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gv[r] = act_grad_from_in(gv[r], g.act);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = acc[j][r] + bv[r];
+      if (actgrad_in) v *= gv[r];
+      if (add_in) v += av[r];
+      asm volatile("" : "+v"(v));  // materialise here: sunk into the store's branch, every store waits for vmcnt(0)
+      bv[r] = v;
+    }
+    if (full && pv) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) out[off[r]] = bv[r];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = cb + j * 32 + (r & 3) + 8 * (r >> 2);
+        if (pv && co < g.Cout) out[off[r]] = bv[r];
+      }
+    }
+  }
+}
+
+// Workgroup tile = 128 pixels x 32*NT channels, 4 waves (32 pixels each).  Steps = (16-channel chunk) x (tap group of tg
+// taps, tg | taps); per step the weights of the group's taps (and, on a new chunk, the patch) go registers -> LDS between
+// two barriers, then the NEXT step's global loads are issued and stay in flight under this step's MFMA chain (no barrier
+// inside).  The staging is VALU work (activation + three bf16 roundings per element) of the order of the MFMA time, so all
+// addressing is hoisted: per-thread 32-bit offsets are computed once, a step adds one scalar.
+template <int NT, int SPLIT, int PIT>  // PIT: patch positions per thread pair = 128 * PIT >= ps_raw
+__global__ __launch_bounds__(kConvThreads, 2) void conv_gather_split_kernel(
+    const MtrssmConvGeom g, const float* __restrict__ src, const float* __restrict__ src2, const unsigned short* __restrict__ wq,
+    const float* __restrict__ bias, const float* __restrict__ actgrad_in, const float* __restrict__ add_in, float* __restrict__ out,
+    const int tg, const int ngroups) {
+  constexpr int TCO = 32 * NT;
+  constexpr int LOGT = NT == 2 ? 6 : 5;
+  constexpr int WP = (split_tg(SPLIT) * SPLIT * TCO * 2 + kConvThreads - 1) / kConvThreads;  // 16-byte weight pieces per thread
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const PatchGeom pg(g, kTP);
+  const int img = pg.ps_raw * kRowB;                          // one piece of the patch: [ps_raw][16 ch]
+  unsigned char* patch = lds_raw;                             // [SPLIT][ps_raw][32 B]
+  unsigned char* w_lds = patch + (size_t)SPLIT * img;         // [tg][SPLIT][TCO][32 B]
+  int* rtab = reinterpret_cast<int*>(w_lds + (size_t)tg * SPLIT * TCO * kRowB);  // [ps_raw]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kl = lane >> 5, il = lane & 31;
+  const int taps = g.KH * g.KW;
+  const int ctot = g.C + g.C2;
+  const int plane_s = g.Hs * g.Ws, plane_q = g.Hq * g.Wq;
+  const long ptot = (long)g.N * plane_q;
+  const long p0 = (long)blockIdx.x * kTP;
+  const int co0 = blockIdx.y * TCO;
+  const int n0 = (int)(p0 / plane_q);
+  const int r0 = (int)((p0 - (long)n0 * plane_q) / g.Wq);
+
+  {  // patch position -> source offset, once per workgroup
+    const int khm = g.TS > 0 ? 0 : g.KH - 1, kwm = g.TS > 0 ? 0 : g.KW - 1;
+    const int sy0 = r0 * g.SS + g.OFFY - khm, sx0 = g.OFFX - kwm;
+    const int phw = pg.ph * pg.pw;
+    for (int r = tid; r < pg.ps_raw; r += kConvThreads) {
+      const int ip = r / phw, q = r - ip * phw;
+      const int pr = q / pg.pw, pcn = q - pr * pg.pw;
+      const int sy = sy0 + pr, sx = sx0 + pcn;
+      const bool ok = n0 + ip < g.N && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
+      rtab[r] = ok ? ((ip << 26) | (sy * g.Ws + sx)) : -1;
+    }
+  }
+  int pixpos;  // this lane's pixel -> patch position (B operand: lane il = pixel); wave w owns pixels [32 w, 32 w + 32)
+  {
+    const int pix = wave * 32 + il;
+    const int row = pix / g.Wq, ox = pix - row * g.Wq;
+    const int ip = row / pg.rp, lr = row - ip * pg.rp;
+    pixpos = ip * pg.ph * pg.pw + lr * g.SS * pg.pw + ox * g.SS;
+  }
+  __syncthreads();  // rtab
+
+  // ---- register prefetch state and the hoisted per-thread offsets
+  float pv[PIT][8];
+  u32x4 wv[WP];
+  const int oct = __builtin_amdgcn_readfirstlane(wave & 1);
+  const int rlane = (wave >> 1) * 64 + lane;
+  const float* src_n0 = src + (size_t)n0 * g.C * plane_s;
+  const int npieces = tg * SPLIT * TCO * 2;
+  unsigned fo[PIT], f2[PIT];   // element offsets of this thread's patch positions in src (from src_n0) / src2
+  bool okp[PIT];
+#pragma unroll
+  for (int it = 0; it < PIT; ++it) {
+    const int r = it * 128 + rlane;
+    const int t = r < pg.ps_raw ? rtab[r] : -1;
+    okp[it] = t >= 0;
+    const int tt = okp[it] ? t : 0;
+    fo[it] = (unsigned)(tt >> 26) * (unsigned)(g.C * plane_s) + (unsigned)(tt & ((1 << 26) - 1));
+    f2[it] = (unsigned)(tt & ((1 << 26) - 1));
+  }
+  unsigned wo[WP];  // element offset of weight piece i in wq for tap group 0, chunk 0; q = tid + 256 i over [t][s][row][half]
+#pragma unroll
+  for (int i = 0; i < WP; ++i) {
+    int q = tid + kConvThreads * i;
+    q = q < npieces ? q : npieces - 1;
+    const int half = q & 1, row = (q >> 1) & (TCO - 1), st = q >> (1 + LOGT);
+    const int t = st / SPLIT, s = st - t * SPLIT;
+    wo[i] = (unsigned)s * (unsigned)(g.CoutPad * taps * g.Cpad) + (unsigned)(((co0 + row) * taps + t) * g.Cpad + half * 8);
+  }
+
+  // Loads are branch-free (clamped addresses, masked at store time): a load inside a divergent branch makes the compiler
+  // wait for it at the join, which serialises the prefetch.
+  auto load_patch = [&](int c0) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      int c = c0 + oct * 8 + u;
+      c = c < ctot ? c : ctot - 1;  // scalar
+      if (c < g.C) {
+        const float* bp = src_n0 + (size_t)c * plane_s;
+#pragma unroll
+        for (int it = 0; it < PIT; ++it) pv[it][u] = bp[fo[it]];
+      } else {
+        const float* bp = src2 + (size_t)(c - g.C) * plane_s;
+#pragma unroll
+        for (int it = 0; it < PIT; ++it) pv[it][u] = bp[f2[it]];
+      }
+    }
+  };
+  auto store_patch = [&](int c0) {
+#pragma unroll
+    for (int it = 0; it < PIT; ++it) {
+      const int r = it * 128 + rlane;
+      if (r < pg.ps_raw) {
+        u16x8 q[SPLIT];
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = (okp[it] && c0 + oct * 8 + u < ctot) ? pv[it][u] : 0.f;
+        if (g.pre_act) act_inplace<8>(x, g.act);  // act(0) = 0 for every supported activation
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          unsigned short p[SPLIT];
+          split_bf16<SPLIT>(x[u], p);
+#pragma unroll
+          for (int s = 0; s < SPLIT; ++s) q[s][u] = p[s];
+        }
+        const unsigned a = swz_row(r, oct);
+#pragma unroll
+        for (int s = 0; s < SPLIT; ++s) *reinterpret_cast<u16x8*>(patch + (size_t)s * img + a) = q[s];
+      }
+    }
+  };
+  auto load_w = [&](int c0, int tap0) {
+    const unsigned short* wb = wq + (size_t)tap0 * g.Cpad + c0;  // scalar
+#pragma unroll
+    for (int i = 0; i < WP; ++i) wv[i] = *reinterpret_cast<const u32x4*>(wb + wo[i]);
+  };
+  auto store_w = [&]() {
+#pragma unroll
+    for (int i = 0; i < WP; ++i) {
+      const int q = tid + kConvThreads * i;
+      const int half = q & 1, row = (q >> 1) & (TCO - 1);
+      if (q < npieces) *reinterpret_cast<u32x4*>(w_lds + (size_t)(q >> 1) * kRowB + ((half ^ ((row >> 3) & 1)) << 4)) = wv[i];
+    }
+  };
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  const unsigned wa = swz_row(il, kl);  // (j*32 + il) >> 3 has the parity of il >> 3
+  const int nsteps = taps > 0 ? (g.Cpad / kKC) * ngroups : 0;
+  if (nsteps > 0) { load_patch(0); load_w(0, 0); }
+  int grp = 0, c0 = 0;
+  for (int step = 0; step < nsteps; ++step) {
+    const int tap0 = grp * tg;
+    __syncthreads();  // every wave is done with the previous step's LDS images
+    if (grp == 0) store_patch(c0);
+    store_w();
+    __syncthreads();
+    {  // next step's loads: in flight under this step's MFMAs
+      int ngrp = grp + 1, nc0 = c0;
+      if (ngrp == ngroups) { ngrp = 0; nc0 += kKC; }
+      if (step + 1 < nsteps) {
+        if (ngrp == 0) load_patch(nc0);
+        load_w(nc0, ngrp * tg);
+      }
+    }
+    int ty = tap0 / g.KW, tx = tap0 - ty * g.KW;
+    for (int t = 0; t < tg; ++t) {
+      const int tapoff = g.TS > 0 ? ty * pg.pw + tx : (g.KH - 1 - ty) * pg.pw + (g.KW - 1 - tx);
+      if (++tx == g.KW) { tx = 0; ++ty; }
+      const int pp = pixpos + tapoff;
+      const unsigned pa = swz_row(pp, kl);
+      bf16x8 b[SPLIT], a[NT][SPLIT];
+#pragma unroll
+      for (int s = 0; s < SPLIT; ++s) b[s] = *reinterpret_cast<const bf16x8*>(patch + (size_t)s * img + pa);
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int s = 0; s < SPLIT; ++s)
+          a[j][s] = *reinterpret_cast<const bf16x8*>(w_lds + ((size_t)(t * SPLIT + s) * TCO + j * 32) * kRowB + wa);
+      // smallest terms first (i + j = SPLIT-1 ... 0)
+#pragma unroll
+      for (int ord = SPLIT - 1; ord >= 0; --ord)
+#pragma unroll
+        for (int sa = 0; sa <= ord; ++sa)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j][sa], b[ord - sa], acc[j], 0, 0, 0);
+    }
+    if (++grp == ngroups) { grp = 0; c0 += kKC; }
+  }
+
+  conv_epilogue<NT>(g, acc, p0 + wave * 32 + il, ptot, plane_q, co0, kl, bias, actgrad_in, add_in, out);
+}
+
+}  // namespace mtrssm
