@@ -1033,7 +1033,7 @@ int conv_gather_gemm_launch(const MtrssmConvGeom* g, const float* src, const flo
         const int taps = g->KH * g->KW;
         static const int tg_env = getenv("MTRSSM_SPLIT_TG") ? atoi(getenv("MTRSSM_SPLIT_TG")) : 99;
         const int tg_cap = tg_env < split_tg(sp) ? tg_env : split_tg(sp);
-        auto lds_of = [&](int t) { return (size_t)sp * ((size_t)pg.ps_raw * kRowB + (size_t)t * tco * kRowB) + (size_t)pg.ps_raw * sizeof(int); };
+        auto lds_of = [&](int t) { return (size_t)sp * ((size_t)pg.ps_raw * kRowB + (size_t)t * tco * kRowB); };
         int tgs = 1;  // largest divisor of taps within the register / LDS budget
         for (int t = 1; t <= tg_cap && t <= taps; ++t)
           if (taps % t == 0 && lds_of(t) <= 80 * 1024) tgs = t;

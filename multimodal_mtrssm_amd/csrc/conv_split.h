@@ -77,79 +77,91 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, int O, int 
   }
 }
 
-// Epilogue of the gather kernels: out = (acc + bias) * act'(actgrad_in) + add_in for one lane's pixel x 32*NT channels.
-// All global loads are issued first (clamped addresses, no branch around a load), then the arithmetic, then the
-// stores: written as "load, wait, use" per element the 3 x 32 dependent loads cost ~60 us of latency per workgroup.
-// Offsets are 32-bit (host checks the output tensor has < 2^31 elements).
-template <int NT>
-__device__ __forceinline__ void conv_epilogue(const MtrssmConvGeom& g, const f32x16 (&acc)[NT], long pe, long ptot, int plane_q, int co0,
-                                              int kl, const float* __restrict__ bias, const float* __restrict__ actgrad_in,
-                                              const float* __restrict__ add_in, float* __restrict__ out) {
-  const bool pv = pe < ptot;
-  const long pc = pv ? pe : ptot - 1;
-  const int n = (int)(pc / plane_q);
-  const int rem = (int)(pc - (long)n * plane_q);
-  const int oy = rem / g.Wq, ox = rem - oy * g.Wq;
-  const unsigned plane_o = (unsigned)(g.Ho * g.Wo);
-  const unsigned base = (unsigned)n * (unsigned)g.Cout * plane_o + (unsigned)((oy * g.OS + g.QY) * g.Wo + (ox * g.OS + g.QX));
-  const bool full = co0 + 32 * NT <= g.Cout;  // workgroup-uniform: no channel clamping needed
-  const int cb = co0 + 4 * kl;
+// Epilogue of the gather kernels: out = (acc + bias) * act'(actgrad_in) + add_in for one lane's pixel x 32*NT channels,
+// one 32-channel tile (16 values per lane) at a time.  A tile's global loads are all issued first (clamped addresses, no
+// branch around a load), then the arithmetic, then the stores: written as "load, wait, use" per element the 3 x 32
+// dependent loads cost ~60 us of latency per workgroup.  load(j) can be issued early (tile 0 under the last MFMA chain,
+// tile j+1 before tile j is finished).  Offsets are 32-bit (host checks the output has < 2^31 elements).
+struct ConvEpilogue {
+  unsigned base, plane_o;
+  bool pv, full;
+  int cb, cout;
+  float bv[16], gv[16], av[16];  // the tile in flight
+
+  __device__ __forceinline__ void init(const MtrssmConvGeom& g, long pe, long ptot, int plane_q, int co0, int tco, int kl) {
+    pv = pe < ptot;
+    const long pc = pv ? pe : ptot - 1;
+    const int n = (int)(pc / plane_q);
+    const int rem = (int)(pc - (long)n * plane_q);
+    const int oy = rem / g.Wq, ox = rem - oy * g.Wq;
+    plane_o = (unsigned)(g.Ho * g.Wo);
+    base = (unsigned)n * (unsigned)g.Cout * plane_o + (unsigned)((oy * g.OS + g.QY) * g.Wo + (ox * g.OS + g.QX));
+    full = co0 + tco <= g.Cout;  // workgroup-uniform: no channel clamping needed
+    cb = co0 + 4 * kl;
+    cout = g.Cout;
+  }
+  __device__ __forceinline__ int chan(int j, int r) const {
+    const int co = cb + j * 32 + (r & 3) + 8 * (r >> 2);
+    return full ? co : (co < cout ? co : cout - 1);
+  }
+  __device__ __forceinline__ void load(int j, const float* __restrict__ bias, const float* __restrict__ actgrad_in,
+                                       const float* __restrict__ add_in) {
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {  // one 32-channel tile at a time: 64 live registers instead of 64 NT
-    unsigned off[16];
-    float bv[16], gv[16], av[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int co = cb + j * 32 + (r & 3) + 8 * (r >> 2);
-      if (!full) co = co < g.Cout ? co : g.Cout - 1;
-      off[r] = base + (unsigned)co * plane_o;
-      bv[r] = bias ? bias[co] : 0.f;
-    }
+    for (int r = 0; r < 16; ++r) bv[r] = bias ? bias[chan(j, r)] : 0.f;
     if (actgrad_in) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) gv[r] = actgrad_in[off[r]];
+      for (int r = 0; r < 16; ++r) gv[r] = actgrad_in[base + (unsigned)chan(j, r) * plane_o];
     }
     if (add_in) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) av[r] = add_in[off[r]];
+      for (int r = 0; r < 16; ++r) av[r] = add_in[base + (unsigned)chan(j, r) * plane_o];
     }
-    if (actgrad_in) {
-      if (g.act == MTRSSM_ACT_ELU) {
+  }
+  // consumes the loaded tile into res[] (so that the next tile's load can be issued before the stores)
+  __device__ __forceinline__ void combine(const f32x16& acc, int act, bool has_g, bool has_a, float (&res)[16]) {
+    if (has_g) {
+      if (act == MTRSSM_ACT_ELU) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) gv[r] = gv[r] > 0.f ? 1.f : __expf(gv[r]);
       } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) gv[r] = act_grad_from_in(gv[r], g.act);
+        for (int r = 0; r < 16; ++r) gv[r] = act_grad_from_in(gv[r], act);
       }
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      float v = acc[j][r] + bv[r];
-      if (actgrad_in) v *= gv[r];
-      if (add_in) v += av[r];
+      float v = acc[r] + bv[r];
+      if (has_g) v *= gv[r];
+      if (has_a) v += av[r];
       asm volatile("" : "+v"(v));  // materialise here: sunk into the store's branch, every store waits for vmcnt(0)
-      bv[r] = v;
+      res[r] = v;
     }
+  }
+  __device__ __forceinline__ void store(int j, const float (&res)[16], float* __restrict__ out) const {
     if (full && pv) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) out[off[r]] = bv[r];
+      for (int r = 0; r < 16; ++r) out[base + (unsigned)chan(j, r) * plane_o] = res[r];
     } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = cb + j * 32 + (r & 3) + 8 * (r >> 2);
-        if (pv && co < g.Cout) out[off[r]] = bv[r];
+        if (pv && co < cout) out[base + (unsigned)co * plane_o] = res[r];
       }
     }
   }
-}
+};
 
 // Workgroup tile = 128 pixels x 32*NT channels, 4 waves (32 pixels each).  Steps = (16-channel chunk) x (tap group of tg
-// taps, tg | taps); per step the weights of the group's taps (and, on a new chunk, the patch) go registers -> LDS between
-// two barriers, then the NEXT step's global loads are issued and stay in flight under this step's MFMA chain (no barrier
-// inside).  The staging is VALU work (activation + three bf16 roundings per element) of the order of the MFMA time, so all
-// addressing is hoisted: per-thread 32-bit offsets are computed once, a step adds one scalar.
+// taps, tg | taps).  A layer is only ~2 tiles per resident workgroup slot, so the kernel time is the per-workgroup
+// dependency chain times the number of rounds, not a throughput bound (measured with everything but the skeleton switched
+// off: profiles/round1_notes.md); everything below shortens that chain:
+//  * no index table / extra barrier: every thread derives its own patch positions' source offsets;
+//  * weights (L2-resident) are fetched one step ahead, the patch (HBM) a whole chunk ahead, into registers; they go to LDS
+//    between the two barriers of a step, activation + bf16 pieces applied once per element;
+//  * the tap loop is software-pipelined (the next tap's fragments are read while this tap's MFMAs run);
+//  * the epilogue's loads are issued before the last MFMA chain, in registers the prefetch no longer needs.
 template <int NT, int SPLIT, int PIT>  // PIT: patch positions per thread pair = 128 * PIT >= ps_raw
-__global__ __launch_bounds__(kConvThreads, 2) void conv_gather_split_kernel(
+__global__ __launch_bounds__(kConvThreads, 3) void conv_gather_split_kernel(
     const MtrssmConvGeom g, const float* __restrict__ src, const float* __restrict__ src2, const unsigned short* __restrict__ wq,
     const float* __restrict__ bias, const float* __restrict__ actgrad_in, const float* __restrict__ add_in, float* __restrict__ out,
     const int tg, const int ngroups) {
@@ -161,7 +173,6 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_gather_split_kernel(
   const int img = pg.ps_raw * kRowB;                          // one piece of the patch: [ps_raw][16 ch]
   unsigned char* patch = lds_raw;                             // [SPLIT][ps_raw][32 B]
   unsigned char* w_lds = patch + (size_t)SPLIT * img;         // [tg][SPLIT][TCO][32 B]
-  int* rtab = reinterpret_cast<int*>(w_lds + (size_t)tg * SPLIT * TCO * kRowB);  // [ps_raw]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kl = lane >> 5, il = lane & 31;
@@ -174,27 +185,6 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_gather_split_kernel(
   const int n0 = (int)(p0 / plane_q);
   const int r0 = (int)((p0 - (long)n0 * plane_q) / g.Wq);
 
-  {  // patch position -> source offset, once per workgroup
-    const int khm = g.TS > 0 ? 0 : g.KH - 1, kwm = g.TS > 0 ? 0 : g.KW - 1;
-    const int sy0 = r0 * g.SS + g.OFFY - khm, sx0 = g.OFFX - kwm;
-    const int phw = pg.ph * pg.pw;
-    for (int r = tid; r < pg.ps_raw; r += kConvThreads) {
-      const int ip = r / phw, q = r - ip * phw;
-      const int pr = q / pg.pw, pcn = q - pr * pg.pw;
-      const int sy = sy0 + pr, sx = sx0 + pcn;
-      const bool ok = n0 + ip < g.N && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
-      rtab[r] = ok ? ((ip << 26) | (sy * g.Ws + sx)) : -1;
-    }
-  }
-  int pixpos;  // this lane's pixel -> patch position (B operand: lane il = pixel); wave w owns pixels [32 w, 32 w + 32)
-  {
-    const int pix = wave * 32 + il;
-    const int row = pix / g.Wq, ox = pix - row * g.Wq;
-    const int ip = row / pg.rp, lr = row - ip * pg.rp;
-    pixpos = ip * pg.ph * pg.pw + lr * g.SS * pg.pw + ox * g.SS;
-  }
-  __syncthreads();  // rtab
-
   // ---- register prefetch state and the hoisted per-thread offsets
   float pv[PIT][8];
   u32x4 wv[WP];
@@ -204,14 +194,20 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_gather_split_kernel(
   const int npieces = tg * SPLIT * TCO * 2;
   unsigned fo[PIT], f2[PIT];   // element offsets of this thread's patch positions in src (from src_n0) / src2
   bool okp[PIT];
+  {
+    const int khm = g.TS > 0 ? 0 : g.KH - 1, kwm = g.TS > 0 ? 0 : g.KW - 1;
+    const int sy0 = r0 * g.SS + g.OFFY - khm, sx0 = g.OFFX - kwm;
+    const int phw = pg.ph * pg.pw;
 #pragma unroll
-  for (int it = 0; it < PIT; ++it) {
-    const int r = it * 128 + rlane;
-    const int t = r < pg.ps_raw ? rtab[r] : -1;
-    okp[it] = t >= 0;
-    const int tt = okp[it] ? t : 0;
-    fo[it] = (unsigned)(tt >> 26) * (unsigned)(g.C * plane_s) + (unsigned)(tt & ((1 << 26) - 1));
-    f2[it] = (unsigned)(tt & ((1 << 26) - 1));
+    for (int it = 0; it < PIT; ++it) {
+      const int r = it * 128 + rlane;
+      const int ip = r / phw, q = r - ip * phw;
+      const int pr = q / pg.pw, pcn = q - pr * pg.pw;
+      const int sy = sy0 + pr, sx = sx0 + pcn;
+      okp[it] = r < pg.ps_raw && n0 + ip < g.N && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
+      f2[it] = okp[it] ? (unsigned)(sy * g.Ws + sx) : 0u;
+      fo[it] = okp[it] ? (unsigned)ip * (unsigned)(g.C * plane_s) + f2[it] : 0u;
+    }
   }
   unsigned wo[WP];  // element offset of weight piece i in wq for tap group 0, chunk 0; q = tid + 256 i over [t][s][row][half]
 #pragma unroll
@@ -223,8 +219,8 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_gather_split_kernel(
     wo[i] = (unsigned)s * (unsigned)(g.CoutPad * taps * g.Cpad) + (unsigned)(((co0 + row) * taps + t) * g.Cpad + half * 8);
   }
 
-  // Loads are branch-free (clamped addresses, masked at store time): a load inside a divergent branch makes the compiler
-  // wait for it at the join, which serialises the prefetch.
+  // Loads are branch-free per lane (clamped addresses, masked at store time): a load inside a divergent branch makes the
+  // compiler wait for it at the join, which serialises the prefetch.
   auto load_patch = [&](int c0) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -278,57 +274,99 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_gather_split_kernel(
     }
   };
 
+  const int nsteps = taps > 0 ? (g.Cpad / kKC) * ngroups : 0;
+  if (nsteps > 0) { load_patch(0); load_w(0, 0); }
+
+  int pixpos;  // this lane's pixel -> patch position (B operand: lane il = pixel); wave w owns pixels [32 w, 32 w + 32)
+  {
+    const int pix = wave * 32 + il;
+    const int row = pix / g.Wq, ox = pix - row * g.Wq;
+    const int ip = row / pg.rp, lr = row - ip * pg.rp;
+    pixpos = ip * pg.ph * pg.pw + lr * g.SS * pg.pw + ox * g.SS;
+  }
   f32x16 acc[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-
   const unsigned wa = swz_row(il, kl);  // (j*32 + il) >> 3 has the parity of il >> 3
-  const int nsteps = taps > 0 ? (g.Cpad / kKC) * ngroups : 0;
-  if (nsteps > 0) { load_patch(0); load_w(0, 0); }
+  constexpr bool kPipe = SPLIT == 1;  // register budget: three bf16 pieces leave no room for a second fragment set
+  ConvEpilogue epi;
+  epi.init(g, p0 + wave * 32 + il, ptot, plane_q, co0, TCO, kl);
+
+  // one tap's operand fragments
+  struct Frag { bf16x8 b[SPLIT], a[NT][SPLIT]; };
+  auto read_frag = [&](Frag& f, int t, int tapoff) {
+    const int pp = pixpos + tapoff;
+    const unsigned pa = swz_row(pp, kl);
+#pragma unroll
+    for (int s = 0; s < SPLIT; ++s) f.b[s] = *reinterpret_cast<const bf16x8*>(patch + (size_t)s * img + pa);
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int s = 0; s < SPLIT; ++s)
+        f.a[j][s] = *reinterpret_cast<const bf16x8*>(w_lds + ((size_t)(t * SPLIT + s) * TCO + j * 32) * kRowB + wa);
+  };
+  auto mfma_frag = [&](const Frag& f) {  // smallest terms first (i + j = SPLIT-1 ... 0)
+#pragma unroll
+    for (int ord = SPLIT - 1; ord >= 0; --ord)
+#pragma unroll
+      for (int sa = 0; sa <= ord; ++sa)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[j][sa], f.b[ord - sa], acc[j], 0, 0, 0);
+  };
+
   int grp = 0, c0 = 0;
   for (int step = 0; step < nsteps; ++step) {
     const int tap0 = grp * tg;
-    __syncthreads();  // every wave is done with the previous step's LDS images
-    if (grp == 0) store_patch(c0);
+    if (step > 0) __syncthreads();  // every wave is done with the previous step's LDS images
     store_w();
-    __syncthreads();
-    {  // next step's loads: in flight under this step's MFMAs
+    {  // next step's weights (L2-resident): in flight under the patch conversion and this step's MFMAs
       int ngrp = grp + 1, nc0 = c0;
       if (ngrp == ngroups) { ngrp = 0; nc0 += kKC; }
-      if (step + 1 < nsteps) {
-        if (ngrp == 0) load_patch(nc0);
-        load_w(nc0, ngrp * tg);
-      }
+      if (step + 1 < nsteps) load_w(nc0, ngrp * tg);
     }
+    if (grp == 0) {
+      store_patch(c0);
+      // the NEXT chunk's patch (HBM): a whole chunk of steps ahead of its conversion, in the same registers
+      if (c0 + kKC < g.Cpad) load_patch(c0 + kKC);
+    }
+    __syncthreads();
     int ty = tap0 / g.KW, tx = tap0 - ty * g.KW;
-    for (int t = 0; t < tg; ++t) {
-      const int tapoff = g.TS > 0 ? ty * pg.pw + tx : (g.KH - 1 - ty) * pg.pw + (g.KW - 1 - tx);
+    auto next_tapoff = [&]() {
+      const int o = g.TS > 0 ? ty * pg.pw + tx : (g.KH - 1 - ty) * pg.pw + (g.KW - 1 - tx);
       if (++tx == g.KW) { tx = 0; ++ty; }
-      const int pp = pixpos + tapoff;
-      const unsigned pa = swz_row(pp, kl);
-      bf16x8 b[SPLIT], a[NT][SPLIT];
-#pragma unroll
-      for (int s = 0; s < SPLIT; ++s) b[s] = *reinterpret_cast<const bf16x8*>(patch + (size_t)s * img + pa);
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int s = 0; s < SPLIT; ++s)
-          a[j][s] = *reinterpret_cast<const bf16x8*>(w_lds + ((size_t)(t * SPLIT + s) * TCO + j * 32) * kRowB + wa);
-      // smallest terms first (i + j = SPLIT-1 ... 0)
-#pragma unroll
-      for (int ord = SPLIT - 1; ord >= 0; --ord)
-#pragma unroll
-        for (int sa = 0; sa <= ord; ++sa)
-#pragma unroll
-          for (int j = 0; j < NT; ++j)
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j][sa], b[ord - sa], acc[j], 0, 0, 0);
+      return o;
+    };
+    if (kPipe) {  // software-pipelined taps: fragments of tap t+1 are read while tap t's MFMAs run
+      Frag f0, f1;
+      read_frag(f0, 0, next_tapoff());
+      int t = 0;
+      for (; t + 2 <= tg; t += 2) {
+        read_frag(f1, t + 1, next_tapoff());
+        mfma_frag(f0);
+        if (t + 2 < tg) read_frag(f0, t + 2, next_tapoff());
+        mfma_frag(f1);
+      }
+      if (t < tg) mfma_frag(f0);
+    } else {
+      for (int t = 0; t < tg; ++t) {
+        Frag f;
+        read_frag(f, t, next_tapoff());
+        mfma_frag(f);
+      }
     }
     if (++grp == ngroups) { grp = 0; c0 += kKC; }
   }
-
-  conv_epilogue<NT>(g, acc, p0 + wave * 32 + il, ptot, plane_q, co0, kl, bias, actgrad_in, add_in, out);
+  epi.load(0, bias, actgrad_in, add_in);
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    float res[16];
+    epi.combine(acc[j], g.act, actgrad_in != nullptr, add_in != nullptr, res);
+    if (j + 1 < NT) epi.load(j + 1, bias, actgrad_in, add_in);
+    epi.store(j, res, out);
+  }
 }
 
 }  // namespace mtrssm
