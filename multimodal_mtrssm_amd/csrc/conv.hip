@@ -1113,6 +1113,37 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
       { set_last_kernel("mtrssm::conv_weight_grad_thin_kernel"); hipLaunchKernelGGL(conv_weight_grad_thin_kernel, dim3((unsigned)splits), dim3(kConvThreads), lds_thin, stream, *g, a, src, src2, pre_act_a, dwp, dbias); }
       return launched("conv_weight_grad(thin)");
     }
+    if (tiles && (g->mfma_split == 1 || g->mfma_split == 3) && (g->Hq * g->Wq) % 8 == 0 && ctot <= 128 && !((uintptr_t)a & 15)) {
+      // split-bf16 operands (conv_split.h): same persistent structure, bf16 MFMA + transposed LDS reads
+      const int sp = g->mfma_split;
+      int cp2 = 16;
+      while (cp2 < ctot) cp2 *= 2;
+      const int nhalf = taps * (cp2 / 16);
+      const int tco_s = g->Cout > 32 ? 64 : 32;
+      const int nblk = (pg.ps_raw + 63) / 64;
+      const size_t lds_s = 2 * (size_t)sp * ((size_t)tco_s * kWgLdaB + (size_t)pg.ps_raw * cp2 * 2) + (size_t)nblk * 64 * sizeof(int);
+      if ((nhalf + 1) / 2 <= 4 * kMaxQ && pg.ps_raw < 1024 && pg.ipg < 1024 && lds_s <= 156 * 1024 &&
+          (long)pg.ipg * g->C * g->Hs * g->Ws < (1L << 31)) {
+        const long groups = (ptot + kGP - 1) / kGP;
+        const int cotiles = g->Cout > 32 ? g->CoutPad / 64 : 1;
+        long splits = 256 / cotiles;
+        if (splits > groups) splits = groups;
+        if (splits < 1) splits = 1;
+        dim3 grid((unsigned)splits, cotiles);
+#define MTRSSM_WG_SPLIT_LAUNCH(NT_, SP_)                                                                                       \
+  {                                                                                                                             \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_weight_grad_split_kernel<NT_, SP_>),                           \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);                                          \
+    set_last_kernel("mtrssm::conv_weight_grad_split_kernel<" #NT_ ", " #SP_ ">");                                                \
+    hipLaunchKernelGGL((conv_weight_grad_split_kernel<NT_, SP_>), grid, dim3(2 * kConvThreads), lds_s, stream, *g, a, src, src2, \
+                       pre_act_a, dwp, dbias, cp2);                                                                             \
+  }
+        if (g->Cout > 32) { if (sp == 3) MTRSSM_WG_SPLIT_LAUNCH(2, 3) else MTRSSM_WG_SPLIT_LAUNCH(2, 1) }
+        else { if (sp == 3) MTRSSM_WG_SPLIT_LAUNCH(1, 3) else MTRSSM_WG_SPLIT_LAUNCH(1, 1) }
+#undef MTRSSM_WG_SPLIT_LAUNCH
+        return launched("conv_weight_grad(split)");
+      }
+    }
     if (tiles && nq <= 4 * kMaxQ && lds <= 150 * 1024) {
       const long groups = (ptot + kGP - 1) / kGP;
       const int cotiles = g->Cout > 32 ? g->CoutPad / 64 : 1;

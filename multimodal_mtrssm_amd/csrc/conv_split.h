@@ -369,4 +369,290 @@ __global__ __launch_bounds__(kConvThreads, 3) void conv_gather_split_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient with split-bf16 operands: dWp[co][tap][c] += sum_pix A[co][pix] P[c][pos(pix) + tap].
+// Persistent, one 8-wave workgroup per CU looping over 64-pixel groups (as conv_weight_grad_patch_kernel): waves 4-7
+// stage group g+1 (global fp32 -> activation -> bf16 pieces -> LDS) while waves 0-3 run group g's MFMAs, one barrier per
+// group.  k = pixels: the A operand is a pixel-innermost image [co][64 px] read with ds_read_b128; the B operand comes
+// from the SAME channel-innermost patch image the gather kernel uses, [position][channels], through
+// ds_read_b64_tr_b16 -- the hardware transpose delivers, for a 16-lane group, 4 positions x 16 channels column-major, so
+// a lane gets 4 consecutive k of its channel and a tap is just a row offset (aligned for every tap).  An MFMA's 32
+// columns are two independent 16-channel halves (lane groups {0,2} and {1,3}) that may belong to different taps: column
+// tiles are cut from the flattened (tap, 16-channel block) list.
+// Rows of the patch image are Cp2 * 2 bytes (Cp2 = channels rounded up to a power of two >= 16); 64-byte segments of
+// 128- and 256-byte rows are XOR-swizzled with the position so that the 4 rows x 2 halves a 32-lane half reads per
+// cycle fall on distinct banks.
+// ------------------------------------------------------------------------------------------------
+using s16x4 = __attribute__((ext_vector_type(4))) short;
+constexpr int kWgLdaB = kGP * 2 + 16;  // bytes per A-image row: 64 px bf16 + 16 (odd multiple of 16: conflict-free b128)
+
+__device__ __forceinline__ unsigned wg_swz(unsigned pos, int rowb) {
+  return rowb == 128 ? ((pos >> 1) & 1u) << 6 : (rowb == 256 ? (pos & 3u) << 6 : 0u);
+}
+
+template <int NT, int SPLIT>
+__global__ __launch_bounds__(2 * kConvThreads, 2) void conv_weight_grad_split_kernel(
+    const MtrssmConvGeom g, const float* __restrict__ a, const float* __restrict__ src, const float* __restrict__ src2,
+    const int pre_act_a, float* __restrict__ dwp, float* __restrict__ dbias, const int cp2) {
+  constexpr int TCO = 32 * NT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const PatchGeom pg(g, kGP);
+  const int rowb = cp2 * 2;
+  const int a_bytes = TCO * kWgLdaB;        // one piece of the A image
+  const int p_bytes = pg.ps_raw * rowb;     // one piece of the patch image
+  const int buf_bytes = SPLIT * (a_bytes + p_bytes);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool producer = wave >= 4;
+  const int lw = wave & 3, ptid = tid & (kConvThreads - 1);
+  const int kl = lane >> 5, il = lane & 31;
+  const int taps = g.KH * g.KW;
+  const int ctot = g.C + g.C2;
+  const int nc16 = cp2 >> 4;
+  const int nhalf = taps * nc16;            // 16-column half tiles
+  const int co0 = blockIdx.y * TCO;
+  const int plane_s = g.Hs * g.Ws, plane_a = g.Hq * g.Wq;
+  const long ptot = (long)g.N * plane_a;
+  const long groups = (ptot + kGP - 1) / kGP;
+  const long gper = (groups + gridDim.x - 1) / gridDim.x;
+  const long gbeg = (long)blockIdx.x * gper;
+  const long gend = gbeg + gper < groups ? gbeg + gper : groups;
+  if (gbeg >= gend) return;  // workgroup-uniform
+
+  // group-invariant decode of the patch positions: (frame-in-group << 20) | (patch row << 10) | patch column
+  int* ptab = reinterpret_cast<int*>(lds_raw + (size_t)2 * buf_bytes);  // [nblk * 64]
+  const int nblk = (pg.ps_raw + 63) >> 6;
+  {
+    const int phw = pg.ph * pg.pw;
+    for (int pos = tid; pos < nblk * 64; pos += 2 * kConvThreads) {
+      const int ip = pos / phw, q = pos - ip * phw;
+      const int pr = q / pg.pw, pcn = q - pr * pg.pw;
+      ptab[pos] = pos < pg.ps_raw ? (ip << 20) | (pr << 10) | pcn : -1;
+    }
+  }
+  __syncthreads();
+
+  if (producer) {
+    const int noct = cp2 >> 3;
+    const int ntask = nblk * noct;  // wave-tasks: 64 positions x 8 channels
+    constexpr int RB = 4;           // wave-tasks whose loads are in flight together
+    float bsum[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) bsum[i] = 0.f;
+
+    // iteration gbeg-1 only stages group gbeg (single call site: the body is ~2k instructions)
+#pragma unroll 1
+    for (long grp = gbeg - 1; grp < gend; ++grp) {
+      if (grp + 1 < gend) {
+        const int buf = (int)((grp + 1 - gbeg) & 1);
+        unsigned char* A = lds_raw + (size_t)buf * buf_bytes;
+        unsigned char* P = A + (size_t)SPLIT * a_bytes;
+        const long p0 = (grp + 1) * kGP;
+        // ---- A tile: 2 x 16 B per task
+        float4 av[NT][2];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+          const int idx = ptid + kConvThreads * i;
+          const int row = idx >> 3, o8 = idx & 7;
+          long p = p0 + 8 * o8;
+          p = p < ptot ? p : ptot - 8;  // plane_a % 8 == 0 (host-checked): an octet never leaves its frame
+          const int n = (int)(p / plane_a);
+          const int rem = (int)(p - (long)n * plane_a);
+          const int co = co0 + row < g.Cout ? co0 + row : g.Cout - 1;
+          const float4* ap = reinterpret_cast<const float4*>(a + ((size_t)n * g.Cout + co) * plane_a + rem);
+          av[i][0] = ap[0];
+          av[i][1] = ap[1];
+        }
+        const int n0 = (int)(p0 / plane_a);
+        const int r0 = (int)((p0 - (long)n0 * plane_a) / g.Wq);
+        const int sy0 = r0 * g.SS + g.OFFY, sx0 = g.OFFX;
+        const float* src_n0 = src + (size_t)n0 * g.C * plane_s;
+        // ---- patch, RB wave-tasks at a time: loads, then conversion + stores
+#pragma unroll 1
+        for (int wb = 0; wb < ntask; wb += 4 * RB) {
+          float pv[RB][8];
+          bool okp[RB];
+          int posr[RB];
+#pragma unroll
+          for (int i = 0; i < RB; ++i) {
+            int wt = wb + lw + 4 * i;
+            wt = wt < ntask ? wt : ntask - 1;  // clamped: the surplus tasks redo the last one (same values, same address)
+            const int oct = wt / nblk, pb = wt - oct * nblk;
+            const int pos = pb * 64 + lane;
+            posr[i] = pos | (oct << 16);
+            const int d = ptab[pos];
+            const int ip = d >> 20, pr = (d >> 10) & 1023, pcn = d & 1023;
+            const int sy = sy0 + pr, sx = sx0 + pcn;
+            okp[i] = d >= 0 && n0 + ip < g.N && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
+            const unsigned f2 = okp[i] ? (unsigned)(sy * g.Ws + sx) : 0u;
+            const unsigned fo = okp[i] ? (unsigned)ip * (unsigned)(g.C * plane_s) + f2 : 0u;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              int c = oct * 8 + u;
+              c = __builtin_amdgcn_readfirstlane(c < ctot ? c : ctot - 1);
+              const bool own = c < g.C;
+              const float* bp = own ? src_n0 + (size_t)c * plane_s : src2 + (size_t)(c - g.C) * plane_s;
+              pv[i][u] = bp[own ? fo : f2];
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < RB; ++i) {
+            const int pos = posr[i] & 0xffff, oct = posr[i] >> 16;
+            float x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = (okp[i] && oct * 8 + u < ctot) ? pv[i][u] : 0.f;
+            if (g.pre_act) act_inplace<8>(x, g.act);
+            u16x8 q[SPLIT];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              unsigned short pc[SPLIT];
+              split_bf16<SPLIT>(x[u], pc);
+#pragma unroll
+              for (int s = 0; s < SPLIT; ++s) q[s][u] = pc[s];
+            }
+            const unsigned ad = (unsigned)pos * rowb + (((unsigned)oct * 16) ^ wg_swz(pos, rowb));
+            if (pos < pg.ps_raw) {
+#pragma unroll
+              for (int s = 0; s < SPLIT; ++s) *reinterpret_cast<u16x8*>(P + (size_t)s * p_bytes + ad) = q[s];
+            }
+          }
+        }
+        // ---- A tile conversion (its loads have landed under the patch work)
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+          const int idx = ptid + kConvThreads * i;
+          const int row = idx >> 3, o8 = idx & 7;
+          const bool ok = p0 + 8 * o8 < ptot && co0 + row < g.Cout;
+          float x[8] = {av[i][0].x, av[i][0].y, av[i][0].z, av[i][0].w, av[i][1].x, av[i][1].y, av[i][1].z, av[i][1].w};
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { x[u] = ok ? x[u] : 0.f; bsum[i] += x[u]; }
+          if (pre_act_a) act_inplace<8>(x, g.act);
+          u16x8 q[SPLIT];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            unsigned short pc[SPLIT];
+            split_bf16<SPLIT>(x[u], pc);
+#pragma unroll
+            for (int s = 0; s < SPLIT; ++s) q[s][u] = pc[s];
+          }
+#pragma unroll
+          for (int s = 0; s < SPLIT; ++s) *reinterpret_cast<u16x8*>(A + (size_t)s * a_bytes + row * kWgLdaB + o8 * 16) = q[s];
+        }
+      }
+      __syncthreads();
+    }
+    if (dbias != nullptr) {  // thread (row, o8): the 8 octet lanes of a row are consecutive lanes
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        float t = bsum[i];
+        t += __shfl_xor(t, 1, kWave);
+        t += __shfl_xor(t, 2, kWave);
+        t += __shfl_xor(t, 4, kWave);
+        const int row = (ptid + kConvThreads * i) >> 3;
+        if ((ptid & 7) == 0 && co0 + row < g.Cout) atomicAdd(&dbias[co0 + row], t);
+      }
+    }
+    return;
+  }
+
+  // ---- consumers: this wave's column tiles q = lw + 4 s; lane group G = lane >> 4 serves half h = G & 1, k-rows 8 (G >> 1) ..
+  const int G = lane >> 4, h = G & 1, qrow = (lane & 15) >> 2, pq = lane & 3;
+  int posq[4][2];  // patch position of pixel 16 kb + 8 (G >> 1) + 4 rd + qrow
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+      const int pix = 16 * kb + 8 * (G >> 1) + 4 * rd + qrow;
+      const int row = pix / g.Wq, ox = pix - row * g.Wq;
+      const int ip = row / pg.rp, lr = row - ip * pg.rp;
+      posq[kb][rd] = ip * pg.ph * pg.pw + lr * g.SS * pg.pw + ox * g.SS;
+    }
+  int toff[kMaxQ], cby[kMaxQ];
+  int nsl = 0;
+#pragma unroll
+  for (int s = 0; s < kMaxQ; ++s) {
+    const int q = lw + 4 * s;
+    toff[s] = 0;
+    cby[s] = pq * 8;
+    if (2 * q < nhalf) {
+      nsl = s + 1;
+      const int hf = 2 * q + h;
+      if (hf < nhalf) {
+        const int tap = hf / nc16, c16 = hf - tap * nc16;
+        const int ty = tap / g.KW, tx = tap - ty * g.KW;
+        toff[s] = ty * pg.pw + tx;
+        cby[s] = c16 * 32 + pq * 8;
+      }
+    }
+  }
+  f32x16 acc[kMaxQ][NT];
+#pragma unroll
+  for (int s = 0; s < kMaxQ; ++s)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[s][j][r] = 0.f;
+
+  __syncthreads();  // first group staged
+  int cur = 0;
+  for (long grp = gbeg; grp < gend; ++grp) {
+    const unsigned char* A = lds_raw + (size_t)cur * buf_bytes;
+    const unsigned char* P = A + (size_t)SPLIT * a_bytes;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      bf16x8 af[NT][SPLIT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int s = 0; s < SPLIT; ++s)
+          af[j][s] = *reinterpret_cast<const bf16x8*>(A + (size_t)s * a_bytes + (j * 32 + il) * kWgLdaB + kb * 32 + kl * 16);
+#pragma unroll
+      for (int sl = 0; sl < kMaxQ; ++sl) {
+        if (sl < nsl) {  // wave-uniform: EXEC stays all ones for the transposed reads
+          const unsigned p0 = (unsigned)(posq[kb][0] + toff[sl]), p1 = (unsigned)(posq[kb][1] + toff[sl]);
+          const unsigned a0 = p0 * rowb + ((unsigned)cby[sl] ^ wg_swz(p0, rowb));
+          const unsigned a1 = p1 * rowb + ((unsigned)cby[sl] ^ wg_swz(p1, rowb));
+          bf16x8 bfr[SPLIT];
+#pragma unroll
+          for (int s = 0; s < SPLIT; ++s) {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(P + (size_t)s * p_bytes + a0));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(P + (size_t)s * p_bytes + a1));
+            u16x8 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = (unsigned short)lo[e]; v[4 + e] = (unsigned short)hi[e]; }
+            bfr[s] = __builtin_bit_cast(bf16x8, v);
+          }
+#pragma unroll
+          for (int ord = SPLIT - 1; ord >= 0; --ord)
+#pragma unroll
+            for (int sa = 0; sa <= ord; ++sa)
+#pragma unroll
+              for (int j = 0; j < NT; ++j)
+                acc[sl][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[j][sa], bfr[ord - sa], acc[sl][j], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+#pragma unroll
+  for (int s = 0; s < kMaxQ; ++s) {
+    const int hf = 2 * (lw + 4 * s) + (il >> 4);  // this lane's COLUMN half (il), not its staging half
+    if (s < nsl && hf < nhalf) {
+      const int tap = hf / nc16, c16 = hf - tap * nc16;
+      const int c = c16 * 16 + (il & 15);
+      if (c < ctot) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int co = co0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
+            if (co < g.Cout) atomicAdd(&dwp[((size_t)co * taps + tap) * g.Cpad + c], acc[s][j][r]);
+          }
+      }
+    }
+  }
+}
+
 }  // namespace mtrssm
