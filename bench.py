@@ -33,6 +33,9 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16 = 16x the fp32 MFMA rate)
+# MFMA instructions issued per algorithmic multiply-add block, by conv MFMA mode (csrc/conv_split.h)
+MFMA_PRODUCTS = {"f32": 1, "bf16x3": 6, "bf16": 1}
 
 WORKLOAD = dict(batch_per_gpu=64, steps=50, deter=200, hidden=200, classes=5, cats=6, action=4, embed=256,
                 vision=(1, 64, 64), audio=(1, 128, 32))
@@ -152,6 +155,9 @@ def main() -> None:  # noqa: PLR0914, PLR0915
     ap.add_argument("--model", choices=("mrssm", "mmtrssm"), default="mrssm",
                     help="mrssm = BASELINE configs[1] (the metric's config); mmtrssm = configs[2] (MTState variant)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even for one rank (exercises the N>1 code path)")
+    ap.add_argument("--conv-mfma", choices=("bf16x3", "f32", "bf16"), default="bf16x3",
+                    help="conv MFMA operand format: bf16x3 = fp32-grade (three bf16 pieces, six products, fp32 accumulate; the mode "
+                         "the fp32 parity tests run in), f32 = fp32 MFMA, bf16 = plain bf16 operands (reduced precision: reported as dtype bf16)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -170,8 +176,10 @@ def main() -> None:  # noqa: PLR0914, PLR0915
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
 
     import multimodal_mtrssm_amd as mt
-    from multimodal_mtrssm_amd import scan
+    from multimodal_mtrssm_amd import conv, scan
     from multimodal_mtrssm_amd.optim import FlatParameters
+
+    conv.set_mfma_mode(args.conv_mfma)
 
     w = WORKLOAD
     model = build_model(device, args.model)
@@ -225,8 +233,16 @@ def main() -> None:  # noqa: PLR0914, PLR0915
         if row:
             secs = row["total_ms"] * 1e-3
             if "conv_" in name and "thin" not in name:
+                # algorithmic FLOPs (each multiply-add counted once) against the rate at which the MFMA pipe can deliver
+                # them in this operand format: fp32 MFMA 157.3 TFLOP/s; split kernels issue `products` bf16 MFMAs per
+                # algorithmic block, so their ceiling is the dense bf16 peak / products (bf16x3: 2500 / 6 = 416.7).
+                split = "split_kernel" in name
+                products = MFMA_PRODUCTS[args.conv_mfma] if split else 1
+                peak = MFMA_BF16_PEAK_TFLOPS / products if split else MFMA_F32_PEAK_TFLOPS
                 achieved = row["flops"] / secs / 1e12
-                roof.update(bound="mfma", achieved=achieved, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=achieved / MFMA_F32_PEAK_TFLOPS)
+                roof.update(bound="mfma", achieved=achieved, peak=peak, unit="TFLOP/s", frac=achieved / peak,
+                            mfma_products_per_block=products,
+                            hbm_frac=row["bytes"] / secs / 1e9 / HBM_PEAK_GBS)
             else:
                 achieved = row["bytes"] / secs / 1e9
                 roof.update(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS)
@@ -249,7 +265,7 @@ def main() -> None:  # noqa: PLR0914, PLR0915
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "bf16" if args.conv_mfma == "bf16" else "f32",
             "data": "synthetic",
             "config": {
                 "workload": ("BASELINE configs[1]: MoPoE-MRSSM train step, B=64/GPU T=50 deter=200 stoch=30, vision 1x64x64 + audio 1x128x32 + action 4"
@@ -259,6 +275,8 @@ def main() -> None:  # noqa: PLR0914, PLR0915
                 "hidden": w["hidden"], "embed": w["embed"], "categoricals_x_classes": f"{w['cats']}x{w['classes']}",
                 "enc_channels": [8, 16, 32], "dec_channels": [32, 16, 1], "residual_blocks": 3, "activation": "ELU",
                 "optimizer": "AdamW lr 1e-3 + clip 10 (fused HIP)", "params": flat.numel,
+                "conv_mfma": {"bf16x3": "fp32 operands as 3 bf16 pieces, 6 bf16-MFMA products, fp32 accumulate (fp32-grade: the mode of the parity tests)",
+                              "f32": "fp32 MFMA", "bf16": "bf16 operands, fp32 accumulate; tensors, scan, losses, optimizer fp32"}[args.conv_mfma],
             },
             "loss": float(scalars["loss"]),
             "roofline": roof,

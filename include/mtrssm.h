@@ -354,7 +354,8 @@ typedef struct MtrssmConvGeom {
   int32_t act;                  /* MTRSSM_ACT_* */
   int32_t mfma_split;           /* MFMA operand format of the patch-staged kernels: 0 = fp32 (v_mfma_f32_32x32x2_f32, exact);
                                    3 = three bf16 pieces per operand, six v_mfma_f32_32x32x16_bf16 products (fp32-grade, ~2^-24);
-                                   2 = two pieces, three products (~2^-16); 1 = plain bf16 operands.  Accumulation is fp32. */
+                                   1 = plain bf16 operands.  Accumulation is fp32.  Layers the split kernels do not cover
+                                   (thin layers, odd geometries) run the fp32 kernels whatever this says. */
 } MtrssmConvGeom;
 
 int mtrssm_conv_gather_gemm(const MtrssmConvGeom* g, const float* src, const float* src2, const float* wp, const uint16_t* wq,

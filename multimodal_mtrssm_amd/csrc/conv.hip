@@ -966,8 +966,8 @@ static int check_geom(const MtrssmConvGeom* g, const char* who) {
     set_error("%s: unknown activation id %d", who, g->act);
     return MTRSSM_EINVAL;
   }
-  if (g->mfma_split < 0 || g->mfma_split > 3) {
-    set_error("%s: mfma_split must be 0 (fp32 MFMA) or 1..3 bf16 pieces, got %d", who, g->mfma_split);
+  if (g->mfma_split != 0 && g->mfma_split != 1 && g->mfma_split != 3) {
+    set_error("%s: mfma_split must be 0 (fp32 MFMA), 1 (bf16) or 3 (three bf16 pieces), got %d", who, g->mfma_split);
     return MTRSSM_EINVAL;
   }
   return MTRSSM_OK;
@@ -1039,8 +1039,8 @@ int conv_gather_gemm_launch(const MtrssmConvGeom* g, const float* src, const flo
           if (taps % t == 0 && lds_of(t) <= 80 * 1024) tgs = t;
         const int ngroups = taps / tgs;
         const size_t lds_s = lds_of(tgs);
-        const int pit = pg.ps_raw <= 384 ? 3 : 5;
-        if (lds_s <= 80 * 1024 && pg.ps_raw <= 640 && (sp == 1 || sp == 3) && (long)pg.ipg * g->C * g->Hs * g->Ws < (1L << 31) &&
+        const int pit = pg.ps_raw <= 384 ? 3 : 6;
+        if (lds_s <= 80 * 1024 && pg.ps_raw <= 768 && (sp == 1 || sp == 3) && (long)pg.ipg * g->C * g->Hs * g->Ws < (1L << 31) &&
             (long)g->N * g->Cout * g->Ho * g->Wo < (1L << 31) && (long)sp * g->CoutPad * taps * g->Cpad < (1L << 31)) {
 #define MTRSSM_SPLIT_LAUNCH(NT_, SP_, PIT_)                                                                                     \
   {                                                                                                                             \
@@ -1055,11 +1055,11 @@ int conv_gather_gemm_launch(const MtrssmConvGeom* g, const float* src, const flo
                        bias, actgrad_in, add_in, out, tgs, ngroups);                                                            \
   }
           if (tco == 64) {
-            if (sp == 3) { if (pit == 3) MTRSSM_SPLIT_LAUNCH(2, 3, 3) else MTRSSM_SPLIT_LAUNCH(2, 3, 5) }
-            else { if (pit == 3) MTRSSM_SPLIT_LAUNCH(2, 1, 3) else MTRSSM_SPLIT_LAUNCH(2, 1, 5) }
+            if (sp == 3) { if (pit == 3) MTRSSM_SPLIT_LAUNCH(2, 3, 3) else MTRSSM_SPLIT_LAUNCH(2, 3, 6) }
+            else { if (pit == 3) MTRSSM_SPLIT_LAUNCH(2, 1, 3) else MTRSSM_SPLIT_LAUNCH(2, 1, 6) }
           } else {
-            if (sp == 3) { if (pit == 3) MTRSSM_SPLIT_LAUNCH(1, 3, 3) else MTRSSM_SPLIT_LAUNCH(1, 3, 5) }
-            else { if (pit == 3) MTRSSM_SPLIT_LAUNCH(1, 1, 3) else MTRSSM_SPLIT_LAUNCH(1, 1, 5) }
+            if (sp == 3) { if (pit == 3) MTRSSM_SPLIT_LAUNCH(1, 3, 3) else MTRSSM_SPLIT_LAUNCH(1, 3, 6) }
+            else { if (pit == 3) MTRSSM_SPLIT_LAUNCH(1, 1, 3) else MTRSSM_SPLIT_LAUNCH(1, 1, 6) }
           }
 #undef MTRSSM_SPLIT_LAUNCH
           return launched("conv_gather_gemm(split)");
@@ -1123,7 +1123,7 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
       const int nblk = (pg.ps_raw + 63) / 64;
       const size_t lds_s = 2 * (size_t)sp * ((size_t)tco_s * kWgLdaB + (size_t)pg.ps_raw * cp2 * 2) + (size_t)nblk * 64 * sizeof(int);
       if ((nhalf + 1) / 2 <= 4 * kMaxQ && pg.ps_raw < 1024 && pg.ipg < 1024 && lds_s <= 156 * 1024 &&
-          (long)pg.ipg * g->C * g->Hs * g->Ws < (1L << 31)) {
+          (long)pg.ipg * g->C * g->Hs * g->Ws < (1L << 31) && ptot < (1L << 31)) {
         const long groups = (ptot + kGP - 1) / kGP;
         const int cotiles = g->Cout > 32 ? g->CoutPad / 64 : 1;
         long splits = 256 / cotiles;

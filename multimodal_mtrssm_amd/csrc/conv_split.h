@@ -439,107 +439,145 @@ __global__ __launch_bounds__(2 * kConvThreads, 2) void conv_weight_grad_split_ke
     float bsum[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i) bsum[i] = 0.f;
+    const int igroups = (int)groups, iptot = (int)ptot;  // host checks N * Hq * Wq < 2^31
 
-    // iteration gbeg-1 only stages group gbeg (single call site: the body is ~2k instructions)
-#pragma unroll 1
-    for (long grp = gbeg - 1; grp < gend; ++grp) {
-      if (grp + 1 < gend) {
-        const int buf = (int)((grp + 1 - gbeg) & 1);
-        unsigned char* A = lds_raw + (size_t)buf * buf_bytes;
-        unsigned char* P = A + (size_t)SPLIT * a_bytes;
-        const long p0 = (grp + 1) * kGP;
-        // ---- A tile: 2 x 16 B per task
-        float4 av[NT][2];
+    // one group's staging data in registers
+    struct Regs {
+      float4 av[NT][2];
+      float pv[RB][8];
+      int posr[RB];  // pos | oct << 16 | ok << 31
+    };
+    auto load_a = [&](Regs& R, int grp) {  // A tile: 2 x 16 B per task
+      const int p0 = grp * kGP;
 #pragma unroll
-        for (int i = 0; i < NT; ++i) {
-          const int idx = ptid + kConvThreads * i;
-          const int row = idx >> 3, o8 = idx & 7;
-          long p = p0 + 8 * o8;
-          p = p < ptot ? p : ptot - 8;  // plane_a % 8 == 0 (host-checked): an octet never leaves its frame
-          const int n = (int)(p / plane_a);
-          const int rem = (int)(p - (long)n * plane_a);
-          const int co = co0 + row < g.Cout ? co0 + row : g.Cout - 1;
-          const float4* ap = reinterpret_cast<const float4*>(a + ((size_t)n * g.Cout + co) * plane_a + rem);
-          av[i][0] = ap[0];
-          av[i][1] = ap[1];
-        }
-        const int n0 = (int)(p0 / plane_a);
-        const int r0 = (int)((p0 - (long)n0 * plane_a) / g.Wq);
-        const int sy0 = r0 * g.SS + g.OFFY, sx0 = g.OFFX;
-        const float* src_n0 = src + (size_t)n0 * g.C * plane_s;
-        // ---- patch, RB wave-tasks at a time: loads, then conversion + stores
-#pragma unroll 1
-        for (int wb = 0; wb < ntask; wb += 4 * RB) {
-          float pv[RB][8];
-          bool okp[RB];
-          int posr[RB];
+      for (int i = 0; i < NT; ++i) {
+        const int idx = ptid + kConvThreads * i;
+        const int row = idx >> 3, o8 = idx & 7;
+        int p = p0 + 8 * o8;
+        p = p < iptot ? p : iptot - 8;  // plane_a % 8 == 0 (host-checked): an octet never leaves its frame
+        const int n = p / plane_a;
+        const int rem = p - n * plane_a;
+        const int co = co0 + row < g.Cout ? co0 + row : g.Cout - 1;
+        const float4* ap = reinterpret_cast<const float4*>(a + ((size_t)n * g.Cout + co) * plane_a + rem);
+        R.av[i][0] = ap[0];
+        R.av[i][1] = ap[1];
+      }
+    };
+    auto load_p = [&](Regs& R, int grp, int wb) {  // RB wave-tasks of the patch starting at wave-task wb
+      const int p0 = grp * kGP;
+      const int n0 = p0 / plane_a;
+      const int r0 = (p0 - n0 * plane_a) / g.Wq;
+      const int sy0 = r0 * g.SS + g.OFFY, sx0 = g.OFFX;
+      const float* src_n0 = src + (size_t)n0 * g.C * plane_s;
 #pragma unroll
-          for (int i = 0; i < RB; ++i) {
-            int wt = wb + lw + 4 * i;
-            wt = wt < ntask ? wt : ntask - 1;  // clamped: the surplus tasks redo the last one (same values, same address)
-            const int oct = wt / nblk, pb = wt - oct * nblk;
-            const int pos = pb * 64 + lane;
-            posr[i] = pos | (oct << 16);
-            const int d = ptab[pos];
-            const int ip = d >> 20, pr = (d >> 10) & 1023, pcn = d & 1023;
-            const int sy = sy0 + pr, sx = sx0 + pcn;
-            okp[i] = d >= 0 && n0 + ip < g.N && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
-            const unsigned f2 = okp[i] ? (unsigned)(sy * g.Ws + sx) : 0u;
-            const unsigned fo = okp[i] ? (unsigned)ip * (unsigned)(g.C * plane_s) + f2 : 0u;
+      for (int i = 0; i < RB; ++i) {
+        int wt = wb + lw + 4 * i;
+        wt = __builtin_amdgcn_readfirstlane(wt < ntask ? wt : ntask - 1);  // clamped: surplus tasks redo the last one
+        const int oct = wt / nblk, pb = wt - oct * nblk;
+        const int pos = pb * 64 + lane;
+        const int d = ptab[pos];
+        const int ip = d >> 20, pr = (d >> 10) & 1023, pcn = d & 1023;
+        const int sy = sy0 + pr, sx = sx0 + pcn;
+        const bool ok = d >= 0 && n0 + ip < g.N && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
+        R.posr[i] = pos | (oct << 16) | (ok ? (int)0x80000000 : 0);
+        const unsigned f2 = ok ? (unsigned)(sy * g.Ws + sx) : 0u;
+        const unsigned fo = ok ? (unsigned)ip * (unsigned)(g.C * plane_s) + f2 : 0u;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-              int c = oct * 8 + u;
-              c = __builtin_amdgcn_readfirstlane(c < ctot ? c : ctot - 1);
-              const bool own = c < g.C;
-              const float* bp = own ? src_n0 + (size_t)c * plane_s : src2 + (size_t)(c - g.C) * plane_s;
-              pv[i][u] = bp[own ? fo : f2];
-            }
-          }
-#pragma unroll
-          for (int i = 0; i < RB; ++i) {
-            const int pos = posr[i] & 0xffff, oct = posr[i] >> 16;
-            float x[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) x[u] = (okp[i] && oct * 8 + u < ctot) ? pv[i][u] : 0.f;
-            if (g.pre_act) act_inplace<8>(x, g.act);
-            u16x8 q[SPLIT];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-              unsigned short pc[SPLIT];
-              split_bf16<SPLIT>(x[u], pc);
-#pragma unroll
-              for (int s = 0; s < SPLIT; ++s) q[s][u] = pc[s];
-            }
-            const unsigned ad = (unsigned)pos * rowb + (((unsigned)oct * 16) ^ wg_swz(pos, rowb));
-            if (pos < pg.ps_raw) {
-#pragma unroll
-              for (int s = 0; s < SPLIT; ++s) *reinterpret_cast<u16x8*>(P + (size_t)s * p_bytes + ad) = q[s];
-            }
-          }
-        }
-        // ---- A tile conversion (its loads have landed under the patch work)
-#pragma unroll
-        for (int i = 0; i < NT; ++i) {
-          const int idx = ptid + kConvThreads * i;
-          const int row = idx >> 3, o8 = idx & 7;
-          const bool ok = p0 + 8 * o8 < ptot && co0 + row < g.Cout;
-          float x[8] = {av[i][0].x, av[i][0].y, av[i][0].z, av[i][0].w, av[i][1].x, av[i][1].y, av[i][1].z, av[i][1].w};
-#pragma unroll
-          for (int u = 0; u < 8; ++u) { x[u] = ok ? x[u] : 0.f; bsum[i] += x[u]; }
-          if (pre_act_a) act_inplace<8>(x, g.act);
-          u16x8 q[SPLIT];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            unsigned short pc[SPLIT];
-            split_bf16<SPLIT>(x[u], pc);
-#pragma unroll
-            for (int s = 0; s < SPLIT; ++s) q[s][u] = pc[s];
-          }
-#pragma unroll
-          for (int s = 0; s < SPLIT; ++s) *reinterpret_cast<u16x8*>(A + (size_t)s * a_bytes + row * kWgLdaB + o8 * 16) = q[s];
+        for (int u = 0; u < 8; ++u) {
+          int c = oct * 8 + u;
+          c = c < ctot ? c : ctot - 1;  // scalar
+          const bool own = c < g.C;
+          const float* bp = own ? src_n0 + (size_t)c * plane_s : src2 + (size_t)(c - g.C) * plane_s;
+          R.pv[i][u] = bp[own ? fo : f2];
         }
       }
-      __syncthreads();
+    };
+    auto conv_p = [&](const Regs& R, unsigned char* P) {
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        const int pos = R.posr[i] & 0xffff, oct = (R.posr[i] >> 16) & 0x7fff;
+        const bool ok = R.posr[i] < 0;
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = (ok && oct * 8 + u < ctot) ? R.pv[i][u] : 0.f;
+        if (g.pre_act) act_inplace<8>(x, g.act);
+        u16x8 q[SPLIT];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          unsigned short pc[SPLIT];
+          split_bf16<SPLIT>(x[u], pc);
+#pragma unroll
+          for (int s = 0; s < SPLIT; ++s) q[s][u] = pc[s];
+        }
+        const unsigned ad = (unsigned)pos * rowb + (((unsigned)oct * 16) ^ wg_swz(pos, rowb));
+        if (pos < pg.ps_raw) {
+#pragma unroll
+          for (int s = 0; s < SPLIT; ++s) *reinterpret_cast<u16x8*>(P + (size_t)s * p_bytes + ad) = q[s];
+        }
+      }
+    };
+    auto conv_a = [&](const Regs& R, int grp, unsigned char* A) {
+      const int p0 = grp * kGP;
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const int idx = ptid + kConvThreads * i;
+        const int row = idx >> 3, o8 = idx & 7;
+        const bool ok = p0 + 8 * o8 < iptot && co0 + row < g.Cout;
+        float x[8] = {R.av[i][0].x, R.av[i][0].y, R.av[i][0].z, R.av[i][0].w, R.av[i][1].x, R.av[i][1].y, R.av[i][1].z, R.av[i][1].w};
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { x[u] = ok ? x[u] : 0.f; bsum[i] += x[u]; }
+        if (pre_act_a) act_inplace<8>(x, g.act);
+        u16x8 q[SPLIT];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          unsigned short pc[SPLIT];
+          split_bf16<SPLIT>(x[u], pc);
+#pragma unroll
+          for (int s = 0; s < SPLIT; ++s) q[s][u] = pc[s];
+        }
+#pragma unroll
+        for (int s = 0; s < SPLIT; ++s) *reinterpret_cast<u16x8*>(A + (size_t)s * a_bytes + row * kWgLdaB + o8 * 16) = q[s];
+      }
+    };
+
+    const int ibeg = (int)gbeg, iend = (int)gend;
+    (void)igroups;
+    if (ntask <= 4 * RB) {
+      // One round per group: the loads of group k+2 are issued BEFORE group k+1 is converted, so a full group of MFMA
+      // time hides the HBM latency.  Loads are unconditional (group index clamped) so that the wait before the
+      // conversion is a counted vmcnt, not vmcnt(0).
+      Regs cur, nxt;
+      load_a(nxt, ibeg);
+      load_p(nxt, ibeg, 0);
+#pragma unroll 1
+      for (int grp = ibeg - 1; grp < iend; ++grp) {  // iteration ibeg-1 only stages group ibeg
+        if (grp + 1 < iend) {
+          cur = nxt;
+          const int g2 = grp + 2 < iend ? grp + 2 : iend - 1;
+          load_a(nxt, g2);
+          load_p(nxt, g2, 0);
+          unsigned char* A = lds_raw + (size_t)((grp + 1 - ibeg) & 1) * buf_bytes;
+          conv_p(cur, A + (size_t)SPLIT * a_bytes);
+          conv_a(cur, grp + 1, A);
+        }
+        __syncthreads();
+      }
+    } else {
+#pragma unroll 1
+      for (int grp = ibeg - 1; grp < iend; ++grp) {
+        if (grp + 1 < iend) {
+          unsigned char* A = lds_raw + (size_t)((grp + 1 - ibeg) & 1) * buf_bytes;
+          Regs R;
+          load_a(R, grp + 1);
+#pragma unroll 1
+          for (int wb = 0; wb < ntask; wb += 4 * RB) {
+            load_p(R, grp + 1, wb);
+            conv_p(R, A + (size_t)SPLIT * a_bytes);
+          }
+          conv_a(R, grp + 1, A);  // its loads have landed under the patch work
+        }
+        __syncthreads();
+      }
     }
     if (dbias != nullptr) {  // thread (row, o8): the 8 octet lanes of a row are consecutive lanes
 #pragma unroll
@@ -557,31 +595,32 @@ __global__ __launch_bounds__(2 * kConvThreads, 2) void conv_weight_grad_split_ke
 
   // ---- consumers: this wave's column tiles q = lw + 4 s; lane group G = lane >> 4 serves half h = G & 1, k-rows 8 (G >> 1) ..
   const int G = lane >> 4, h = G & 1, qrow = (lane & 15) >> 2, pq = lane & 3;
-  int posq[4][2];  // patch position of pixel 16 kb + 8 (G >> 1) + 4 rd + qrow
+  unsigned posq[4];  // packed (16 bits each): patch positions of pixels 16 kb + 8 (G >> 1) + 4 rd + qrow, rd = 0, 1
 #pragma unroll
-  for (int kb = 0; kb < 4; ++kb)
+  for (int kb = 0; kb < 4; ++kb) {
+    unsigned pk = 0;
 #pragma unroll
     for (int rd = 0; rd < 2; ++rd) {
       const int pix = 16 * kb + 8 * (G >> 1) + 4 * rd + qrow;
       const int row = pix / g.Wq, ox = pix - row * g.Wq;
       const int ip = row / pg.rp, lr = row - ip * pg.rp;
-      posq[kb][rd] = ip * pg.ph * pg.pw + lr * g.SS * pg.pw + ox * g.SS;
+      pk |= (unsigned)(ip * pg.ph * pg.pw + lr * g.SS * pg.pw + ox * g.SS) << (16 * rd);
     }
-  int toff[kMaxQ], cby[kMaxQ];
+    posq[kb] = pk;
+  }
+  unsigned tcb[kMaxQ];  // packed per column tile: tap offset in positions << 16 | channel byte offset of this lane's 4 columns
   int nsl = 0;
 #pragma unroll
   for (int s = 0; s < kMaxQ; ++s) {
     const int q = lw + 4 * s;
-    toff[s] = 0;
-    cby[s] = pq * 8;
+    tcb[s] = (unsigned)(pq * 8);
     if (2 * q < nhalf) {
       nsl = s + 1;
       const int hf = 2 * q + h;
       if (hf < nhalf) {
         const int tap = hf / nc16, c16 = hf - tap * nc16;
         const int ty = tap / g.KW, tx = tap - ty * g.KW;
-        toff[s] = ty * pg.pw + tx;
-        cby[s] = c16 * 32 + pq * 8;
+        tcb[s] = ((unsigned)(ty * pg.pw + tx) << 16) | (unsigned)(c16 * 32 + pq * 8);
       }
     }
   }
@@ -609,9 +648,12 @@ __global__ __launch_bounds__(2 * kConvThreads, 2) void conv_weight_grad_split_ke
 #pragma unroll
       for (int sl = 0; sl < kMaxQ; ++sl) {
         if (sl < nsl) {  // wave-uniform: EXEC stays all ones for the transposed reads
-          const unsigned p0 = (unsigned)(posq[kb][0] + toff[sl]), p1 = (unsigned)(posq[kb][1] + toff[sl]);
-          const unsigned a0 = p0 * rowb + ((unsigned)cby[sl] ^ wg_swz(p0, rowb));
-          const unsigned a1 = p1 * rowb + ((unsigned)cby[sl] ^ wg_swz(p1, rowb));
+          unsigned pk = posq[kb];
+          asm volatile("" : "+v"(pk));  // opaque per iteration: otherwise all 40 read addresses are hoisted out of the group loop and spill
+          const unsigned to = tcb[sl] >> 16, cb = tcb[sl] & 0xffffu;
+          const unsigned p0 = (pk & 0xffffu) + to, p1 = (pk >> 16) + to;
+          const unsigned a0 = p0 * rowb + (cb ^ wg_swz(p0, rowb));
+          const unsigned a1 = p1 * rowb + (cb ^ wg_swz(p1, rowb));
           bf16x8 bfr[SPLIT];
 #pragma unroll
           for (int s = 0; s < SPLIT; ++s) {
