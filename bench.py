@@ -146,6 +146,40 @@ def cpu_baseline(seconds_budget: float = 20.0) -> dict[str, object]:
                       f"({warm:.1f}s), {cores} torch threads"}
 
 
+def feed_benchmark(device: str, batches: int = 20) -> dict[str, object]:
+    """SURVEY section 8f-4, measured beside the train step (never part of `value`): one [64, 50, ...] 6-tuple batch per
+    iteration from an HBM-resident store of 256 synthetic episodes x 60 steps (TakeFirstN(50) + GaussianNoise(0.1) fused in
+    mtrssm_episode_gather; shuffled epoch order; normals drawn by torch.randn on the device)."""
+    from multimodal_mtrssm_amd.dataset import DeviceEpisodeLoader, _Stream
+    from multimodal_mtrssm_amd.transform import Compose, GaussianNoise, TakeFirstN
+
+    w = WORKLOAD
+    n, t_full, t, b = 256, 60, w["steps"], w["batch_per_gpu"]
+    g = torch.Generator(device=device).manual_seed(3)
+    shapes = [(w["action"],), w["audio"], w["vision"]]
+    noisy, clean = Compose([TakeFirstN(t), GaussianNoise(0.1)]), Compose([TakeFirstN(t)])
+    streams = tuple(_Stream(torch.rand(n, t_full, *sh, device=device, generator=g) * 2 - 1, noisy, clean) for sh in shapes)
+    loader = DeviceEpisodeLoader(streams, b, shuffle=True)
+    order = torch.randperm(n, device=device)
+    for i in range(3):
+        loader.batch(order[i * b % n: i * b % n + b].contiguous())
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    start.record()
+    for i in range(batches):
+        lo = (i * b) % (n - b + 1)
+        loader.batch(order[lo: lo + b].contiguous())
+    stop.record()
+    torch.cuda.synchronize()
+    ms = start.elapsed_time(stop) / batches
+    elems = b * t * sum(int(torch.tensor(sh).prod()) for sh in shapes)
+    # algorithmic bytes per batch: store read once, normals written by the generator and read once, input + target written
+    nbytes = 4.0 * elems * 5
+    return {"value": b * t / (ms * 1e-3), "unit": "seq-steps/s", "ms_per_batch": ms, "achieved_GBps": nbytes / (ms * 1e-3) / 1e9,
+            "hbm_frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "what": f"6-tuple batch B={b} T={t} from {n} HBM-resident episodes x {t_full} steps; gather + TakeFirstN + GaussianNoise fused (mtrssm_episode_gather) + torch.randn"}
+
+
 def main() -> None:  # noqa: PLR0914, PLR0915
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -281,6 +315,8 @@ def main() -> None:  # noqa: PLR0914, PLR0915
             "loss": float(scalars["loss"]),
             "roofline": roof,
         }
+        if world == 1:
+            line["data_feed"] = feed_benchmark(device)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

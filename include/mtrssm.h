@@ -379,6 +379,19 @@ int mtrssm_convt_k4s2_thin(int32_t N, int32_t C, int32_t Hs, int32_t Ws, int32_t
 int mtrssm_channel_sum(const float* x, int32_t N, int32_t C, int32_t HW, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Episode feed.  Replaces EpisodeDataset.__getitem__ + the default collate of the 6-tuple
+ * StackDataset (models/dataset.py:84-112, models/mrssm/dataset.py:155-183) for the YAML's transform chains
+ * TakeFirstN(n) [+ GaussianNoise(std)] (models/transform.py:31-72, default.yaml:176-220): from the HBM-resident store
+ * [n_episodes, Tfull, E] (fp32, already preprocessed) it writes, for the B episodes idx[0..B) (int64, device memory),
+ *   target[b, t, :] = store[idx[b], t, :]                t < T <= Tfull
+ *   input [b, t, :] = target[b, t, :] + noise[b, t, :] * std     (mul then add, each rounded: bitwise torch's expression)
+ * noise (caller-drawn standard normals [B, T, E]) may be NULL (input = target); input or target may be NULL.
+ * E % 4 == 0; every buffer 16-byte aligned.  idx values are NOT range-checked on the device.
+ * ------------------------------------------------------------------------------------------ */
+int mtrssm_episode_gather(const float* store, const int64_t* idx, const float* noise, int64_t n_episodes, int64_t B, int64_t T,
+                          int64_t Tfull, int64_t E, float std_, float* input, float* target, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Gaussian NLL with unit scale, fused reduction.  Replaces objective.likelihood
  * (objective.py:7-23) as used by compute_reconstruction_loss (mrssm/mopoe_mrssm/core.py:279-308):
  *   nll = mean_n sum_e [ 0.5 (target - pred)^2 + 0.5 log(2 pi) ],  n = B*T frames, e = C*H*W.

@@ -8,6 +8,7 @@ Importing the package does not need a GPU; running a rollout does, and fails lou
 
 from multimodal_mtrssm_amd.cnn import Decoder, Encoder
 from multimodal_mtrssm_amd.core import MoPoE_MMTRSSM, MoPoE_MRSSM
+from multimodal_mtrssm_amd.dataset import DeviceEpisodeLoader, EpisodeDataModule, EpisodeDataModuleConfig
 from multimodal_mtrssm_amd.distributions import (
     Distribution,
     MultiOneHot,
@@ -27,7 +28,7 @@ from multimodal_mtrssm_amd.state import MTState, State, cat_mtstates, cat_states
 __version__ = "0.1.0"
 
 __all__ = [
-    "MLP", "MTRNN", "Decoder", "Distribution", "Encoder", "FlatAdamW", "FlatDataParallel", "MTState", "MoPoE_MMTRSSM",
+    "MLP", "MTRNN", "Decoder", "DeviceEpisodeLoader", "Distribution", "Encoder", "EpisodeDataModule", "EpisodeDataModuleConfig", "FlatAdamW", "FlatDataParallel", "MTState", "MoPoE_MMTRSSM",
     "MoPoE_MRSSM", "MultiOneHot", "MultiOneHotFactory", "Representation", "State", "Transition", "cat_distribution",
     "cat_mtstates", "cat_states", "inject_uniforms", "kl_divergence", "likelihood", "make_mmtrssm", "make_mrssm",
     "stack_distribution", "stack_mtstates", "stack_states",

@@ -157,4 +157,53 @@ int adamw_launch(float* p, const float* g, float* m, float* v, int64_t n, const 
   return check_launch("adamw_step");
 }
 
+// ------------------------------------------------------------------------------------------------
+// Episode feed: one [B, T, E] input / target pair from the HBM-resident episode store.
+//   target[b, t, :] = store[idx[b], t, :]            (TakeFirstN: t < T <= Tfull, transform.py:31-52)
+//   input [b, t, :] = target + noise[b, t, :] * std  (GaussianNoise, transform.py:55-72: two roundings, mul then add)
+// Replaces EpisodeDataset.__getitem__ + default collate of the 6-tuple StackDataset (dataset.py:84-112,
+// mrssm/dataset.py:155-183).  One float4 per thread; rows are E floats, E % 4 == 0.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void episode_gather_kernel(
+    const float* __restrict__ store, const long* __restrict__ idx, const float* __restrict__ noise, long B, long T, long Tfull,
+    long E4, float std_, float* __restrict__ input, float* __restrict__ target) {
+#pragma clang fp contract(off)  // mul then add, each rounded (torch's `data + randn * std`): hipcc would contract to v_pk_fma_f32
+  const long per_b = T * E4;
+  const long total = B * per_b;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / per_b, r = i - b * per_b;  // r = t * E4 + e4
+    const float4 x = reinterpret_cast<const float4*>(store)[idx[b] * Tfull * E4 + r];
+    if (target) reinterpret_cast<float4*>(target)[i] = x;
+    if (input) {
+      float4 y = x;
+      if (noise) {
+        const float4 n = reinterpret_cast<const float4*>(noise)[i];
+        const float px = n.x * std_, py = n.y * std_, pz = n.z * std_, pw = n.w * std_;  // plain expressions: the pragma
+        y.x = x.x + px;                                                                  // above does not reach into the
+        y.y = x.y + py;                                                                  // headers' __fmul_rn / __fadd_rn
+        y.z = x.z + pz;
+        y.w = x.w + pw;
+      }
+      reinterpret_cast<float4*>(input)[i] = y;
+    }
+  }
+}
+
+int episode_gather_launch(const float* store, const int64_t* idx, const float* noise, int64_t n_episodes, int64_t B, int64_t T,
+                          int64_t Tfull, int64_t E, float std_, float* input, float* target, hipStream_t s) {
+  if (!store || !idx || (!input && !target) || n_episodes <= 0 || B <= 0 || T <= 0 || Tfull < T || E <= 0) {
+    set_error("episode_gather: bad argument (need 0 < T <= Tfull, B, E > 0, an output)");
+    return MTRSSM_EINVAL;
+  }
+  if (E % 4) { set_error("episode_gather: the event size %ld must be a multiple of 4 floats", (long)E); return MTRSSM_EINVAL; }
+  if (((uintptr_t)store | (uintptr_t)noise | (uintptr_t)input | (uintptr_t)target) & 15) {
+    set_error("episode_gather: buffers must be 16-byte aligned");
+    return MTRSSM_EINVAL;
+  }
+  set_last_kernel("mtrssm::episode_gather_kernel");
+  hipLaunchKernelGGL(episode_gather_kernel, dim3(grid_for(B * T * E / 4)), dim3(kThreads), 0, s, store, reinterpret_cast<const long*>(idx),
+                     noise, (long)B, (long)T, (long)Tfull, (long)(E / 4), std_, input, target);
+  return check_launch("episode_gather");
+}
+
 }  // namespace mtrssm

@@ -1,0 +1,260 @@
+"""Episode feed with the reference DataModule's surface (``multimodal_rssm/models/dataset.py``,
+``models/mrssm/dataset.py``): same config fields, same processed-file layout (``act_*.pt``, ``audio_obs_*.pt``,
+``vision_obs_*.pt``), same 80/20 split of the SORTED path lists, same 6-tuple batches
+``(action_input, audio_input, vision_input, action_target, audio_target, vision_target)`` of shape ``[B, T, ...]``.
+
+MI355X-first: the reference re-reads and re-transforms every episode file in DataLoader workers each epoch
+(``EpisodeDataset.__getitem__``: ``torch.load`` + transform; ``prefetch_factor=1``).  Here ``setup()`` loads the processed
+episodes ONCE into HBM (288 GB: a whole dataset is a few GB) as three ``[N, T, E]`` stores, and a batch is one
+``mtrssm_episode_gather`` launch per stream (index gather + ``TakeFirstN`` + ``GaussianNoise`` fused, input and target
+written in the same pass).  Nothing touches the host per step.  Differences: files are read with
+``torch.load(weights_only=True)`` (the reference unpickles); no Google-Drive download (``gdown``): missing data raises
+with the reference's hint; the noise comes from the device generator, so the random stream differs (not a parity goal:
+``GaussianNoise`` is unseeded in the reference's workers too).
+"""
+
+from __future__ import annotations
+
+from collections.abc import Iterator
+from dataclasses import dataclass
+from pathlib import Path
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from multimodal_mtrssm_amd import _lib
+from multimodal_mtrssm_amd.transform import Transform, fused_chain
+
+try:  # Lightning is optional (absent here): the module only needs prepare_data / setup / *_dataloader
+    from lightning import LightningDataModule as _Base
+except ImportError:  # pragma: no cover - depends on the environment
+    class _Base:  # noqa: D101
+        def __init__(self) -> None:
+            pass
+
+
+def load_tensor(path: Path) -> Tensor:
+    """``.npy`` or ``.pt`` tensor file (``dataset.py:44-64``), read without unpickling arbitrary objects."""
+    path = Path(path)
+    if path.suffix == ".npy":
+        return torch.Tensor(np.load(path))
+    if path.suffix == ".pt":
+        tensor = torch.load(path, weights_only=True)
+        if isinstance(tensor, Tensor):
+            return tensor
+    msg = f"Unknown file extension: {path.suffix}"
+    raise ValueError(msg)
+
+
+def split_path_list(path_list: list[Path], train_ratio: float) -> tuple[list[Path], list[Path]]:
+    """``dataset.py:67-81``."""
+    split_point = int(len(path_list) * train_ratio)
+    return path_list[:split_point], path_list[split_point:]
+
+
+def normalize_observation_shape(observations: Tensor) -> Tensor:
+    """(N,T,H,W,C) -> (N,T,C,H,W); (N,T,H,W) -> (N,T,1,H,W) (``dataset.py:239-256``)."""
+    if observations.dim() == 5:  # noqa: PLR2004
+        return observations.permute(0, 1, 4, 2, 3)
+    if observations.dim() == 4:  # noqa: PLR2004
+        return observations.unsqueeze(2)
+    return observations
+
+
+@dataclass
+class EpisodeDataModuleConfig:
+    """Fields of ``BaseEpisodeDataModuleConfig`` + the multimodal ``EpisodeDataModuleConfig`` (``dataset.py:115-128``,
+    ``mrssm/dataset.py:22-34``), plus ``data_root`` (the reference hard-codes ``Path("data")``)."""
+
+    data_name: str
+    batch_size: int
+    num_workers: int
+    gdrive_url: str
+    action_preprocess: Transform
+    action_input_transform: Transform
+    action_target_transform: Transform
+    audio_observation_file_name: str
+    vision_observation_file_name: str
+    audio_observation_preprocess: Transform
+    vision_observation_preprocess: Transform
+    audio_observation_input_transform: Transform
+    audio_observation_target_transform: Transform
+    vision_observation_input_transform: Transform
+    vision_observation_target_transform: Transform
+    data_root: Path = Path("data")
+
+    @property
+    def data_dir(self) -> Path:
+        return Path(self.data_root) / self.data_name
+
+    @property
+    def processed_data_dir(self) -> Path:
+        return Path(self.data_root) / f"processed_{self.data_name}"
+
+    def get_observation_file_names(self) -> list[str]:
+        return [self.audio_observation_file_name, self.vision_observation_file_name]
+
+    @staticmethod
+    def get_observation_glob_patterns() -> list[str]:
+        return ["audio_obs*", "vision_obs*"]
+
+    def get_effective_processed_data_dir(self, observation_patterns: list[str]) -> Path:
+        """``data/processed_data`` when it holds actions and every observation kind, else ``processed_<name>``
+        (``dataset.py:140-163``)."""
+        common = Path(self.data_root) / "processed_data"
+        if common.exists() and list(common.glob("act*")) and all(list(common.glob(p)) for p in observation_patterns):
+            return common
+        return self.processed_data_dir
+
+
+class _Stream:
+    """One HBM-resident stream ``[N, T, *event]`` + how its input / target are derived."""
+
+    def __init__(self, store: Tensor, input_transform: Transform, target_transform: Transform) -> None:
+        self.store = store.contiguous()
+        self.event_shape = tuple(store.shape[2:])
+        self.event = int(np.prod(self.event_shape)) if self.event_shape else 1
+        self.chains = (fused_chain(input_transform), fused_chain(target_transform))
+        self.transforms = (input_transform, target_transform)
+
+    def batch(self, idx: Tensor, noise: Tensor | None) -> tuple[Tensor, Tensor]:
+        """``(input, target)`` for the episodes ``idx``; fused when both chains are the YAML's and E % 4 == 0."""
+        cin, ctg = self.chains
+        n_ep, t_full = self.store.shape[:2]
+        fused = (cin is not None and ctg is not None and cin[0] == ctg[0] and ctg[1] is None and self.event % 4 == 0)
+        if not fused:  # arbitrary user transforms: applied per episode on the device tensors, then stacked
+            eps = [self.store[i] for i in idx.tolist()]
+            return (torch.stack([self.transforms[0](e) for e in eps]), torch.stack([self.transforms[1](e) for e in eps]))
+        t = t_full if cin[0] is None else min(int(cin[0]), t_full)
+        b = idx.numel()
+        std = cin[1]
+        inp = torch.empty(b, t, *self.event_shape, device=self.store.device, dtype=torch.float32)
+        tgt = torch.empty_like(inp)
+        if std is not None and noise is None:
+            noise = torch.randn(b, t, *self.event_shape, device=self.store.device, dtype=torch.float32)
+        lib = _lib.load()
+        _lib.check(_lib.TIMERS.call(
+            "mtrssm_episode_gather", lib.mtrssm_episode_gather, _lib.ptr(self.store), _lib.raw_ptr(idx), _lib.ptr(noise if std is not None else None),
+            n_ep, b, t, t_full, self.event, float(std or 0.0), _lib.ptr(inp), _lib.ptr(tgt), _lib.stream_ptr(self.store.device),
+            nbytes=4.0 * b * t * self.event * (4 if std is not None else 3)), "mtrssm_episode_gather")
+        return inp, tgt
+
+
+class DeviceEpisodeLoader:
+    """Iterable of 6-tuple batches over device-resident episodes (what ``train_dataloader`` / ``val_dataloader`` return).
+
+    ``shuffle`` draws a fresh device permutation per epoch; ``rank`` / ``world`` give each data-parallel rank a disjoint
+    slice of it (rows of one global batch, as ``FlatDataParallel.shard`` would cut them).  The last batch may be short
+    (the reference's DataLoader keeps it too)."""
+
+    def __init__(self, streams: tuple[_Stream, _Stream, _Stream], batch_size: int, *, shuffle: bool, rank: int = 0, world: int = 1) -> None:
+        self.streams = streams
+        self.batch_size = int(batch_size)
+        self.shuffle = shuffle
+        self.rank, self.world = rank, world
+        self.n = int(streams[0].store.shape[0])
+
+    def __len__(self) -> int:
+        return (self.n + self.batch_size - 1) // self.batch_size
+
+    def batch(self, idx: Tensor, noise: tuple[Tensor | None, Tensor | None, Tensor | None] = (None, None, None)) -> tuple[Tensor, ...]:
+        """The 6-tuple for episode indices ``idx`` (int64, on the device); ``noise`` injects the standard normals."""
+        pairs = [s.batch(idx, n) for s, n in zip(self.streams, noise, strict=True)]
+        return (pairs[0][0], pairs[1][0], pairs[2][0], pairs[0][1], pairs[1][1], pairs[2][1])
+
+    def __iter__(self) -> Iterator[tuple[Tensor, ...]]:
+        dev = self.streams[0].store.device
+        order = torch.randperm(self.n, device=dev) if self.shuffle else torch.arange(self.n, device=dev)
+        for lo in range(0, self.n, self.batch_size):
+            rows = order[lo: lo + self.batch_size]
+            if self.world > 1:
+                rows = rows[self.rank:: self.world]
+            if rows.numel():
+                yield self.batch(rows.contiguous())
+
+
+class EpisodeDataModule(_Base):
+    """``multimodal_rssm.models.mrssm.dataset.EpisodeDataModule`` over an HBM-resident episode store."""
+
+    def __init__(self, config: EpisodeDataModuleConfig, device: str | torch.device = "cuda", rank: int = 0, world: int = 1) -> None:
+        super().__init__()
+        self.config = config
+        self.device = torch.device(device)
+        self.rank, self.world = rank, world
+        self.train_streams: tuple[_Stream, _Stream, _Stream] | None = None
+        self.val_streams: tuple[_Stream, _Stream, _Stream] | None = None
+
+    # ---- prepare_data: raw arrays -> processed per-episode files (mrssm/dataset.py:62-153)
+    def _find_data_paths(self) -> tuple[Path, Path, Path, bool]:
+        c = self.config
+        root = Path(c.data_root)
+        cand = [(root / c.audio_observation_file_name, root / c.vision_observation_file_name, root / "joint_states.npy"),
+                (c.data_dir / c.audio_observation_file_name, c.data_dir / c.vision_observation_file_name, c.data_dir / "joint_states.npy")]
+        for a, v, j in cand:
+            if a.is_file() and v.is_file() and j.is_file():
+                return a, v, j, True
+        return (*cand[1], False)
+
+    def _is_processed_data_ready(self) -> bool:
+        d = self.config.get_effective_processed_data_dir(self.config.get_observation_glob_patterns())
+        return d.exists() and all(bool(list(d.glob(p))) for p in ("act*", "audio_obs*", "vision_obs*"))
+
+    def prepare_data(self) -> None:
+        """Writes the processed per-episode files unless they exist (``dataset.py:281-341``).  No download."""
+        if self._is_processed_data_ready():
+            return
+        c = self.config
+        audio_path, vision_path, act_path, has_local = self._find_data_paths()
+        if not has_local and not c.data_dir.exists():
+            msg = (f"no data for {c.data_name!r}: place {', '.join(c.get_observation_file_names())} and joint_states.npy in "
+                   f"{c.data_dir}, or processed act_* / audio_obs_* / vision_obs_* files in {c.processed_data_dir} "
+                   "(this build does not download from Google Drive)")
+            raise FileNotFoundError(msg)
+        c.processed_data_dir.mkdir(parents=True, exist_ok=True)
+        if has_local:
+            audio = normalize_observation_shape(load_tensor(audio_path))
+            vision = normalize_observation_shape(load_tensor(vision_path))
+            actions = load_tensor(act_path)
+            for i in range(audio.shape[0]):
+                torch.save(c.action_preprocess(actions[i]).detach().clone(), c.processed_data_dir / f"act_{i:03d}.pt")
+                torch.save(c.audio_observation_preprocess(audio[i]).detach().clone(), c.processed_data_dir / f"audio_obs_{i:03d}.pt")
+                torch.save(c.vision_observation_preprocess(vision[i]).detach().clone(), c.processed_data_dir / f"vision_obs_{i:03d}.pt")
+            return
+        for pattern, pre in (("act*", c.action_preprocess), ("audio_obs*", c.audio_observation_preprocess),
+                             ("vision_obs*", c.vision_observation_preprocess)):
+            for path in sorted(c.data_dir.glob(pattern)):
+                torch.save(pre(load_tensor(path)).detach().clone(), c.processed_data_dir / f"{path.stem}.pt")
+
+    # ---- setup: processed files -> HBM stores, 80/20 split of the sorted lists (mrssm/dataset.py:155-183)
+    def _stack(self, paths: list[Path]) -> Tensor:
+        eps = [load_tensor(p).to(torch.float32) for p in paths]
+        t = min(e.shape[0] for e in eps)  # ragged episode lengths: the common prefix (TakeFirstN cuts further)
+        return torch.stack([e[:t] for e in eps]).to(self.device)
+
+    def setup(self, stage: str = "fit") -> None:
+        c = self.config
+        d = c.get_effective_processed_data_dir(c.get_observation_glob_patterns())
+        lists = [sorted(d.glob(p)) for p in ("act*", "audio_obs*", "vision_obs*")]
+        if not all(lists) or len({len(x) for x in lists}) != 1:
+            msg = f"{d}: need the same number (> 0) of act*, audio_obs* and vision_obs* files, found {[len(x) for x in lists]}"
+            raise FileNotFoundError(msg)
+        splits = [split_path_list(x, 0.8) for x in lists]
+        tr = ((c.action_input_transform, c.action_target_transform), (c.audio_observation_input_transform, c.audio_observation_target_transform),
+              (c.vision_observation_input_transform, c.vision_observation_target_transform))
+        if stage == "fit" and splits[0][0]:
+            self.train_streams = tuple(_Stream(self._stack(s[0]), *t) for s, t in zip(splits, tr, strict=True))
+        if splits[0][1]:
+            self.val_streams = tuple(_Stream(self._stack(s[1]), *t) for s, t in zip(splits, tr, strict=True))
+
+    def train_dataloader(self) -> DeviceEpisodeLoader:
+        if self.train_streams is None:
+            msg = "train_dataset is not set. Call setup() first."
+            raise RuntimeError(msg)
+        return DeviceEpisodeLoader(self.train_streams, self.config.batch_size, shuffle=True, rank=self.rank, world=self.world)
+
+    def val_dataloader(self) -> DeviceEpisodeLoader:
+        if self.val_streams is None:
+            msg = "val_dataset is not set. Call setup() first."
+            raise RuntimeError(msg)
+        return DeviceEpisodeLoader(self.val_streams, self.config.batch_size, shuffle=False, rank=self.rank, world=self.world)
