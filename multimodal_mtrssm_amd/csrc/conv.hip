@@ -1040,7 +1040,7 @@ int conv_gather_gemm_launch(const MtrssmConvGeom* g, const float* src, const flo
         const int ngroups = taps / tgs;
         const size_t lds_s = lds_of(tgs);
         const int pit = pg.ps_raw <= 384 ? 3 : 6;
-        if (lds_s <= 80 * 1024 && pg.ps_raw <= 768 && (sp == 1 || sp == 3) && (long)pg.ipg * g->C * g->Hs * g->Ws < (1L << 31) &&
+        if (lds_s <= 80 * 1024 && pg.ps_raw <= 640 &&  /* larger patches (the k=4 s=2 backward-data gathers, 648 positions) measured faster on the fp32 kernel */ (sp == 1 || sp == 3) && (long)pg.ipg * g->C * g->Hs * g->Ws < (1L << 31) &&
             (long)g->N * g->Cout * g->Ho * g->Wo < (1L << 31) && (long)sp * g->CoutPad * taps * g->Cpad < (1L << 31)) {
 #define MTRSSM_SPLIT_LAUNCH(NT_, SP_, PIT_)                                                                                     \
   {                                                                                                                             \
@@ -1106,7 +1106,8 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
     const size_t lds_thin = ((size_t)g->Cout * kLDA + (size_t)ctot * pg.ps + kGP) * sizeof(float);
     const bool mfma_ok = nq <= 4 * kMaxQ && lds <= 150 * 1024;
     (void)mfma_ok;
-    if (tiles && n_out <= kThinOut * kConvThreads && lds_thin <= 64 * 1024) {  // thin layer: staging-bound, VALU reduction is faster
+    if (tiles && n_out <= kThinOut * kConvThreads && lds_thin <= 64 * 1024 &&
+        !((g->mfma_split == 1 || g->mfma_split == 3) && ctot >= 8 && (g->Hq * g->Wq) % 8 == 0)) {  // thin layer: staging-bound, VALU reduction is faster
       const long groups = (ptot + kGP - 1) / kGP;
       long splits = 2048;  // 8 small workgroups per CU: the kernel is staging-latency-bound, occupancy hides it
       if (splits > groups) splits = groups;
