@@ -42,6 +42,46 @@ except ImportError:  # this image: a LightningModule-shaped nn.Module
 
 Noise = dict[str, Tensor | None]
 
+# The audio and vision branches (encoders; decoders + their NLL) are independent.  Each conv kernel is a few rounds of
+# workgroup tiles with a partly empty last round, so the two branches run on two HIP streams and fill
+# each other's tails; autograd replays the backward of each branch on the stream its forward ran on.  Values are unchanged.
+BRANCH_STREAMS = True
+_SIDE_STREAMS: dict[int, torch.cuda.Stream] = {}
+
+
+def _tensors(x: object):  # noqa: ANN202
+    if isinstance(x, Tensor):
+        yield x
+    elif isinstance(x, (tuple, list)):
+        for y in x:
+            yield from _tensors(y)
+    elif isinstance(x, dict):
+        for y in x.values():
+            yield from _tensors(y)
+
+
+def fork_join(side_fn, main_fn, *inputs: Tensor):  # noqa: ANN001, ANN201
+    """``(side_fn(), main_fn())`` with ``side_fn`` on a second stream of the current device (ordered after everything
+    already enqueued on the current stream, joined before returning)."""
+    dev = next((t.device for t in inputs if t.is_cuda), None)
+    if not BRANCH_STREAMS or dev is None:
+        return side_fn(), main_fn()
+    cur = torch.cuda.current_stream(dev)
+    side = _SIDE_STREAMS.get(dev.index)
+    if side is None:
+        side = _SIDE_STREAMS[dev.index] = torch.cuda.Stream(dev)
+    side.wait_stream(cur)
+    for t in inputs:
+        if t.is_cuda:
+            t.record_stream(side)
+    with torch.cuda.stream(side):
+        a = side_fn()
+    b = main_fn()
+    cur.wait_stream(side)
+    for t in _tensors(a):
+        t.record_stream(cur)
+    return a, b
+
 
 def _st_onehot(dist: MultiOneHot, u: Tensor | None) -> Tensor:
     """Straight-through one-hot sample of ``dist`` from uniforms ``u`` (drawn on device when None)."""
@@ -119,6 +159,14 @@ class MoPoE_MRSSM(_Base):  # noqa: N801
         vision = likelihood(prediction=reconstructions["recon/vision"], target=targets["recon/vision"], event_ndims=3)
         return {"recon": audio + vision, "recon/audio": audio, "recon/vision": vision}
 
+    def _reconstruction_losses(self, feature: Tensor, targets: dict[str, Tensor]) -> dict[str, Tensor]:
+        """``decode_state`` + ``compute_reconstruction_loss`` (``mrssm core.py:262-308``), one modality per stream."""
+        audio, vision = fork_join(
+            lambda: likelihood(prediction=self.audio_decoder(feature), target=targets["recon/audio"], event_ndims=3),
+            lambda: likelihood(prediction=self.vision_decoder(feature), target=targets["recon/vision"], event_ndims=3),
+            feature, targets["recon/audio"], targets["recon/vision"])
+        return {"recon": audio + vision, "recon/audio": audio, "recon/vision": vision}
+
     # -- states ---------------------------------------------------------------------------------
     def _initial_from_embed(self, obs_embed: Tensor, u_init: Tensor | None) -> State:
         deter = self.init_proj(obs_embed)
@@ -185,14 +233,13 @@ class MoPoE_MRSSM(_Base):  # noqa: N801
         """``core.py:187-221``: ``loss = recon + kl_coeff * KL(post || prior)``."""
         action_input = batch[0]
         audio_obs, vision_obs = self.get_observations_from_batch(batch)
-        audio_embed = self.audio_encoder(audio_obs)
-        vision_embed = self.vision_encoder(vision_obs)
+        audio_embed, vision_embed = fork_join(lambda: self.audio_encoder(audio_obs), lambda: self.vision_encoder(vision_obs),
+                                              audio_obs, vision_obs)
         u_init = None if noise is None else noise.get("u_init")
         state0 = self._initial_from_embed((audio_embed[:, 0] + vision_embed[:, 0]) / 2.0, u_init)
         out = self._rollout_embedded(action_input, audio_embed, vision_embed, state0, noise, sample_prior=False)
         feature = torch.cat([out["deter"], out["post_stoch"]], dim=-1)
-        reconstructions = {"recon/audio": self.audio_decoder(feature), "recon/vision": self.vision_decoder(feature)}
-        loss_dict = self.compute_reconstruction_loss(reconstructions, self.get_targets_from_batch(batch))
+        loss_dict = self._reconstruction_losses(feature, self.get_targets_from_batch(batch))
         kl_div = out["kl"].mean().mul(self.kl_coeff)
         loss_dict["kl"] = kl_div
         loss_dict["loss"] = loss_dict["recon"] + kl_div
@@ -347,13 +394,12 @@ class MoPoE_MMTRSSM(MoPoE_MRSSM):  # noqa: N801
         """``mmtrssm core.py:563-606``: ``loss = recon + kl_coeff KL_l + kl_coeff w_kl_h KL_h``."""
         action_input = batch[0]
         audio_obs, vision_obs = self.get_observations_from_batch(batch)
-        audio_embed = self.audio_encoder(audio_obs)
-        vision_embed = self.vision_encoder(vision_obs)
+        audio_embed, vision_embed = fork_join(lambda: self.audio_encoder(audio_obs), lambda: self.vision_encoder(vision_obs),
+                                              audio_obs, vision_obs)
         state0 = self._initial_from_embed((audio_embed[:, 0] + vision_embed[:, 0]) / 2.0, noise)
         out = self._rollout_embedded(action_input, audio_embed, vision_embed, state0, noise, sample_prior=False)
         feature = torch.cat([out["deter_h"], out["post_stoch_h"], out["deter_l"], out["post_stoch_l"]], dim=-1)
-        reconstructions = {"recon/audio": self.audio_decoder(feature), "recon/vision": self.vision_decoder(feature)}
-        loss_dict = MoPoE_MRSSM.compute_reconstruction_loss(reconstructions, self.get_targets_from_batch(batch))
+        loss_dict = self._reconstruction_losses(feature, self.get_targets_from_batch(batch))
         kl_div_l = out["kl_l"].mean().mul(self.kl_coeff)
         kl_div_h = out["kl_h"].mean().mul(self.kl_coeff * self.w_kl_h)
         loss_dict["kl"] = kl_div_l
