@@ -49,6 +49,24 @@ BRANCH_STREAMS = True
 _SIDE_STREAMS: dict[int, torch.cuda.Stream] = {}
 
 
+# With two streams and the host several steps ahead of the GPU, the cross-stream waits stopped making progress on the GPU
+# (reproducible hang after 25-45 queued steps, profiles/round1_notes.md); at most MAX_INFLIGHT_STEPS shared_step calls are
+# therefore kept in flight.  The GPU never idles for it: the host needs ~14 ms per step, the GPU ~21.
+MAX_INFLIGHT_STEPS = 2
+_INFLIGHT: dict[int, list[torch.cuda.Event]] = {}
+
+
+def bound_run_ahead(dev: torch.device) -> None:
+    if not BRANCH_STREAMS or dev.type != "cuda":
+        return
+    q = _INFLIGHT.setdefault(dev.index or 0, [])
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    q.append(ev)
+    if len(q) > MAX_INFLIGHT_STEPS:
+        q.pop(0).synchronize()
+
+
 def _tensors(x: object):  # noqa: ANN202
     if isinstance(x, Tensor):
         yield x
@@ -233,6 +251,7 @@ class MoPoE_MRSSM(_Base):  # noqa: N801
         """``core.py:187-221``: ``loss = recon + kl_coeff * KL(post || prior)``."""
         action_input = batch[0]
         audio_obs, vision_obs = self.get_observations_from_batch(batch)
+        bound_run_ahead(audio_obs.device)
         audio_embed, vision_embed = fork_join(lambda: self.audio_encoder(audio_obs), lambda: self.vision_encoder(vision_obs),
                                               audio_obs, vision_obs)
         u_init = None if noise is None else noise.get("u_init")
@@ -394,6 +413,7 @@ class MoPoE_MMTRSSM(MoPoE_MRSSM):  # noqa: N801
         """``mmtrssm core.py:563-606``: ``loss = recon + kl_coeff KL_l + kl_coeff w_kl_h KL_h``."""
         action_input = batch[0]
         audio_obs, vision_obs = self.get_observations_from_batch(batch)
+        bound_run_ahead(audio_obs.device)
         audio_embed, vision_embed = fork_join(lambda: self.audio_encoder(audio_obs), lambda: self.vision_encoder(vision_obs),
                                               audio_obs, vision_obs)
         state0 = self._initial_from_embed((audio_embed[:, 0] + vision_embed[:, 0]) / 2.0, noise)
