@@ -923,15 +923,26 @@ __global__ __launch_bounds__(kConvThreads) void conv_weight_grad_thin_kernel(
 
 // per-channel sum over (N, H*W): out[c] += sum x[n, c, :]
 __global__ void channel_sum_kernel(const float* __restrict__ x, int N, int C, int HW, float* __restrict__ out) {
+  // block (c, split): frames [nbeg, nend) of channel c; 16-byte loads when the plane is a multiple of 4 floats
   __shared__ float red[4];
   const int c = blockIdx.x;
-  const long total = (long)N * HW;
-  const long per = (total + gridDim.y - 1) / gridDim.y;
-  const long beg = (long)blockIdx.y * per, end = beg + per < total ? beg + per : total;
+  const int fper = (N + gridDim.y - 1) / gridDim.y;
+  const int nbeg = blockIdx.y * fper, nend = nbeg + fper < N ? nbeg + fper : N;
   float acc = 0.f;
-  for (long i = beg + threadIdx.x; i < end; i += blockDim.x) {
-    const long n = i / HW, r = i - n * HW;
-    acc += x[((size_t)n * C + c) * HW + r];
+  if ((HW & 3) == 0 && !((uintptr_t)x & 15)) {
+    const int hw4 = HW >> 2;
+    const int quads = (nend - nbeg) * hw4;  // < 2^31: host checks N * HW
+    for (int q = threadIdx.x; q < quads; q += blockDim.x) {
+      const int n = nbeg + q / hw4, r4 = q % hw4;
+      const float4 v = reinterpret_cast<const float4*>(x + ((size_t)n * C + c) * HW)[r4];
+      acc += (v.x + v.y) + (v.z + v.w);
+    }
+  } else {
+    const int elems = (nend - nbeg) * HW;
+    for (int i = threadIdx.x; i < elems; i += blockDim.x) {
+      const int n = nbeg + i / HW, r = i % HW;
+      acc += x[((size_t)n * C + c) * HW + r];
+    }
   }
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
@@ -1202,8 +1213,11 @@ int convt_k4s2_thin_launch(int N, int C, int Hs, int Ws, int Cout, const float* 
 int channel_sum_launch(const float* x, int N, int C, int HW, float* out, hipStream_t stream) {
   if (!x || !out || N <= 0 || C <= 0 || HW <= 0) { set_error("channel_sum: bad argument"); return MTRSSM_EINVAL; }
   const long total = (long)N * HW;
-  int splits = (int)((total + 16383) / 16384);
-  if (splits > 256) splits = 256;
+  if (total >= (1L << 31)) { set_error("channel_sum: N * HW must be below 2^31"); return MTRSSM_EINVAL; }
+  int splits = (int)((total + 16383) / 16384);  // ~2048 blocks over all channels: enough loads in flight to stream from HBM
+  if (splits > 2048 / C) splits = 2048 / C;
+  if (splits > N) splits = N;
+  if (splits < 1) splits = 1;
   { set_last_kernel("mtrssm::channel_sum_kernel"); hipLaunchKernelGGL(channel_sum_kernel, dim3(C, splits), dim3(256), 0, stream, x, N, C, HW, out); }
   return launched("channel_sum");
 }
