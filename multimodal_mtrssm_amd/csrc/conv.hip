@@ -317,7 +317,7 @@ __global__ __launch_bounds__(2 * kConvThreads) void conv_weight_grad_patch_kerne
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool loader = wave >= 4;
-  const int lw = wave & 3, ltid = tid & (kConvThreads - 1);
+  const int lw = wave & 3;
   const int kl = lane >> 5, il = lane & 31;
   const int taps = g.KH * g.KW;
   const int nq = (taps * ctot + 31) / 32;
@@ -1164,10 +1164,10 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
       if (splits < 1) splits = 1;
       dim3 grid((unsigned)splits, cotiles);
       if (g->Cout > 32) {
-        if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(conv_weight_grad_patch_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_weight_grad_patch_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         { set_last_kernel("mtrssm::conv_weight_grad_patch_kernel<2>"); hipLaunchKernelGGL(conv_weight_grad_patch_kernel<2>, grid, dim3(2 * kConvThreads), lds, stream, *g, a, src, src2, pre_act_a, dwp, dbias); }
       } else {
-        if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(conv_weight_grad_patch_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_weight_grad_patch_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         { set_last_kernel("mtrssm::conv_weight_grad_patch_kernel<1>"); hipLaunchKernelGGL(conv_weight_grad_patch_kernel<1>, grid, dim3(2 * kConvThreads), lds, stream, *g, a, src, src2, pre_act_a, dwp, dbias); }
       }
       return launched("conv_weight_grad(patch)");

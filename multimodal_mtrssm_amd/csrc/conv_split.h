@@ -180,7 +180,12 @@ __global__ __launch_bounds__(kConvThreads, 3) void conv_gather_split_kernel(
   const int ctot = g.C + g.C2;
   const int plane_s = g.Hs * g.Ws, plane_q = g.Hq * g.Wq;
   const long ptot = (long)g.N * plane_q;
-  const long p0 = (long)blockIdx.x * kTP;
+  // XCD-aware tile order: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2); give every XCD
+  // a contiguous run of tiles so that neighbouring row bands of a frame (which share halo rows) meet in one L2.
+  const unsigned nb = gridDim.x, per_xcd = (nb + 7) / 8;
+  unsigned bid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if ((nb & 7) != 0) bid = blockIdx.x;  // ragged grids keep the plain order (the remap must stay a bijection)
+  const long p0 = (long)bid * kTP;
   const int co0 = blockIdx.y * TCO;
   const int n0 = (int)(p0 / plane_q);
   const int r0 = (int)((p0 - (long)n0 * plane_q) / g.Wq);
