@@ -28,7 +28,7 @@ from multimodal_mtrssm_amd.distributions import (
 from multimodal_mtrssm_amd.factory import make_mmtrssm, make_mrssm
 from multimodal_mtrssm_amd.networks import MLP, MTRNN, Representation, Transition
 from multimodal_mtrssm_amd.objective import likelihood
-from multimodal_mtrssm_amd.optim import FlatAdamW
+from multimodal_mtrssm_amd.optim import FlatAdamW, ReduceLROnPlateau, load_reference_checkpoint
 from multimodal_mtrssm_amd.parallel import FlatDataParallel
 from multimodal_mtrssm_amd.state import MTState, State, cat_mtstates, cat_states, stack_mtstates, stack_states
 
@@ -36,7 +36,7 @@ __version__ = "0.1.0"
 
 __all__ = [
     "MLP", "MTRNN", "Decoder", "DeviceEpisodeLoader", "Distribution", "Encoder", "EpisodeDataModule", "EpisodeDataModuleConfig", "FlatAdamW", "FlatDataParallel", "MTState", "MoPoE_MMTRSSM",
-    "MoPoE_MRSSM", "MultiOneHot", "MultiOneHotFactory", "Representation", "State", "Transition", "cat_distribution",
-    "cat_mtstates", "cat_states", "inject_uniforms", "kl_divergence", "likelihood", "make_mmtrssm", "make_mrssm",
+    "MoPoE_MRSSM", "MultiOneHot", "MultiOneHotFactory", "ReduceLROnPlateau", "Representation", "State", "Transition", "cat_distribution",
+    "cat_mtstates", "cat_states", "inject_uniforms", "kl_divergence", "likelihood", "load_reference_checkpoint", "make_mmtrssm", "make_mrssm",
     "stack_distribution", "stack_mtstates", "stack_states",
 ]

@@ -108,3 +108,56 @@ class FlatAdamW:
         self.exp_avg_sq.copy_(state["exp_avg_sq"])  # type: ignore[arg-type]
         self.steps = int(state["steps"])  # type: ignore[arg-type]
         self.param_groups[0]["lr"] = float(state["lr"])  # type: ignore[arg-type]
+
+
+class ReduceLROnPlateau:
+    """``torch.optim.lr_scheduler.ReduceLROnPlateau`` semantics for ``FlatAdamW`` (the reference wraps it as
+    ``lightning.pytorch.cli.ReduceLROnPlateau``: monitor ``val/loss``, mode ``min``, factor 0.5, patience 50,
+    ``default.yaml:109-114``): relative threshold 1e-4, no cooldown.  ``step(metric)`` once per validation epoch."""
+
+    def __init__(self, optimizer: FlatAdamW, mode: str = "min", factor: float = 0.1, patience: int = 10,  # noqa: PLR0913
+                 threshold: float = 1e-4, min_lr: float = 0.0, eps: float = 1e-8) -> None:
+        if mode not in {"min", "max"}:
+            msg = f"mode {mode} is unknown!"
+            raise ValueError(msg)
+        if factor >= 1.0:
+            msg = "Factor should be < 1.0."
+            raise ValueError(msg)
+        self.optimizer, self.mode, self.factor, self.patience = optimizer, mode, factor, patience
+        self.threshold, self.min_lr, self.eps = threshold, min_lr, eps
+        self.best = float("inf") if mode == "min" else -float("inf")
+        self.num_bad_epochs = 0
+
+    def _better(self, a: float) -> bool:
+        if self.mode == "min":
+            return a < self.best * (1.0 - self.threshold)
+        return a > self.best * (1.0 + self.threshold)
+
+    def step(self, metric: float | Tensor) -> None:
+        current = float(metric)
+        if self._better(current):
+            self.best = current
+            self.num_bad_epochs = 0
+        else:
+            self.num_bad_epochs += 1
+        if self.num_bad_epochs > self.patience:
+            for group in self.optimizer.param_groups:
+                old = float(group["lr"])
+                new = max(old * self.factor, self.min_lr)
+                if old - new > self.eps:
+                    group["lr"] = new
+            self.num_bad_epochs = 0
+
+
+def load_reference_checkpoint(module: nn.Module, path: str, *, strict: bool = True) -> dict[str, object]:
+    """Loads a checkpoint written by the reference's Lightning run (``{"state_dict": {...}, ...}``, SURVEY section 8b:
+    same parameter names, ``representation.*`` aliasing ``audio_representation.*``) or a bare ``state_dict`` file into
+    ``module``.  The file is read with ``weights_only=True`` (nothing in it is executed).  Returns the rest of the
+    checkpoint (epoch, optimizer states ...) for the caller."""
+    ckpt = torch.load(path, map_location="cpu", weights_only=True)
+    state = ckpt["state_dict"] if isinstance(ckpt, dict) and "state_dict" in ckpt else ckpt
+    with torch.no_grad():  # parameters may be views of a FlatParameters buffer: copy in place
+        missing, unexpected = module.load_state_dict(state, strict=strict)
+    rest = {k: v for k, v in ckpt.items() if k != "state_dict"} if isinstance(ckpt, dict) and "state_dict" in ckpt else {}
+    rest["missing_keys"], rest["unexpected_keys"] = list(missing), list(unexpected)
+    return rest

@@ -134,3 +134,47 @@ def test_encoder_decoder_share_the_oracle_architecture() -> None:
     enc = mt.Encoder(CASES["mrssm_default"].dims.enc_audio)
     with pytest.raises(mt._lib.MtrssmLibraryError, match="no CPU fallback"):  # noqa: SLF001
         enc(torch.zeros(1, 1, 32, 32))
+
+
+def test_reference_checkpoint_round_trip(tmp_path) -> None:  # noqa: ANN001
+    """A Lightning-style checkpoint ({"state_dict": ...}) written from the oracle model (the reference's parameter
+    names, checked with strict=True when the fixtures were generated) loads into the product classes, aliases included."""
+    from multimodal_mtrssm_amd.optim import load_reference_checkpoint
+
+    case = CASES["mmtrssm_default"]
+    oracle = build_model(case)
+    path = tmp_path / "last.ckpt"
+    torch.save({"state_dict": oracle.state_dict(), "epoch": 7, "global_step": 123}, path)
+    torch.manual_seed(1)
+    model = product_from_case(case, build_model(case), "cpu")
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(1.0)  # make sure the load really writes
+    rest = load_reference_checkpoint(model, str(path))
+    assert rest["epoch"] == 7 and rest["missing_keys"] == [] and rest["unexpected_keys"] == []
+    for (k, a), (_, b) in zip(model.state_dict().items(), oracle.state_dict().items(), strict=True):
+        assert torch.equal(a, b), k
+    bare = tmp_path / "weights.pt"
+    torch.save(oracle.state_dict(), bare)
+    assert load_reference_checkpoint(model, str(bare))["missing_keys"] == []
+
+
+def test_plateau_scheduler_follows_torch() -> None:
+    """optim.ReduceLROnPlateau on a FlatAdamW-like optimizer = torch's scheduler on a torch optimizer (mode min,
+    factor 0.5 as in default.yaml:109-114; a short patience so that the trace shows several reductions)."""
+    from multimodal_mtrssm_amd.optim import ReduceLROnPlateau
+
+    class _Opt:
+        param_groups = [{"lr": 1e-3}]
+
+    mine = ReduceLROnPlateau(_Opt(), mode="min", factor=0.5, patience=2)
+    w = torch.nn.Parameter(torch.zeros(1))
+    ref_opt = torch.optim.AdamW([w], lr=1e-3)
+    ref = torch.optim.lr_scheduler.ReduceLROnPlateau(ref_opt, mode="min", factor=0.5, patience=2)
+    g = torch.Generator().manual_seed(0)
+    trace = [5.0, 4.0, 4.0, 4.0, 4.0, 3.9999, 3.0, 3.1, 3.2, 3.3, 3.4, 3.5, 3.6, 2.0] + (3 + torch.rand(20, generator=g)).tolist()
+    for v in trace:
+        mine.step(v)
+        ref.step(v)
+        assert mine.optimizer.param_groups[0]["lr"] == pytest.approx(ref_opt.param_groups[0]["lr"], rel=1e-12)
+    assert mine.optimizer.param_groups[0]["lr"] < 1e-3
