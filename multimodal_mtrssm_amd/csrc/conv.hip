@@ -1133,7 +1133,10 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
       const int nhalf = taps * (cp2 / 16);
       const int tco_s = g->Cout > 32 ? 64 : 32;
       const int nblk = (pg.ps_raw + 63) / 64;
-      const size_t lds_s = 2 * (size_t)sp * ((size_t)tco_s * kWgLdaB + (size_t)pg.ps_raw * cp2 * 2) + (size_t)nblk * 64 * sizeof(int);
+      const size_t lds_1 = (size_t)sp * ((size_t)tco_s * kWgLdaB + (size_t)pg.ps_raw * cp2 * 2);
+      // double-buffered when it fits; a single buffer (stage / compute alternate) for big multi-round patches
+      const int nbuf = 2 * lds_1 + (size_t)nblk * 64 * sizeof(int) <= 156 * 1024 || nblk * (cp2 / 8) <= 16 ? 2 : 1;
+      const size_t lds_s = nbuf * lds_1 + (size_t)nblk * 64 * sizeof(int);
       if ((nhalf + 1) / 2 <= 4 * kMaxQ && pg.ps_raw < 1024 && pg.ipg < 1024 && lds_s <= 156 * 1024 &&
           (long)pg.ipg * g->C * g->Hs * g->Ws < (1L << 31) && ptot < (1L << 31)) {
         const long groups = (ptot + kGP - 1) / kGP;
@@ -1148,7 +1151,7 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
                               hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);                                          \
     set_last_kernel("mtrssm::conv_weight_grad_split_kernel<" #NT_ ", " #SP_ ">");                                                \
     hipLaunchKernelGGL((conv_weight_grad_split_kernel<NT_, SP_>), grid, dim3(2 * kConvThreads), lds_s, stream, *g, a, src, src2, \
-                       pre_act_a, dwp, dbias, cp2);                                                                             \
+                       pre_act_a, dwp, dbias, cp2, nbuf);                                                                             \
   }
         if (g->Cout > 32) { if (sp == 3) MTRSSM_WG_SPLIT_LAUNCH(2, 3) else MTRSSM_WG_SPLIT_LAUNCH(2, 1) }
         else { if (sp == 3) MTRSSM_WG_SPLIT_LAUNCH(1, 3) else MTRSSM_WG_SPLIT_LAUNCH(1, 1) }

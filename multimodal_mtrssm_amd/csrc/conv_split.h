@@ -398,7 +398,7 @@ __device__ __forceinline__ unsigned wg_swz(unsigned pos, int rowb) {
 template <int NT, int SPLIT>
 __global__ __launch_bounds__(2 * kConvThreads, 2) void conv_weight_grad_split_kernel(
     const MtrssmConvGeom g, const float* __restrict__ a, const float* __restrict__ src, const float* __restrict__ src2,
-    const int pre_act_a, float* __restrict__ dwp, float* __restrict__ dbias, const int cp2) {
+    const int pre_act_a, float* __restrict__ dwp, float* __restrict__ dbias, const int cp2, const int nbuf) {
   constexpr int TCO = 32 * NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const PatchGeom pg(g, kGP);
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(2 * kConvThreads, 2) void conv_weight_grad_split_ke
   if (gbeg >= gend) return;  // workgroup-uniform
 
   // group-invariant decode of the patch positions: (frame-in-group << 20) | (patch row << 10) | patch column
-  int* ptab = reinterpret_cast<int*>(lds_raw + (size_t)2 * buf_bytes);  // [nblk * 64]
+  int* ptab = reinterpret_cast<int*>(lds_raw + (size_t)nbuf * buf_bytes);  // [nblk * 64]
   const int nblk = (pg.ps_raw + 63) >> 6;
   {
     const int phw = pg.ph * pg.pw;
@@ -568,10 +568,12 @@ __global__ __launch_bounds__(2 * kConvThreads, 2) void conv_weight_grad_split_ke
         __syncthreads();
       }
     } else {
+      // nbuf == 1 (images too big to double-buffer: the k=4 s=2 decoder layers in three pieces): stage, barrier, the
+      // consumers compute, barrier -- no overlap, still faster than the fp32 kernel.
 #pragma unroll 1
       for (int grp = ibeg - 1; grp < iend; ++grp) {
         if (grp + 1 < iend) {
-          unsigned char* A = lds_raw + (size_t)((grp + 1 - ibeg) & 1) * buf_bytes;
+          unsigned char* A = lds_raw + (size_t)(nbuf == 2 ? (grp + 1 - ibeg) & 1 : 0) * buf_bytes;
           Regs R;
           load_a(R, grp + 1);
 #pragma unroll 1
@@ -582,6 +584,7 @@ __global__ __launch_bounds__(2 * kConvThreads, 2) void conv_weight_grad_split_ke
           conv_a(R, grp + 1, A);  // its loads have landed under the patch work
         }
         __syncthreads();
+        if (nbuf == 1 && grp + 1 < iend) __syncthreads();  // the consumers are done with the only buffer
       }
     }
     if (dbias != nullptr) {  // thread (row, o8): the 8 octet lanes of a row are consecutive lanes
@@ -680,7 +683,8 @@ __global__ __launch_bounds__(2 * kConvThreads, 2) void conv_weight_grad_split_ke
       }
     }
     __syncthreads();
-    cur ^= 1;
+    if (nbuf == 2) cur ^= 1;
+    else if (grp + 1 < gend) __syncthreads();  // single buffer: wait for the next group to be staged
   }
 
 #pragma unroll
