@@ -232,16 +232,12 @@ def main() -> None:  # noqa: PLR0914, PLR0915
     batch = synthetic_batch(b, device, seed=1000 + rank)  # each rank owns its own 64 sequences (weak scaling)
     torch.manual_seed(7 + rank)
 
-    host = {"sync_s": 0.0}
-
     def train_step() -> dict[str, torch.Tensor]:
         noise = None  # uniforms are drawn on the device inside shared_step (torch.rand), as in training
         opt.zero_grad()
         out = model.shared_step(batch, noise)
         out["loss"].backward()
-        t_sync = time.perf_counter()
         scalars = dp.sync({k: out[k] for k in out})
-        host["sync_s"] += time.perf_counter() - t_sync
         opt.step(grad_scale=dp.grad_scale)
         return scalars
 
@@ -252,31 +248,36 @@ def main() -> None:  # noqa: PLR0914, PLR0915
 
     for _ in range(args.warmup):
         train_step()
-    scan.KERNEL_TIMERS.enable()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         scalars = train_step()
-    enqueue_s = time.perf_counter() - t0  # host time to enqueue the steps (the GPU may still be running)
     barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms = scan.KERNEL_TIMERS.summary()
-    scan.KERNEL_TIMERS.disable()
-    # Outside the timed region: the same step with the two modality branches on ONE stream.  A stream's events bracket
-    # "previous work of this stream done" .. "kernel done": with two streams that includes the time the kernel waits for
-    # the other stream's kernel to leave room, and does not agree with rocprofv3's begin..end of the kernel.  On one stream
-    # it is the kernel's own duration (and agrees with rocprofv3 of `bench.py --single-stream`, profiles/).
+    # Kernel durations, right AFTER the timed region (HIP events around every launch cost the step ~3 %, and with two
+    # streams a stream's events bracket "previous work of this stream done" .. "kernel done", which includes the wait for
+    # the other stream's kernel to leave room and is not rocprofv3's begin..end of the kernel):
+    #   pass A, 3 steps as timed (two streams when enabled) -> `two_stream_event_avg_us`;
+    #   pass B, 3 steps with the two modality branches on ONE stream -> a kernel's own duration: the `roofline` figures
+    #   (agrees with rocprofv3 --kernel-trace --stats of `bench.py --single-stream`, profiles/).
+    kernel_ms: dict[str, dict[str, float]] = {}
     serial_ms: dict[str, dict[str, float]] = {}
-    if _core.BRANCH_STREAMS and rank == 0:
-        _core.BRANCH_STREAMS = False
-        train_step()
-        scan.KERNEL_TIMERS.enable()
-        for _ in range(3):
+    if rank == 0:
+        def timed_pass() -> dict[str, dict[str, float]]:
+            scan.KERNEL_TIMERS.enable()
+            for _ in range(3):
+                train_step()
+            torch.cuda.synchronize()
+            out = scan.KERNEL_TIMERS.summary()
+            scan.KERNEL_TIMERS.disable()
+            return out
+
+        kernel_ms = timed_pass()
+        if _core.BRANCH_STREAMS:
+            _core.BRANCH_STREAMS = False
             train_step()
-        torch.cuda.synchronize()
-        serial_ms = scan.KERNEL_TIMERS.summary()
-        scan.KERNEL_TIMERS.disable()
-        _core.BRANCH_STREAMS = True
+            serial_ms = timed_pass()
+            _core.BRANCH_STREAMS = True
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -291,7 +292,7 @@ def main() -> None:  # noqa: PLR0914, PLR0915
         # priced against HBM.
         name, row_timed = max(kernel_ms.items(), key=lambda kv: kv[1]["total_ms"]) if kernel_ms else ("none", None)
         row = serial_ms.get(name, row_timed)  # the kernel's own duration (one stream) when the timed region used two
-        n_steps = 3 if name in serial_ms else args.steps
+        n_steps = 3
         roof: dict[str, object] = {"kernel": name}
         if row:
             secs = row["total_ms"] * 1e-3
@@ -315,13 +316,14 @@ def main() -> None:  # noqa: PLR0914, PLR0915
                         share_of_step=row["total_ms"] / n_steps / ms)
             if name in serial_ms:
                 roof["measured"] = ("kernel duration by HIP events on ONE stream, 3 steps right after the timed region (agrees with "
-                                    "rocprofv3 of `bench.py --single-stream`); the timed region runs the audio / vision branches on two "
-                                    "streams, where a stream's events also count the wait behind the other stream's kernel")
+                                    "rocprofv3 of `bench.py --single-stream`); the timed region itself carries no events (they cost ~3 %) "
+                                    "and runs the audio / vision branches on two streams, where a stream's events would also count the "
+                                    "wait behind the other stream's kernel (two_stream_event_avg_us, 3 more steps)")
                 roof["two_stream_event_avg_us"] = row_timed["avg_ms"] * 1e3
-        roof["kernels"] = {k: {"launches_per_step": v["launches"] / args.steps, "avg_us": round(v["avg_ms"] * 1e3, 1),
-                               "ms_per_step": round(v["total_ms"] / args.steps, 3),
+        roof["kernels"] = {k: {"launches_per_step": v["launches"] / 3, "avg_us": round(v["avg_ms"] * 1e3, 1),
+                               "ms_per_step": round(v["total_ms"] / 3, 3),
                                "tflops": round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 2) if v["total_ms"] else None}
-                           for k, v in sorted(kernel_ms.items(), key=lambda kv: -kv[1]["total_ms"])}
+                           for k, v in sorted((serial_ms or kernel_ms).items(), key=lambda kv: -kv[1]["total_ms"])}
         line = {
             "metric": "seq-steps/s (BxT) MoPoE-MRSSM train step" if args.model == "mrssm" else "seq-steps/s (BxT) MoPoE-MMTRSSM train step",
             "value": seq_steps / (elapsed / args.steps),
@@ -330,8 +332,6 @@ def main() -> None:  # noqa: PLR0914, PLR0915
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms,
-            "host_enqueue_ms_per_step": enqueue_s / args.steps * 1e3,
-            "host_in_sync_ms_per_step": host["sync_s"] / (args.steps + args.warmup + (4 if serial_ms else 0)) * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
