@@ -695,7 +695,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_gather_thin_kernel(
       const float* wk = w_lds + (size_t)(ty * g.KW + tx) * ctot * COT;
       for (int c = 0; c < ctot; ++c) {
         float v = c < g.C ? src_n[(size_t)c * plane_s + off] : src2[(size_t)(c - g.C) * plane_s + off];
-        if (g.pre_act) v = act_fwd(v, g.act);
+        if (g.pre_act) v = g.act == MTRSSM_ACT_ELU ? elu_fast(v) : act_fwd(v, g.act);
 #pragma unroll
         for (int j = 0; j < COT; ++j) acc[j] = fmaf(v, wk[c * COT + j], acc[j]);
       }
@@ -703,16 +703,35 @@ __global__ __launch_bounds__(kConvThreads) void conv_gather_thin_kernel(
   }
   const size_t plane_o = (size_t)g.Ho * g.Wo;
   const size_t base = (size_t)n * g.Cout * plane_o + (size_t)(oy * g.OS + g.QY) * g.Wo + (ox * g.OS + g.QX);
+  // epilogue: all loads first (clamped channel, no branch around a load), then arithmetic, then stores -- "load, wait,
+  // use" per channel serialised COT dependent round trips per thread
+  float gv[COT], av[COT];
 #pragma unroll
   for (int j = 0; j < COT; ++j) {
-    if (j < g.Cout) {
-      const size_t o = base + (size_t)j * plane_o;
-      float v = acc[j];
-      if (actgrad_in) v *= act_grad_from_in(actgrad_in[o], g.act);
-      if (add_in) v += add_in[o];
-      out[o] = v;
+    const size_t o = base + (size_t)(j < g.Cout ? j : g.Cout - 1) * plane_o;
+    gv[j] = actgrad_in ? actgrad_in[o] : 0.f;
+    av[j] = add_in ? add_in[o] : 0.f;
+  }
+  if (actgrad_in) {
+    if (g.act == MTRSSM_ACT_ELU) {
+#pragma unroll
+      for (int j = 0; j < COT; ++j) gv[j] = gv[j] > 0.f ? 1.f : __expf(gv[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < COT; ++j) gv[j] = act_grad_from_in(gv[j], g.act);
     }
   }
+#pragma unroll
+  for (int j = 0; j < COT; ++j) {
+    float v = acc[j];
+    if (actgrad_in) v *= gv[j];
+    if (add_in) v += av[j];
+    asm volatile("" : "+v"(v));
+    acc[j] = v;
+  }
+#pragma unroll
+  for (int j = 0; j < COT; ++j)
+    if (j < g.Cout) out[base + (size_t)j * plane_o] = acc[j];
 }
 
 // ------------------------------------------------------------------------------------------------
