@@ -813,9 +813,10 @@ __global__ __launch_bounds__(kConvThreads) void conv_weight_grad_thin_kernel(
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const PatchGeom pg(g, kGP);
   const int ctot = g.C + g.C2;
-  float* a_lds = lds;                                   // [Cout][kLDA]
-  float* patch = a_lds + (size_t)g.Cout * kLDA;         // [ctot][ps]
-  int* pixtab = reinterpret_cast<int*>(patch + (size_t)ctot * pg.ps);
+  // two staging buffers [Cout][kLDA] + [ctot][ps]: the LDS-DMA of group g+1 flies while group g is reduced
+  const int buf_floats = g.Cout * kLDA + ctot * pg.ps;
+  int* pixtab = reinterpret_cast<int*>(lds + 2 * (size_t)buf_floats);  // [kGP]
+  int* ptab = pixtab + kGP;  // [ps_raw rounded up to 64]: group-invariant decode (frame << 20 | patch row << 10 | patch column)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int taps = g.KH * g.KW;
   const int n_out = g.Cout * taps * ctot;
@@ -830,6 +831,16 @@ __global__ __launch_bounds__(kConvThreads) void conv_weight_grad_thin_kernel(
     const int ip = row / pg.rp, lr = row - ip * pg.rp;
     pixtab[tid] = ip * pg.ph * pg.pw + lr * g.SS * pg.pw + ox * g.SS;
   }
+  {
+    const int phw = pg.ph * pg.pw;
+    for (int r = tid; r < ((pg.ps_raw + 63) & ~63); r += kConvThreads) {
+      const int ip = r / phw, q = r - ip * phw;
+      const int pr = q / pg.pw, pcn = q - pr * pg.pw;
+      ptab[r] = r < pg.ps_raw ? (ip << 20) | (pr << 10) | pcn : -1;
+    }
+  }
+  __syncthreads();
+  const int iptot = (int)ptot;  // host checks N * Hq * Wq < 2^31
   int arow[kThinOut], pbase[kThinOut];
   float acc[kThinOut];
 #pragma unroll
@@ -851,15 +862,13 @@ __global__ __launch_bounds__(kConvThreads) void conv_weight_grad_thin_kernel(
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)ldst, 4, 0, 0);
   };
-  for (long grp = gbeg; grp < gend; ++grp) {
-    const long p0 = grp * kGP;
-    // staging by LDS-DMA: every row load of the group is in flight at once (the register-staged loop paid one memory
-    // round trip per row: 6 us per 64-pixel group on the first encoder layer)
+  auto stage = [&](long grp, float* a_lds, float* patch) {
+    const int p0 = (int)grp * kGP;
     {
-      const long p = p0 + lane;
-      const bool pv = p < ptot;
+      const int p = p0 + lane;
+      const bool pv = p < iptot;
       int n = 0, rem = 0;
-      if (pv) { n = (int)(p / plane_a); rem = (int)(p - (long)n * plane_a); }
+      if (pv) { n = p / plane_a; rem = p - n * plane_a; }
       const float* a_n = a + (size_t)n * g.Cout * plane_a + rem;
       for (int row = wave; row < g.Cout; row += 4) {
         float* dst = a_lds + row * kLDA;
@@ -868,16 +877,13 @@ __global__ __launch_bounds__(kConvThreads) void conv_weight_grad_thin_kernel(
       }
     }
     {
-      const int n0 = (int)(p0 / plane_a);
-      const int r0 = (int)((p0 - (long)n0 * plane_a) / g.Wq);
+      const int n0 = p0 / plane_a;
+      const int r0 = (p0 - n0 * plane_a) / g.Wq;
       const int sy0 = r0 * g.SS + g.OFFY, sx0 = g.OFFX;
-      const int phw = pg.ph * pg.pw;
       for (int rb = 0; rb < pg.ps_raw; rb += 64) {
-        const int r = rb + lane;
-        const bool rv = r < pg.ps_raw;
-        const int ip = r / phw, q = r - ip * phw;
-        const int pr = q / pg.pw, pcn = q - pr * pg.pw;
-        const int n = n0 + ip, sy = sy0 + pr, sx = sx0 + pcn;
+        const int d = ptab[rb + lane];
+        const bool rv = d >= 0;
+        const int n = n0 + (d >> 20), sy = sy0 + ((d >> 10) & 1023), sx = sx0 + (d & 1023);
         const bool ok = rv && n < g.N && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
         const size_t off = (size_t)sy * g.Ws + sx;
         const float* s_n = src + (size_t)n * g.C * plane_s + off;
@@ -888,26 +894,32 @@ __global__ __launch_bounds__(kConvThreads) void conv_weight_grad_thin_kernel(
         }
       }
     }
-    if (g.pre_act || pre_act_a) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (pre_act_a) {
-        for (int row = wave; row < g.Cout; row += 4) {
-          float* d = a_lds + row * kLDA + lane;
-          *d = act_fwd(*d, g.act);
-        }
+  };
+  // LDS-DMA staging (every row load of a group in flight at once), double-buffered: one barrier per group.
+  if (gbeg < gend) stage(gbeg, lds, lds + (size_t)g.Cout * kLDA);
+  int cur = 0;
+  for (long grp = gbeg; grp < gend; ++grp) {
+    float* a_lds = lds + (size_t)cur * buf_floats;
+    float* patch = a_lds + (size_t)g.Cout * kLDA;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of group grp has landed
+    if (pre_act_a) {  // in place, each wave its own rows
+      for (int row = wave; row < g.Cout; row += 4) {
+        float* d = a_lds + row * kLDA + lane;
+        *d = act_fwd(*d, g.act);
       }
-      if (g.pre_act) {
-        for (int rb = 0; rb < pg.ps_raw; rb += 64) {
-          if (rb + lane < pg.ps_raw) {
-            for (int c = wave; c < ctot; c += 4) {
-              float* d = patch + c * pg.ps + rb + lane;
-              *d = act_fwd(*d, g.act);
-            }
+    }
+    if (g.pre_act) {
+      for (int rb = 0; rb < pg.ps_raw; rb += 64) {
+        if (rb + lane < pg.ps_raw) {
+          for (int c = wave; c < ctot; c += 4) {
+            float* d = patch + c * pg.ps + rb + lane;
+            *d = act_fwd(*d, g.act);
           }
         }
       }
     }
-    __syncthreads();
+    __syncthreads();  // group grp complete in `cur`; every wave is done reducing group grp-1 from the other buffer
+    if (grp + 1 < gend) stage(grp + 1, lds + (size_t)(cur ^ 1) * buf_floats, lds + (size_t)(cur ^ 1) * buf_floats + (size_t)g.Cout * kLDA);
     if (dbias && tid < g.Cout) {
       const float* ar = a_lds + tid * kLDA;
       float t = 0.f;
@@ -926,7 +938,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_weight_grad_thin_kernel(
         acc[s] += t;
       }
     }
-    __syncthreads();
+    cur ^= 1;
   }
 #pragma unroll
   for (int s = 0; s < kThinOut; ++s) {
@@ -1133,10 +1145,10 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
     const int tco = g->Cout > 32 ? 64 : 32;
     const size_t lds = (2 * ((size_t)tco * kLDA + (size_t)ctot * pg.ps) + kGP) * sizeof(float);
     const int n_out = g->Cout * taps * ctot;
-    const size_t lds_thin = ((size_t)g->Cout * kLDA + (size_t)ctot * pg.ps + kGP) * sizeof(float);
+    const size_t lds_thin = (2 * ((size_t)g->Cout * kLDA + (size_t)ctot * pg.ps) + kGP + ((pg.ps_raw + 63) & ~63)) * sizeof(float);
     const bool mfma_ok = nq <= 4 * kMaxQ && lds <= 150 * 1024;
     (void)mfma_ok;
-    if (tiles && n_out <= kThinOut * kConvThreads && lds_thin <= 64 * 1024 &&
+    if (tiles && n_out <= kThinOut * kConvThreads && lds_thin <= 64 * 1024 && ptot < (1L << 31) && pg.ps_raw < 1024 && pg.ipg < 1024 &&
         !((g->mfma_split == 1 || g->mfma_split == 3) && ctot >= 8 && (g->Hq * g->Wq) % 8 == 0)) {  // thin layer: staging-bound, VALU reduction is faster
       const long groups = (ptot + kGP - 1) / kGP;
       long splits = 2048;  // 8 small workgroups per CU: the kernel is staging-latency-bound, occupancy hides it
