@@ -414,6 +414,34 @@ def test_encoder_decoder_match_oracle(name: str, fp32_grade_mode: str, lib_loade
         np.testing.assert_allclose(_np(mine(xg[:, 0])), _np(yg[:, 0]), rtol=1e-5, atol=1e-6)
 
 
+def test_two_stream_branches_change_nothing(lib_loaded: None) -> None:
+    """core.fork_join (audio / vision encoders and decoders on two HIP streams, the default) against the same step on one
+    stream: the same losses and gradients up to the arrival order of fp32 atomics (NLL reduction, weight-gradient kernels)."""
+    from multimodal_mtrssm_amd import core
+
+    case = CASES["mrssm_default"]
+    fx = load_golden("mrssm_default")
+    batch, noise = tuple(b.to(DEV) for b in golden_batch(fx)), _to(golden_noise(fx), DEV)
+    runs = {}
+    for two in (False, True):
+        core.BRANCH_STREAMS = two
+        try:
+            model = product_from_case(case, build_model(case), DEV)
+            for _ in range(4):  # more calls than core.MAX_INFLIGHT_STEPS: the run-ahead bound is exercised too
+                model.zero_grad(set_to_none=True)
+                out = model.shared_step(batch, noise)
+                out["loss"].backward()
+            torch.cuda.synchronize()
+            runs[two] = ({k: float(v) for k, v in out.items()}, {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+        finally:
+            core.BRANCH_STREAMS = True
+    for k, v in runs[False][0].items():  # the NLL reduction uses fp32 atomics: equal up to their arrival order
+        np.testing.assert_allclose(runs[True][0][k], v, rtol=2e-6, err_msg=k)
+    for k, g in runs[False][1].items():
+        scale = float(g.abs().max()) + 1e-12
+        np.testing.assert_allclose(_np(runs[True][1][k]), _np(g), rtol=1e-5, atol=2e-6 * scale, err_msg=k)
+
+
 def test_fp32_mfma_mode_train_step_matches_golden(lib_loaded: None) -> None:
     """The whole train step with the fp32 MFMA conv kernels ("f32" mode; every other GPU test of the step runs in the
     default "bf16x3" mode): same golden losses, same tolerance."""
