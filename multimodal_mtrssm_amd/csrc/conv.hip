@@ -1008,8 +1008,8 @@ static int check_geom(const MtrssmConvGeom* g, const char* who) {
     set_error("%s: unknown activation id %d", who, g->act);
     return MTRSSM_EINVAL;
   }
-  if (g->mfma_split != 0 && g->mfma_split != 1 && g->mfma_split != 3) {
-    set_error("%s: mfma_split must be 0 (fp32 MFMA), 1 (bf16) or 3 (three bf16 pieces), got %d", who, g->mfma_split);
+  if (g->mfma_split < 0 || g->mfma_split > 3) {
+    set_error("%s: mfma_split must be 0 (fp32 MFMA) or 1..3 bf16 pieces, got %d", who, g->mfma_split);
     return MTRSSM_EINVAL;
   }
   return MTRSSM_OK;
@@ -1082,7 +1082,7 @@ int conv_gather_gemm_launch(const MtrssmConvGeom* g, const float* src, const flo
         const int ngroups = taps / tgs;
         const size_t lds_s = lds_of(tgs);
         const int pit = pg.ps_raw <= 384 ? 3 : 6;
-        if (lds_s <= 80 * 1024 && pg.ps_raw <= 640 &&  /* larger patches (the k=4 s=2 backward-data gathers, 648 positions) measured faster on the fp32 kernel */ (sp == 1 || sp == 3) && (long)pg.ipg * g->C * g->Hs * g->Ws < (1L << 31) &&
+        if (lds_s <= 80 * 1024 && pg.ps_raw <= 640 &&  /* larger patches (the k=4 s=2 backward-data gathers, 648 positions) measured faster on the fp32 kernel */ (sp >= 1 && sp <= 3) && (long)pg.ipg * g->C * g->Hs * g->Ws < (1L << 31) &&
             (long)g->N * g->Cout * g->Ho * g->Wo < (1L << 31) && (long)sp * g->CoutPad * taps * g->Cpad < (1L << 31)) {
 #define MTRSSM_SPLIT_LAUNCH(NT_, SP_, PIT_)                                                                                     \
   {                                                                                                                             \
@@ -1098,9 +1098,11 @@ int conv_gather_gemm_launch(const MtrssmConvGeom* g, const float* src, const flo
   }
           if (tco == 64) {
             if (sp == 3) { if (pit == 3) MTRSSM_SPLIT_LAUNCH(2, 3, 3) else MTRSSM_SPLIT_LAUNCH(2, 3, 6) }
+            else if (sp == 2) { if (pit == 3) MTRSSM_SPLIT_LAUNCH(2, 2, 3) else MTRSSM_SPLIT_LAUNCH(2, 2, 6) }
             else { if (pit == 3) MTRSSM_SPLIT_LAUNCH(2, 1, 3) else MTRSSM_SPLIT_LAUNCH(2, 1, 6) }
           } else {
             if (sp == 3) { if (pit == 3) MTRSSM_SPLIT_LAUNCH(1, 3, 3) else MTRSSM_SPLIT_LAUNCH(1, 3, 6) }
+            else if (sp == 2) { if (pit == 3) MTRSSM_SPLIT_LAUNCH(1, 2, 3) else MTRSSM_SPLIT_LAUNCH(1, 2, 6) }
             else { if (pit == 3) MTRSSM_SPLIT_LAUNCH(1, 1, 3) else MTRSSM_SPLIT_LAUNCH(1, 1, 6) }
           }
 #undef MTRSSM_SPLIT_LAUNCH
@@ -1149,14 +1151,14 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
     const bool mfma_ok = nq <= 4 * kMaxQ && lds <= 150 * 1024;
     (void)mfma_ok;
     if (tiles && n_out <= kThinOut * kConvThreads && lds_thin <= 64 * 1024 && ptot < (1L << 31) && pg.ps_raw < 1024 && pg.ipg < 1024 &&
-        !((g->mfma_split == 1 || g->mfma_split == 3) && ctot >= 8 && (g->Hq * g->Wq) % 8 == 0)) {  // thin layer: staging-bound, VALU reduction is faster
+        !(g->mfma_split >= 1 && ctot >= 8 && (g->Hq * g->Wq) % 8 == 0)) {  // thin layer: staging-bound, VALU reduction is faster
       const long groups = (ptot + kGP - 1) / kGP;
       long splits = 2048;  // 8 small workgroups per CU: the kernel is staging-latency-bound, occupancy hides it
       if (splits > groups) splits = groups;
       { set_last_kernel("mtrssm::conv_weight_grad_thin_kernel"); hipLaunchKernelGGL(conv_weight_grad_thin_kernel, dim3((unsigned)splits), dim3(kConvThreads), lds_thin, stream, *g, a, src, src2, pre_act_a, dwp, dbias); }
       return launched("conv_weight_grad(thin)");
     }
-    if (tiles && (g->mfma_split == 1 || g->mfma_split == 3) && (g->Hq * g->Wq) % 8 == 0 && ctot <= 128 && !((uintptr_t)a & 15)) {
+    if (tiles && g->mfma_split >= 1 && (g->Hq * g->Wq) % 8 == 0 && ctot <= 128 && !((uintptr_t)a & 15)) {
       // split-bf16 operands (conv_split.h): same persistent structure, bf16 MFMA + transposed LDS reads
       const int sp = g->mfma_split;
       int cp2 = 16;
@@ -1184,8 +1186,8 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
     hipLaunchKernelGGL((conv_weight_grad_split_kernel<NT_, SP_>), grid, dim3(2 * kConvThreads), lds_s, stream, *g, a, src, src2, \
                        pre_act_a, dwp, dbias, cp2, nbuf);                                                                             \
   }
-        if (g->Cout > 32) { if (sp == 3) MTRSSM_WG_SPLIT_LAUNCH(2, 3) else MTRSSM_WG_SPLIT_LAUNCH(2, 1) }
-        else { if (sp == 3) MTRSSM_WG_SPLIT_LAUNCH(1, 3) else MTRSSM_WG_SPLIT_LAUNCH(1, 1) }
+        if (g->Cout > 32) { if (sp == 3) MTRSSM_WG_SPLIT_LAUNCH(2, 3) else if (sp == 2) MTRSSM_WG_SPLIT_LAUNCH(2, 2) else MTRSSM_WG_SPLIT_LAUNCH(2, 1) }
+        else { if (sp == 3) MTRSSM_WG_SPLIT_LAUNCH(1, 3) else if (sp == 2) MTRSSM_WG_SPLIT_LAUNCH(1, 2) else MTRSSM_WG_SPLIT_LAUNCH(1, 1) }
 #undef MTRSSM_WG_SPLIT_LAUNCH
         return launched("conv_weight_grad(split)");
       }

@@ -22,7 +22,7 @@ using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 
 constexpr int kRowB = 32;      // bytes per LDS row: 16 bf16 channels
 // taps whose weights are resident in LDS at once: bounded by the register-prefetch budget (2 waves / SIMD need <= 256 VGPRs)
-__host__ __device__ constexpr int split_tg(int split) { return split == 3 ? 5 : 9; }
+__host__ __device__ constexpr int split_tg(int split) { return split >= 2 ? 5 : 9; }
 
 template <int SPLIT>
 __device__ __forceinline__ void split_bf16(float x, unsigned short (&p)[SPLIT]) {

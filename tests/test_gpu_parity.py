@@ -222,7 +222,8 @@ def test_row_tiles_agree(name: str, rows: int, threads: int, lib_loaded: None) -
         np.testing.assert_allclose(float(out[k]), float(base[k]), rtol=1e-6, err_msg=k)
     for k, p in model.named_parameters():
         if p.grad is not None:
-            np.testing.assert_allclose(_np(p.grad), _np(g0[k]), rtol=1e-4, atol=1e-6 * (float(g0[k].abs().max()) + 1e-9), err_msg=k)
+            # conv weight gradients are summed with fp32 atomics: two runs differ by their arrival order (~3e-6 of the max)
+            np.testing.assert_allclose(_np(p.grad), _np(g0[k]), rtol=1e-4, atol=1e-5 * (float(g0[k].abs().max()) + 1e-9), err_msg=k)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -301,10 +302,11 @@ CONV_CASES = [
 ]
 
 
-@pytest.fixture(params=["bf16x3", "f32"])
+@pytest.fixture(params=["bf16x2", "bf16x3", "f32"])
 def fp32_grade_mode(request):  # noqa: ANN001, ANN201
-    """Both fp32-grade MFMA operand formats of the conv kernels (conv.set_mfma_mode): the default "bf16x3" (three bf16
-    pieces per operand, six bf16 MFMA products, fp32 accumulation) and the fp32 MFMA kernels; same tolerances."""
+    """The MFMA operand formats of the conv kernels that meet the parity tolerances (conv.set_mfma_mode): the default
+    "bf16x2" (two bf16 pieces per operand, three bf16 MFMA products, fp32 accumulation), "bf16x3" (three pieces, six
+    products) and the fp32 MFMA kernels; same tolerances for all three."""
     from multimodal_mtrssm_amd import conv
 
     before = conv.mfma_mode()
@@ -337,10 +339,12 @@ def test_conv2d_kernel(n, cin, h, w, cout, k, s, p, pre, coords, fp32_grade_mode
     bg = b.detach().to(DEV).requires_grad_()
     got = conv2d(xg, wg, bg, stride=s, padding=p, pre_act=pre, act=2, coords=None if cc is None else cc.to(DEV))
     got.backward(gout.to(DEV))
+    # tolerances relative to each tensor's scale (weight gradients are sums over all pixels: O(30) here): 2e-5 of the max
+    # covers the default two-piece operands (measured 8e-6) and is ~10x what the three-piece / fp32 kernels need
     np.testing.assert_allclose(_np(got), want.detach().numpy(), rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(_np(xg.grad), x.grad.numpy(), rtol=1e-4, atol=1e-4)
-    np.testing.assert_allclose(_np(wg.grad), wt.grad.numpy(), rtol=1e-4, atol=2e-4)
-    np.testing.assert_allclose(_np(bg.grad), b.grad.numpy(), rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(_np(wg.grad), wt.grad.numpy(), rtol=1e-4, atol=max(2e-4, 2e-5 * float(wt.grad.abs().max())))
+    np.testing.assert_allclose(_np(bg.grad), b.grad.numpy(), rtol=1e-4, atol=max(2e-4, 2e-5 * float(b.grad.abs().max())))
 
 
 DECONV_CASES = [
@@ -378,10 +382,12 @@ def test_conv_transpose2d_kernel(n, cin, h, w, cout, k, s, p, op, pre, fp32_grad
     got = conv_transpose2d(xg, wg, bg, stride=s, padding=p, output_padding=op, pre_act=pre, act=2)
     got.backward(gout.to(DEV))
     assert got.shape == want.shape
+    # tolerances relative to each tensor's scale (weight gradients are sums over all pixels: O(30) here): 2e-5 of the max
+    # covers the default two-piece operands (measured 8e-6) and is ~10x what the three-piece / fp32 kernels need
     np.testing.assert_allclose(_np(got), want.detach().numpy(), rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(_np(xg.grad), x.grad.numpy(), rtol=1e-4, atol=1e-4)
-    np.testing.assert_allclose(_np(wg.grad), wt.grad.numpy(), rtol=1e-4, atol=2e-4)
-    np.testing.assert_allclose(_np(bg.grad), b.grad.numpy(), rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(_np(wg.grad), wt.grad.numpy(), rtol=1e-4, atol=max(2e-4, 2e-5 * float(wt.grad.abs().max())))
+    np.testing.assert_allclose(_np(bg.grad), b.grad.numpy(), rtol=1e-4, atol=max(2e-4, 2e-5 * float(b.grad.abs().max())))
 
 
 @pytest.mark.parametrize("name", ["mrssm_default", "mrssm_nonsquare"])
@@ -444,7 +450,7 @@ def test_two_stream_branches_change_nothing(lib_loaded: None) -> None:
 
 def test_fp32_mfma_mode_train_step_matches_golden(lib_loaded: None) -> None:
     """The whole train step with the fp32 MFMA conv kernels ("f32" mode; every other GPU test of the step runs in the
-    default "bf16x3" mode): same golden losses, same tolerance."""
+    default "bf16x2" mode): same golden losses, same tolerance."""
     from multimodal_mtrssm_amd import conv
 
     conv.set_mfma_mode("f32")
@@ -456,7 +462,7 @@ def test_fp32_mfma_mode_train_step_matches_golden(lib_loaded: None) -> None:
         for k in out:
             np.testing.assert_allclose(float(out[k].detach()), float(fx[f"loss/{k}"]), rtol=2e-5, err_msg=k)
     finally:
-        conv.set_mfma_mode("bf16x3")
+        conv.set_mfma_mode("bf16x2")
 
 
 def test_bf16_mode_stays_within_its_stated_tolerance(lib_loaded: None) -> None:
@@ -483,7 +489,7 @@ def test_bf16_mode_stays_within_its_stated_tolerance(lib_loaded: None) -> None:
         err = float((got.cpu() - want).abs().max() / want.abs().max())
         assert 1e-5 < err < 2e-2, err  # really bf16 operands (not silently fp32), within the stated bound
     finally:
-        conv.set_mfma_mode("bf16x3")
+        conv.set_mfma_mode("bf16x2")
 
 
 # ---------------------------------------------------------------------------------------------
