@@ -1070,6 +1070,30 @@ int conv_gather_gemm_launch(const MtrssmConvGeom* g, const float* src, const flo
       const long nx = (ptot + tpx - 1) / tpx;
       if (!tiles || pg.ipg >= 32) continue;
       const dim3 grid((unsigned)nx, ny);
+      if (g->mfma_split > 0 && wq && g->KH * g->KW == 1 && g->SS == 1 && g->OS == 1 && g->OFFY == 0 && g->OFFX == 0 && g->C2 == 0 &&
+          g->Hs == g->Hq && g->Ws == g->Wq && g->Ho == g->Hq && g->Wo == g->Wq && g->Cpad % 64 == 0 &&
+          (long)g->N * g->Cout * g->Ho * g->Wo < (1L << 31)) {
+        // 1x1 layers: 64 channels per step (conv_split.h: conv1x1_split_kernel)
+        const int sp = g->mfma_split;
+        const size_t lds_1 = (size_t)sp * (kTP + tco) * 128;
+        const dim3 grid1((unsigned)((ptot + kTP - 1) / kTP), ny);
+#define MTRSSM_1X1_LAUNCH(NT_, SP_)                                                                                            \
+  {                                                                                                                             \
+    static bool attr_done = false;                                                                                              \
+    if (!attr_done) {                                                                                                           \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_split_kernel<NT_, SP_>),                                  \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);                                         \
+      attr_done = true;                                                                                                         \
+    }                                                                                                                           \
+    set_last_kernel("mtrssm::conv1x1_split_kernel<" #NT_ ", " #SP_ ">");                                                         \
+    hipLaunchKernelGGL((conv1x1_split_kernel<NT_, SP_>), grid1, dim3(kConvThreads), lds_1, stream, *g, src, wq, bias, actgrad_in,  \
+                       add_in, out);                                                                                            \
+    return launched("conv_gather_gemm(1x1)");                                                                                   \
+  }
+        if (tco == 64) { if (sp == 3) MTRSSM_1X1_LAUNCH(2, 3) else if (sp == 2) MTRSSM_1X1_LAUNCH(2, 2) else MTRSSM_1X1_LAUNCH(2, 1) }
+        else { if (sp == 3) MTRSSM_1X1_LAUNCH(1, 3) else if (sp == 2) MTRSSM_1X1_LAUNCH(1, 2) else MTRSSM_1X1_LAUNCH(1, 1) }
+#undef MTRSSM_1X1_LAUNCH
+      }
       if (g->mfma_split > 0 && wq) {
         const int sp = g->mfma_split;
         const int taps = g->KH * g->KW;

@@ -375,6 +375,126 @@ __global__ __launch_bounds__(kConvThreads, 3) void conv_gather_split_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// 1x1 convolutions (the second conv of every residual block, forward and backward-data): no halo, one tap, K = Cin.
+// The general kernel walks them in 16-channel chunks -- two barriers and a staging round per 2 * NT * products MFMAs,
+// pure dependency-chain latency (55 us for 105 MB of traffic).  Here a step stages 64 channels at once: [128 pixels]
+// [64 ch] and [TCO][64 ch] bf16 images, 128-byte rows whose 16-byte slots are XOR-swizzled with (row >> 1) & 7 so that
+// the 16 lanes of a ds_read_b128 cycle fall on 16 distinct slots of the 256-byte bank window; one barrier pair per 64
+// channels, four back-to-back k-blocks of MFMAs per step.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned swz128(int row, int slot) { return (unsigned)row * 128u + (unsigned)((slot ^ ((row >> 1) & 7)) << 4); }
+
+template <int NT, int SPLIT>
+__global__ __launch_bounds__(kConvThreads, 3) void conv1x1_split_kernel(
+    const MtrssmConvGeom g, const float* __restrict__ src, const unsigned short* __restrict__ wq, const float* __restrict__ bias,
+    const float* __restrict__ actgrad_in, const float* __restrict__ add_in, float* __restrict__ out) {
+  constexpr int TCO = 32 * NT;
+  constexpr int KCH = 64;                                   // channels per step
+  constexpr int WPC = SPLIT * TCO * (KCH / 8) / kConvThreads;  // 16-byte weight pieces per thread per step
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  unsigned char* patch = lds_raw;                            // [SPLIT][128 px][128 B]
+  unsigned char* w_lds = patch + SPLIT * kTP * 128;          // [SPLIT][TCO][128 B]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kl = lane >> 5, il = lane & 31;
+  const int plane = g.Hq * g.Wq;
+  const long ptot = (long)g.N * plane;
+  const unsigned nb = gridDim.x, per_xcd = (nb + 7) / 8;
+  unsigned bid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if ((nb & 7) != 0) bid = blockIdx.x;
+  const long p0 = (long)bid * kTP;
+  const int co0 = blockIdx.y * TCO;
+
+  // staging role: position = tid & 127, channel half = tid >> 7 (32 of the step's 64 channels)
+  const int spos = tid & 127, shalf = tid >> 7;
+  long sp = p0 + spos;
+  const bool sok = sp < ptot;
+  sp = sok ? sp : ptot - 1;
+  const int sn = (int)(sp / plane), srem = (int)(sp - (long)sn * plane);
+  const float* sbase = src + ((size_t)sn * g.C) * plane + srem;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  ConvEpilogue epi;
+  epi.init(g, p0 + wave * 32 + il, ptot, plane, co0, TCO, kl);
+  const int prow = wave * 32 + il;  // this lane's pixel row in the patch image
+  const size_t wq_plane = (size_t)g.CoutPad * g.Cpad;
+
+  for (int c0 = 0; c0 < g.Cpad; c0 += KCH) {
+    // ---- loads first: 32 channels of this thread's pixel, and its weight pieces
+    float v[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {
+      int c = c0 + shalf * 32 + u;
+      c = c < g.C ? c : g.C - 1;  // wave-uniform clamp; masked below
+      v[u] = sbase[(size_t)c * plane];
+    }
+    u32x4 wv[WPC];
+#pragma unroll
+    for (int i = 0; i < WPC; ++i) {
+      const int q = tid + kConvThreads * i;           // over [s][row][slot]
+      const int slot = q & 7, row = (q >> 3) & (TCO - 1), s = q / (8 * TCO);
+      wv[i] = *reinterpret_cast<const u32x4*>(wq + s * wq_plane + (size_t)(co0 + row) * g.Cpad + c0 + slot * 8);
+    }
+    if (c0 > 0) __syncthreads();  // everyone is done with the previous step's images
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      float x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = (sok && c0 + shalf * 32 + o * 8 + u < g.C) ? v[o * 8 + u] : 0.f;
+      if (g.pre_act) act_inplace<8>(x, g.act);
+      u16x8 qv[SPLIT];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        unsigned short pc[SPLIT];
+        split_bf16<SPLIT>(x[u], pc);
+#pragma unroll
+        for (int s = 0; s < SPLIT; ++s) qv[s][u] = pc[s];
+      }
+      const unsigned ad = swz128(spos, shalf * 4 + o);
+#pragma unroll
+      for (int s = 0; s < SPLIT; ++s) *reinterpret_cast<u16x8*>(patch + s * kTP * 128 + ad) = qv[s];
+    }
+#pragma unroll
+    for (int i = 0; i < WPC; ++i) {
+      const int q = tid + kConvThreads * i;
+      const int slot = q & 7, row = (q >> 3) & (TCO - 1), s = q / (8 * TCO);
+      *reinterpret_cast<u32x4*>(w_lds + s * TCO * 128 + swz128(row, slot)) = wv[i];
+    }
+    __syncthreads();
+    // ---- four k-blocks of 16 channels
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      bf16x8 b[SPLIT], a[NT][SPLIT];
+#pragma unroll
+      for (int s = 0; s < SPLIT; ++s) b[s] = *reinterpret_cast<const bf16x8*>(patch + s * kTP * 128 + swz128(prow, kb * 2 + kl));
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int s = 0; s < SPLIT; ++s)
+          a[j][s] = *reinterpret_cast<const bf16x8*>(w_lds + s * TCO * 128 + swz128(j * 32 + il, kb * 2 + kl));
+#pragma unroll
+      for (int ord = SPLIT - 1; ord >= 0; --ord)
+#pragma unroll
+        for (int sa = 0; sa <= ord; ++sa)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j][sa], b[ord - sa], acc[j], 0, 0, 0);
+    }
+  }
+  epi.load(0, bias, actgrad_in, add_in);
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    float res[16];
+    epi.combine(acc[j], g.act, actgrad_in != nullptr, add_in != nullptr, res);
+    if (j + 1 < NT) epi.load(j + 1, bias, actgrad_in, add_in);
+    epi.store(j, res, out);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Weight gradient with split-bf16 operands: dWp[co][tap][c] += sum_pix A[co][pix] P[c][pos(pix) + tap].
 // Persistent, one 8-wave workgroup per CU looping over 64-pixel groups (as conv_weight_grad_patch_kernel): waves 4-7
 // stage group g+1 (global fp32 -> activation -> bf16 pieces -> LDS) while waves 0-3 run group g's MFMAs, one barrier per
