@@ -192,8 +192,10 @@ def main() -> None:  # noqa: PLR0914, PLR0915
     ap.add_argument("--model", choices=("mrssm", "mmtrssm"), default="mrssm",
                     help="mrssm = BASELINE configs[1] (the metric's config); mmtrssm = configs[2] (MTState variant)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even for one rank (exercises the N>1 code path)")
-    ap.add_argument("--single-stream", action="store_true",
-                    help="run the audio / vision branches on one stream (default: two streams, core.fork_join)")
+    ap.add_argument("--two-streams", action="store_true",
+                    help="run the audio / vision branches on two HIP streams (core.fork_join): -9 % step time, but about one run in "
+                         "fifteen stalled on the GPU on this stack (profiles/round1_notes.md); default: one stream")
+    ap.add_argument("--single-stream", action="store_true", help="(default; kept for the commands quoted in profiles/)")
     ap.add_argument("--conv-mfma", choices=("bf16x2", "bf16x3", "f32", "bf16"), default="bf16x2",
                     help="conv MFMA operand format: bf16x2 = two bf16 pieces per fp32 operand, three products, fp32 accumulate (the mode "
                          "the parity tests run in; errors vs golden 7e-7 / 1.3e-7 / 8e-6, tools/mode_errors.py), bf16x3 = three pieces, "
@@ -221,7 +223,7 @@ def main() -> None:  # noqa: PLR0914, PLR0915
 
     conv.set_mfma_mode(args.conv_mfma)
     from multimodal_mtrssm_amd import core as _core
-    _core.BRANCH_STREAMS = not args.single_stream
+    _core.BRANCH_STREAMS = bool(args.two_streams) and not args.single_stream
 
     w = WORKLOAD
     model = build_model(device, args.model)
@@ -346,7 +348,7 @@ def main() -> None:  # noqa: PLR0914, PLR0915
                 "hidden": w["hidden"], "embed": w["embed"], "categoricals_x_classes": f"{w['cats']}x{w['classes']}",
                 "enc_channels": [8, 16, 32], "dec_channels": [32, 16, 1], "residual_blocks": 3, "activation": "ELU",
                 "optimizer": "AdamW lr 1e-3 + clip 10 (fused HIP)", "params": flat.numel,
-                "streams": 1 if args.single_stream else 2,
+                "streams": 2 if _core.BRANCH_STREAMS else 1,
                 "conv_mfma": {"bf16x3": "fp32 operands as 3 bf16 pieces, 6 bf16-MFMA products, fp32 accumulate (~2^-24 per product)",
                               "bf16x2": "fp32 operands as 2 bf16 pieces, 3 bf16-MFMA products, fp32 accumulate; the mode of the parity tests "
                                         "(vs golden: losses 7e-7 rel, posterior 1.3e-7, gradients 8e-6 of max)",

@@ -8,9 +8,9 @@ Importing the package does not need a GPU; running a rollout does, and fails lou
 
 import os as _os
 
-# Effective only if HIP has not been initialised yet (harmless otherwise): the two modality branches run on two streams
-# (core.fork_join); with ROCm's default of 4 hardware queues per process a side stream can share the default stream's
-# queue once RCCL has taken its own, and the branches then serialise.
+# Effective only if HIP has not been initialised yet (harmless otherwise): with core.BRANCH_STREAMS the two modality
+# branches run on two streams (core.fork_join); with ROCm's default of 4 hardware queues per process a side stream can
+# share the default stream's queue once RCCL has taken its own, and the branches then serialise.
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 from multimodal_mtrssm_amd.cnn import Decoder, Encoder  # noqa: E402

@@ -43,9 +43,13 @@ except ImportError:  # this image: a LightningModule-shaped nn.Module
 Noise = dict[str, Tensor | None]
 
 # The audio and vision branches (encoders; decoders + their NLL) are independent.  Each conv kernel is a few rounds of
-# workgroup tiles with a partly empty last round, so the two branches run on two HIP streams and fill
-# each other's tails; autograd replays the backward of each branch on the stream its forward ran on.  Values are unchanged.
-BRANCH_STREAMS = True
+# workgroup tiles with a partly empty last round, so the two branches can run on two HIP streams and
+# fill each other's tails (-9 % step time, values unchanged); autograd replays the backward of each branch on the stream
+# its forward ran on.  OFF by default: on this stack (ROCm 7.2, torch 2.10) about one 65-step run in fifteen stopped
+# making progress on the GPU with the two streams on -- 6 of 84 runs with the encoders' branch on two streams, 0 of 30 with
+# only the decoders', 0 of 36 on one stream (profiles/round1_notes.md).  `bench.py --two-streams` / BRANCH_STREAMS = True
+# turn it on.
+BRANCH_STREAMS = False
 _SIDE_STREAMS: dict[int, torch.cuda.Stream] = {}
 
 

@@ -1204,8 +1204,12 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
         dim3 grid((unsigned)splits, cotiles);
 #define MTRSSM_WG_SPLIT_LAUNCH(NT_, SP_)                                                                                       \
   {                                                                                                                             \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_weight_grad_split_kernel<NT_, SP_>),                           \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);                                          \
+    static bool attr_done = false; /* once per instantiation: never while another stream may be running the kernel */       \
+    if (!attr_done) {                                                                                                           \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_weight_grad_split_kernel<NT_, SP_>),                         \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);                                        \
+      attr_done = true;                                                                                                         \
+    }                                                                                                                           \
     set_last_kernel("mtrssm::conv_weight_grad_split_kernel<" #NT_ ", " #SP_ ">");                                                \
     hipLaunchKernelGGL((conv_weight_grad_split_kernel<NT_, SP_>), grid, dim3(2 * kConvThreads), lds_s, stream, *g, a, src, src2, \
                        pre_act_a, dwp, dbias, cp2, nbuf);                                                                             \

@@ -421,7 +421,7 @@ def test_encoder_decoder_match_oracle(name: str, fp32_grade_mode: str, lib_loade
 
 
 def test_two_stream_branches_change_nothing(lib_loaded: None) -> None:
-    """core.fork_join (audio / vision encoders and decoders on two HIP streams, the default) against the same step on one
+    """core.fork_join (audio / vision encoders and decoders on two HIP streams, opt-in) against the same step on one
     stream: the same losses and gradients up to the arrival order of fp32 atomics (NLL reduction, weight-gradient kernels)."""
     from multimodal_mtrssm_amd import core
 
@@ -440,7 +440,7 @@ def test_two_stream_branches_change_nothing(lib_loaded: None) -> None:
             torch.cuda.synchronize()
             runs[two] = ({k: float(v) for k, v in out.items()}, {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
         finally:
-            core.BRANCH_STREAMS = True
+            core.BRANCH_STREAMS = False
     for k, v in runs[False][0].items():  # the NLL reduction uses fp32 atomics: equal up to their arrival order
         np.testing.assert_allclose(runs[True][0][k], v, rtol=2e-6, err_msg=k)
     for k, g in runs[False][1].items():
