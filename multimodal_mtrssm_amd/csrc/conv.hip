@@ -1097,8 +1097,7 @@ int conv_gather_gemm_launch(const MtrssmConvGeom* g, const float* src, const flo
       if (g->mfma_split > 0 && wq) {
         const int sp = g->mfma_split;
         const int taps = g->KH * g->KW;
-        static const int tg_env = getenv("MTRSSM_SPLIT_TG") ? atoi(getenv("MTRSSM_SPLIT_TG")) : 99;
-        const int tg_cap = tg_env < split_tg(sp) ? tg_env : split_tg(sp);
+        const int tg_cap = split_tg(sp);
         auto lds_of = [&](int t) { return (size_t)sp * ((size_t)pg.ps_raw * kRowB + (size_t)t * tco * kRowB); };
         int tgs = 1;  // largest divisor of taps within the register / LDS budget
         for (int t = 1; t <= tg_cap && t <= taps; ++t)
