@@ -198,7 +198,7 @@ def main() -> None:  # noqa: PLR0914, PLR0915
     ap.add_argument("--single-stream", action="store_true", help="(default; kept for the commands quoted in profiles/)")
     ap.add_argument("--conv-mfma", choices=("bf16x2", "bf16x3", "f32", "bf16"), default="bf16x2",
                     help="conv MFMA operand format: bf16x2 = two bf16 pieces per fp32 operand, three products, fp32 accumulate (the mode "
-                         "the parity tests run in; errors vs golden 7e-7 / 1.3e-7 / 8e-6, tools/mode_errors.py), bf16x3 = three pieces, "
+                         "the parity tests run in; errors vs golden 7e-7 / 1.3e-7 / 8e-6, tests/mode_errors.py), bf16x3 = three pieces, "
                          "six products (~2^-24), f32 = fp32 MFMA, bf16 = plain bf16 operands (outside the posterior tolerance: dtype bf16)")
     args = ap.parse_args()
 

@@ -66,7 +66,7 @@ def set_mfma_mode(mode: str) -> None:
     """``"bf16x2"`` (default): every fp32 operand as two bf16 pieces (16 significant bits), the three products
     ``p0 q0 + p0 q1 + p1 q0`` as bf16 MFMAs with fp32 accumulation; against the golden fixtures: losses 7e-7 relative,
     posterior 1.3e-7 absolute, gradients 8e-6 of the tensor's max -- the fp32 MFMA kernels' own figures are 7e-7 / 0 / 3e-6
-    (tools/mode_errors.py), two orders inside the parity tolerances.  ``"bf16x3"``: three pieces, six products (~2^-24:
+    (tests/mode_errors.py), two orders inside the parity tolerances.  ``"bf16x3"``: three pieces, six products (~2^-24:
     indistinguishable from fp32).  ``"f32"``: fp32 MFMA (bitwise an fma chain).  ``"bf16"``: plain bf16 operands
     (posterior 7e-5, gradients 7e-3: outside the 1e-5 posterior tolerance)."""
     global _MFMA_SPLIT  # noqa: PLW0603

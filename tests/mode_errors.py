@@ -1,4 +1,5 @@
-"""Error of each conv MFMA mode against the golden fixtures (profiling helper): losses (relative), posterior
+"""Error of each conv MFMA mode against the golden fixtures (measurement script, run by hand on the MI355X: `python tests/mode_errors.py`;
+it lives under tests/ because it uses the oracle): losses (relative), posterior
 probabilities / deter (absolute), gradients (relative to the tensor's max)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
