@@ -360,6 +360,14 @@ typedef struct MtrssmConvGeom {
 
 int mtrssm_conv_gather_gemm(const MtrssmConvGeom* g, const float* src, const float* src2, const float* wp, const uint16_t* wq,
                             const float* bias, const float* actgrad_in, const float* add_in, float* out, void* stream);
+/* Two independent gather problems (the same layer of the audio and of the vision stack: same channels and taps, different
+ * planes) in ONE launch when both map to the same split-bf16 kernel, else two launches: a layer is ~2 rounds of workgroup tiles
+ * with a nearly empty last one, two of them back to back in one grid waste one round instead of two.  Arguments as
+ * mtrssm_conv_gather_gemm, once per problem. */
+int mtrssm_conv_gather_gemm_pair(const MtrssmConvGeom* ga, const float* srca, const float* src2a, const float* wpa, const uint16_t* wqa,
+                                 const float* biasa, const float* actgrada, const float* adda, float* outa,
+                                 const MtrssmConvGeom* gb, const float* srcb, const float* src2b, const float* wpb, const uint16_t* wqb,
+                                 const float* biasb, const float* actgradb, const float* addb, float* outb, void* stream);
 /* Packs a conv weight view w[O][I][KH][KW] (element strides so, si, sh, sw: any permuted / strided view of the module's
  * parameter, e.g. the per-parity-class tap subset of a ConvTranspose2d weight) into the kernels' layout:
  *   wp fp32 [OPad][KH*KW][IPad], zero padded;

@@ -30,7 +30,7 @@ import torch
 from torch import Tensor, nn
 
 from multimodal_mtrssm_amd import _lib
-from multimodal_mtrssm_amd.conv import conv2d, conv_transpose2d, residual_block
+from multimodal_mtrssm_amd.conv import conv2d, conv_transpose2d, residual_block, residual_block_pair
 
 
 def _act(name: str) -> nn.Module:
@@ -61,6 +61,40 @@ class ResidualBlock(nn.Module):
 
     def forward(self, x: Tensor) -> Tensor:
         return residual_block(x, self.conv3.weight, self.conv3.bias, self.conv1.weight, self.conv1.bias, act=self.act_id)
+
+    def params(self) -> tuple[Tensor, Tensor, Tensor, Tensor]:
+        return self.conv3.weight, self.conv3.bias, self.conv1.weight, self.conv1.bias
+
+
+def _res_pair(res_a: nn.ModuleList, res_b: nn.ModuleList, xa: Tensor, xb: Tensor) -> tuple[Tensor, Tensor]:
+    """Two residual stacks walked in lockstep: blocks of equal shape go out as paired launches (``conv.paired``)."""
+    n = min(len(res_a), len(res_b))
+    for ba, bb in zip(res_a[:n], res_b[:n], strict=True):
+        if ba.act_id == bb.act_id and ba.conv3.weight.shape == bb.conv3.weight.shape and ba.conv1.weight.shape == bb.conv1.weight.shape:
+            xa, xb = residual_block_pair(xa, ba.params(), xb, bb.params(), act=ba.act_id)
+        else:
+            xa, xb = ba(xa), bb(xb)
+    for ba in res_a[n:]:
+        xa = ba(xa)
+    for bb in res_b[n:]:
+        xb = bb(xb)
+    return xa, xb
+
+
+def encode_pair(enc_a: "Encoder", enc_b: "Encoder", xa: Tensor, xb: Tensor) -> tuple[Tensor, Tensor]:
+    """``(enc_a(xa), enc_b(xb))`` with the two residual stacks sharing their launches."""
+    lead_a, lead_b = xa.shape[:-3], xb.shape[:-3]
+    xa, xb = enc_a.stem(xa), enc_b.stem(xb)
+    xa, xb = _res_pair(enc_a.res, enc_b.res, xa, xb)
+    return enc_a.head(xa, lead_a), enc_b.head(xb, lead_b)
+
+
+def decode_pair(dec_a: "Decoder", dec_b: "Decoder", fa: Tensor, fb: Tensor) -> tuple[Tensor, Tensor]:
+    """``(dec_a(fa), dec_b(fb))`` with the two residual stacks sharing their launches."""
+    lead_a, lead_b = fa.shape[:-1], fb.shape[:-1]
+    xa, xb = dec_a.stem(fa), dec_b.stem(fb)
+    xa, xb = _res_pair(dec_a.res, dec_b.res, xa, xb)
+    return dec_a.tail(xa, lead_a), dec_b.tail(xb, lead_b)
 
 
 class Encoder(nn.Module):
@@ -110,10 +144,17 @@ class Encoder(nn.Module):
         return self._coords
 
     def forward(self, x: Tensor) -> Tensor:
+        lead = x.shape[:-3]
+        x = self.stem(x)
+        for blk in self.res:
+            x = blk(x)
+        return self.head(x, lead)
+
+    def stem(self, x: Tensor) -> Tensor:
+        """Strided convs (+ the conv into the residual stack) over the flattened frames."""
         if len(self.linears) == 0:
             self.materialize(tuple(x.shape[-3:]))
             self.to(x.device)
-        lead = x.shape[:-3]
         x = x.reshape(-1, *x.shape[-3:]).float()
         # the coordinate channels are frame-independent: the first conv gathers them from one [2,H,W] plane
         coords = self._coord_channels(x) if self.coord_conv else None
@@ -121,8 +162,9 @@ class Encoder(nn.Module):
             x = _conv(x, conv, pre_act=i > 0, act=self.act_id, coords=coords if i == 0 else None)
         if self.res_in is not None:
             x = _conv(x, self.res_in, pre_act=True, act=self.act_id)
-            for blk in self.res:
-                x = blk(x)
+        return x
+
+    def head(self, x: Tensor, lead: torch.Size) -> Tensor:
         x = self.act(x).flatten(start_dim=1)
         for i, lin in enumerate(self.linears):
             x = lin(x)
@@ -163,18 +205,24 @@ class Decoder(nn.Module):
         self.in_features = in_features
 
     def forward(self, f: Tensor) -> Tensor:
+        lead = f.shape[:-1]
+        x = self.stem(f)
+        for blk in self.res:
+            x = blk(x)
+        return self.tail(x, lead)
+
+    def stem(self, f: Tensor) -> Tensor:
         if len(self.linears) == 0:
             self.materialize(f.shape[-1])
             self.to(f.device)
-        lead = f.shape[:-1]
         x = f.reshape(-1, f.shape[-1])
         for i, lin in enumerate(self.linears):
             x = lin(x)
             if i + 1 < len(self.linears):
                 x = self.act(x)
-        x = x.reshape(-1, *self.conv_in_shape)
-        for blk in self.res:
-            x = blk(x)
+        return x.reshape(-1, *self.conv_in_shape)
+
+    def tail(self, x: Tensor, lead: torch.Size) -> Tensor:
         for i, dc in enumerate(self.deconvs):
             # "act -> deconv" everywhere except a first deconv fed straight by the Linear (no residual stack)
             x = _deconv(x, dc, pre_act=i > 0 or len(self.res) > 0, act=self.act_id)

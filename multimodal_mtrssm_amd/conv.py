@@ -32,6 +32,12 @@ def _pads(cout: int, cin: int) -> tuple[int, int]:
 
 _PACK_BUFFERS: dict[tuple, tuple[Tensor, Tensor | None]] = {}
 
+# Paired launches: the audio and the vision stack run the same layer on different planes; inside
+# ``paired()`` the gather launches are collected instead of issued and then go out two per launch
+# (``mtrssm_conv_gather_gemm_pair``), the k-th launch of the first callable with the k-th of the second.
+PAIR_LAUNCH = True
+_DEFER: list[tuple] | None = None
+
 
 def pack_weight(w: Tensor) -> tuple[Tensor, Tensor | None]:
     """``w[O][I][kh][kw]`` (any strided view) -> zero-padded fp32 ``wp[OPad][kh*kw][IPad]`` (channel fastest) and, in a
@@ -42,7 +48,8 @@ def pack_weight(w: Tensor) -> tuple[Tensor, Tensor | None]:
     """
     o, i, kh, kw = w.shape
     opad, ipad = _pads(o, i)
-    key = (o, i, kh, kw, _MFMA_SPLIT, w.device, torch.cuda.current_stream(w.device).cuda_stream if w.is_cuda else 0)
+    slot = len(_DEFER) if _DEFER is not None else 0  # deferred (paired) launches: one buffer per pending job
+    key = (o, i, kh, kw, _MFMA_SPLIT, slot, w.device, torch.cuda.current_stream(w.device).cuda_stream if w.is_cuda else 0)
     bufs = _PACK_BUFFERS.get(key)
     if bufs is None:
         wp = torch.zeros(opad, kh * kw, ipad, device=w.device, dtype=torch.float32)
@@ -93,13 +100,58 @@ def _gather_gemm(geom: C.Structure, src: Tensor, src2: Tensor | None, wpq: tuple
     wp, wq = wpq
     lib = _lib.load()
     # algorithmic work of this launch: 2 FLOPs per (output element, tap, real channel); bytes = source read once + output written once
+    job = (geom, src, src2, wp, wq, bias, actgrad_in, add_in, out)
+    if _DEFER is not None:
+        _DEFER.append(job)
+        return
+    _launch_gather(job)
+
+
+def _job_work(job: tuple) -> tuple[float, float]:
+    geom, actgrad_in = job[0], job[6]
     pixels = geom.N * geom.Hq * geom.Wq
     flops = 2.0 * pixels * geom.Cout * geom.KH * geom.KW * (geom.C + geom.C2)
     nbytes = 4.0 * (geom.N * geom.C * geom.Hs * geom.Ws + pixels * geom.Cout * (2 if actgrad_in is not None else 1))
-    _lib.check(_lib.TIMERS.call(
-        "mtrssm_conv_gather_gemm", lib.mtrssm_conv_gather_gemm, C.byref(geom), _lib.ptr(src), _lib.ptr(src2), _lib.ptr(wp),
-        _lib.raw_ptr(wq), _lib.ptr(bias), _lib.ptr(actgrad_in), _lib.ptr(add_in), _lib.ptr(out), _lib.stream_ptr(src.device), flops=flops,
-        nbytes=nbytes), "mtrssm_conv_gather_gemm")
+    return flops, nbytes
+
+
+def _job_args(job: tuple) -> tuple:
+    geom, src, src2, wp, wq, bias, actgrad_in, add_in, out = job
+    return (C.byref(geom), _lib.ptr(src), _lib.ptr(src2), _lib.ptr(wp), _lib.raw_ptr(wq), _lib.ptr(bias), _lib.ptr(actgrad_in),
+            _lib.ptr(add_in), _lib.ptr(out))
+
+
+def _launch_gather(job: tuple) -> None:
+    lib = _lib.load()
+    flops, nbytes = _job_work(job)
+    _lib.check(_lib.TIMERS.call("mtrssm_conv_gather_gemm", lib.mtrssm_conv_gather_gemm, *_job_args(job),
+                                _lib.stream_ptr(job[1].device), flops=flops, nbytes=nbytes), "mtrssm_conv_gather_gemm")
+
+
+def paired(fn_a, fn_b):  # noqa: ANN001, ANN201
+    """``(fn_a(), fn_b())`` with their gather launches merged two by two (same count and order in both callables)."""
+    global _DEFER  # noqa: PLW0603
+    if not PAIR_LAUNCH or _DEFER is not None:
+        return fn_a(), fn_b()
+    _DEFER = []
+    try:
+        ra = fn_a()
+        na = len(_DEFER)
+        rb = fn_b()
+        jobs = _DEFER
+    finally:
+        _DEFER = None
+    if na * 2 != len(jobs):
+        for job in jobs:
+            _launch_gather(job)
+        return ra, rb
+    lib = _lib.load()
+    for ja, jb in zip(jobs[:na], jobs[na:], strict=True):
+        fa, ba = _job_work(ja)
+        fb, bb = _job_work(jb)
+        _lib.check(_lib.TIMERS.call("mtrssm_conv_gather_gemm_pair", lib.mtrssm_conv_gather_gemm_pair, *_job_args(ja), *_job_args(jb),
+                                    _lib.stream_ptr(ja[1].device), flops=fa + fb, nbytes=ba + bb), "mtrssm_conv_gather_gemm_pair")
+    return ra, rb
 
 
 def _conv_forward_gather(x: Tensor, coords: Tensor | None, w: Tensor, bias: Tensor | None, stride: int, pad: int,  # noqa: PLR0913
@@ -283,6 +335,46 @@ class _ResidualBlock(torch.autograd.Function):
             g_x = _conv_transposed_gather(g_h, w3, None, 1, p3, (x.shape[2], x.shape[3]), False, act, actgrad_in=x, add_in=g_y)
         g_w3, g_b3 = _weight_grad(g_h, x, None, w3.shape[2], w3.shape[3], 1, p3, False, True, act, want_bias=True)
         return g_x, g_w3, g_b3, g_w1, g_b1, None
+
+
+class _PairResidualBlock(torch.autograd.Function):
+    """``_ResidualBlock`` of the audio and of the vision stack as ONE node: every gather of the pair (two forward, two
+    backward-data) is one launch for both branches; the weight gradients stay one launch each (persistent kernels)."""
+
+    @staticmethod
+    def forward(ctx, xa, w3a, b3a, w1a, b1a, xv, w3v, b3v, w1v, b1v, act):  # noqa: ANN001, PLR0913
+        xa, w3a, b3a, w1a, b1a, xv, w3v, b3v, w1v, b1v = (t.contiguous() for t in (xa, w3a, b3a, w1a, b1a, xv, w3v, b3v, w1v, b1v))
+        p3, p1 = w3a.shape[2] // 2, w1a.shape[2] // 2
+        ha, hv = paired(lambda: _conv_forward_gather(xa, None, w3a, b3a, 1, p3, True, act),
+                        lambda: _conv_forward_gather(xv, None, w3v, b3v, 1, p3, True, act))
+        ya, yv = paired(lambda: _conv_forward_gather(ha, None, w1a, b1a, 1, p1, True, act, add_in=xa),
+                        lambda: _conv_forward_gather(hv, None, w1v, b1v, 1, p1, True, act, add_in=xv))
+        ctx.save_for_backward(xa, ha, w3a, w1a, xv, hv, w3v, w1v)
+        ctx.act = act
+        return ya, yv
+
+    @staticmethod
+    def backward(ctx, g_ya, g_yv):  # noqa: ANN001, ANN205
+        xa, ha, w3a, w1a, xv, hv, w3v, w1v = ctx.saved_tensors
+        act = ctx.act
+        g_ya, g_yv = g_ya.contiguous(), g_yv.contiguous()
+        p3, p1 = w3a.shape[2] // 2, w1a.shape[2] // 2
+        g_ha, g_hv = paired(lambda: _conv_transposed_gather(g_ya, w1a, None, 1, p1, (ha.shape[2], ha.shape[3]), False, act, actgrad_in=ha),
+                            lambda: _conv_transposed_gather(g_yv, w1v, None, 1, p1, (hv.shape[2], hv.shape[3]), False, act, actgrad_in=hv))
+        g_w1a, g_b1a = _weight_grad(g_ya, ha, None, w1a.shape[2], w1a.shape[3], 1, p1, False, True, act, want_bias=True)
+        g_w1v, g_b1v = _weight_grad(g_yv, hv, None, w1v.shape[2], w1v.shape[3], 1, p1, False, True, act, want_bias=True)
+        g_xa, g_xv = paired(
+            lambda: _conv_transposed_gather(g_ha, w3a, None, 1, p3, (xa.shape[2], xa.shape[3]), False, act, actgrad_in=xa, add_in=g_ya),
+            lambda: _conv_transposed_gather(g_hv, w3v, None, 1, p3, (xv.shape[2], xv.shape[3]), False, act, actgrad_in=xv, add_in=g_yv))
+        g_w3a, g_b3a = _weight_grad(g_ha, xa, None, w3a.shape[2], w3a.shape[3], 1, p3, False, True, act, want_bias=True)
+        g_w3v, g_b3v = _weight_grad(g_hv, xv, None, w3v.shape[2], w3v.shape[3], 1, p3, False, True, act, want_bias=True)
+        return g_xa, g_w3a, g_b3a, g_w1a, g_b1a, g_xv, g_w3v, g_b3v, g_w1v, g_b1v, None
+
+
+def residual_block_pair(xa: Tensor, pa: tuple[Tensor, Tensor, Tensor, Tensor], xv: Tensor, pv: tuple[Tensor, Tensor, Tensor, Tensor],
+                        *, act: int) -> tuple[Tensor, Tensor]:
+    """Two residual blocks with the same channel counts (``p* = (w3, b3, w1, b1)``) on different planes."""
+    return _PairResidualBlock.apply(xa, *pa, xv, *pv, int(act))
 
 
 def residual_block(x: Tensor, w3: Tensor, b3: Tensor, w1: Tensor, b1: Tensor, *, act: int) -> Tensor:

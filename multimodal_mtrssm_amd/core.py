@@ -19,7 +19,7 @@ from __future__ import annotations
 import torch
 from torch import Tensor, nn
 
-from multimodal_mtrssm_amd import scan
+from multimodal_mtrssm_amd import cnn, conv, scan
 from multimodal_mtrssm_amd.distributions import MultiOneHot, MultiOneHotFactory, kl_divergence, onehot_from_uniforms
 from multimodal_mtrssm_amd.networks import MTRNN, Representation, Transition
 from multimodal_mtrssm_amd.objective import likelihood
@@ -105,6 +105,11 @@ def fork_join(side_fn, main_fn, *inputs: Tensor):  # noqa: ANN001, ANN201
     return a, b
 
 
+def _pairable(a: nn.Module, b: nn.Module, kind: type) -> bool:
+    """Paired launches (``conv.paired``) replace the two-stream overlap on one stream, for this package's own stacks."""
+    return conv.PAIR_LAUNCH and not BRANCH_STREAMS and isinstance(a, kind) and isinstance(b, kind)
+
+
 def _st_onehot(dist: MultiOneHot, u: Tensor | None) -> Tensor:
     """Straight-through one-hot sample of ``dist`` from uniforms ``u`` (drawn on device when None)."""
     if u is None:
@@ -181,8 +186,19 @@ class MoPoE_MRSSM(_Base):  # noqa: N801
         vision = likelihood(prediction=reconstructions["recon/vision"], target=targets["recon/vision"], event_ndims=3)
         return {"recon": audio + vision, "recon/audio": audio, "recon/vision": vision}
 
+    def _encode_both(self, audio_obs: Tensor, vision_obs: Tensor) -> tuple[Tensor, Tensor]:
+        """Both encoders over all B*T frames; equal-shaped residual blocks of the two stacks share launches."""
+        if _pairable(self.audio_encoder, self.vision_encoder, cnn.Encoder):
+            return cnn.encode_pair(self.audio_encoder, self.vision_encoder, audio_obs, vision_obs)
+        return fork_join(lambda: self.audio_encoder(audio_obs), lambda: self.vision_encoder(vision_obs), audio_obs, vision_obs)
+
     def _reconstruction_losses(self, feature: Tensor, targets: dict[str, Tensor]) -> dict[str, Tensor]:
-        """``decode_state`` + ``compute_reconstruction_loss`` (``mrssm core.py:262-308``), one modality per stream."""
+        """``decode_state`` + ``compute_reconstruction_loss`` (``mrssm core.py:262-308``)."""
+        if _pairable(self.audio_decoder, self.vision_decoder, cnn.Decoder):
+            pa, pv = cnn.decode_pair(self.audio_decoder, self.vision_decoder, feature, feature)
+            audio = likelihood(prediction=pa, target=targets["recon/audio"], event_ndims=3)
+            vision = likelihood(prediction=pv, target=targets["recon/vision"], event_ndims=3)
+            return {"recon": audio + vision, "recon/audio": audio, "recon/vision": vision}
         audio, vision = fork_join(
             lambda: likelihood(prediction=self.audio_decoder(feature), target=targets["recon/audio"], event_ndims=3),
             lambda: likelihood(prediction=self.vision_decoder(feature), target=targets["recon/vision"], event_ndims=3),
@@ -256,8 +272,7 @@ class MoPoE_MRSSM(_Base):  # noqa: N801
         action_input = batch[0]
         audio_obs, vision_obs = self.get_observations_from_batch(batch)
         bound_run_ahead(audio_obs.device)
-        audio_embed, vision_embed = fork_join(lambda: self.audio_encoder(audio_obs), lambda: self.vision_encoder(vision_obs),
-                                              audio_obs, vision_obs)
+        audio_embed, vision_embed = self._encode_both(audio_obs, vision_obs)
         u_init = None if noise is None else noise.get("u_init")
         state0 = self._initial_from_embed((audio_embed[:, 0] + vision_embed[:, 0]) / 2.0, u_init)
         out = self._rollout_embedded(action_input, audio_embed, vision_embed, state0, noise, sample_prior=False)
@@ -418,8 +433,7 @@ class MoPoE_MMTRSSM(MoPoE_MRSSM):  # noqa: N801
         action_input = batch[0]
         audio_obs, vision_obs = self.get_observations_from_batch(batch)
         bound_run_ahead(audio_obs.device)
-        audio_embed, vision_embed = fork_join(lambda: self.audio_encoder(audio_obs), lambda: self.vision_encoder(vision_obs),
-                                              audio_obs, vision_obs)
+        audio_embed, vision_embed = self._encode_both(audio_obs, vision_obs)
         state0 = self._initial_from_embed((audio_embed[:, 0] + vision_embed[:, 0]) / 2.0, noise)
         out = self._rollout_embedded(action_input, audio_embed, vision_embed, state0, noise, sample_prior=False)
         feature = torch.cat([out["deter_h"], out["post_stoch_h"], out["deter_l"], out["post_stoch_l"]], dim=-1)

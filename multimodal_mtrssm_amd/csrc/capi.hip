@@ -24,6 +24,8 @@ int mmtrssm_fwd_launch(const MtrssmMmtrssmDims*, const MtrssmMmtrssmFwdWeights*,
 int mmtrssm_bwd_launch(const MtrssmMmtrssmDims*, const MtrssmMmtrssmBwdWeights*, const MtrssmMmtrssmBwdIO*, hipStream_t);
 int conv_gather_gemm_launch(const MtrssmConvGeom*, const float*, const float*, const float*, const unsigned short*, const float*, const float*, const float*, float*, hipStream_t);
 int episode_gather_launch(const float*, const int64_t*, const float*, int64_t, int64_t, int64_t, int64_t, int64_t, float, float*, float*, hipStream_t);
+int conv_gather_gemm_pair_launch(const MtrssmConvGeom*, const float*, const float*, const float*, const unsigned short*, const float*, const float*, const float*, float*,
+                                 const MtrssmConvGeom*, const float*, const float*, const float*, const unsigned short*, const float*, const float*, const float*, float*, hipStream_t);
 int pack_conv_weight_launch(const float*, int, int, int, int, long, long, long, long, int, int, int, float*, unsigned short*, hipStream_t);
 int conv_weight_grad_launch(const MtrssmConvGeom*, const float*, const float*, const float*, int, float*, float*, hipStream_t);
 int channel_sum_launch(const float*, int, int, int, float*, hipStream_t);
@@ -76,6 +78,13 @@ MTRSSM_API int mtrssm_conv_gather_gemm(const MtrssmConvGeom* g, const float* src
 MTRSSM_API int mtrssm_episode_gather(const float* store, const int64_t* idx, const float* noise, int64_t n_episodes, int64_t B, int64_t T,
                                      int64_t Tfull, int64_t E, float std_, float* input, float* target, void* stream) {
   return episode_gather_launch(store, idx, noise, n_episodes, B, T, Tfull, E, std_, input, target, static_cast<hipStream_t>(stream));
+}
+MTRSSM_API int mtrssm_conv_gather_gemm_pair(const MtrssmConvGeom* ga, const float* srca, const float* src2a, const float* wpa, const uint16_t* wqa,
+                                            const float* biasa, const float* actgrada, const float* adda, float* outa,
+                                            const MtrssmConvGeom* gb, const float* srcb, const float* src2b, const float* wpb, const uint16_t* wqb,
+                                            const float* biasb, const float* actgradb, const float* addb, float* outb, void* stream) {
+  return conv_gather_gemm_pair_launch(ga, srca, src2a, wpa, wqa, biasa, actgrada, adda, outa, gb, srcb, src2b, wpb, wqb, biasb, actgradb, addb,
+                                      outb, static_cast<hipStream_t>(stream));
 }
 MTRSSM_API int mtrssm_pack_conv_weight(const float* w, int32_t O, int32_t I, int32_t KH, int32_t KW, int64_t so, int64_t si, int64_t sh,
                                        int64_t sw, int32_t OPad, int32_t IPad, int32_t pieces, float* wp, uint16_t* wq, void* stream) {

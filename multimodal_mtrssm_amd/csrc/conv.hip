@@ -1024,6 +1024,106 @@ static int launched(const char* who) {
   return MTRSSM_OK;
 }
 
+// ---- split-bf16 gather kernels: plan (which kernel, which tiling) and launch of one or two problems
+struct SplitPlan {
+  int kind = 0;  // 0: not covered, 1: conv1x1_split_kernel, 2: conv_gather_split_kernel
+  int tco = 0, ny = 0, nx = 0, sp = 0, pit = 0, tgs = 0, ngroups = 0;
+  size_t lds = 0;
+  bool same_kernel(const SplitPlan& o) const {
+    return kind == o.kind && kind != 0 && tco == o.tco && ny == o.ny && sp == o.sp && pit == o.pit && tgs == o.tgs && ngroups == o.ngroups;
+  }
+};
+
+static SplitPlan plan_split(const MtrssmConvGeom* g, bool has_wq) {
+  SplitPlan pl;
+  if (!(g->mfma_split > 0 && has_wq) || !((g->TS == 1 || g->TS == -1) && g->KH * g->KW > 0 && plane_fits_26bit(g))) return pl;
+  if (g->Wq > kTP || kTP % g->Wq) return pl;
+  const PatchGeom pg(*g, kTP);
+  const bool tiles = (g->Hq % pg.rpg == 0) || (pg.rpg % g->Hq == 0);
+  if (!tiles || pg.ipg >= 32) return pl;
+  const long ptot = (long)g->N * g->Hq * g->Wq;
+  const int sp = g->mfma_split, taps = g->KH * g->KW;
+  pl.tco = g->Cout > 32 ? 64 : 32;
+  pl.ny = g->CoutPad / pl.tco;
+  pl.nx = (int)((ptot + kTP - 1) / kTP);
+  pl.sp = sp;
+  if ((long)g->N * g->Cout * g->Ho * g->Wo >= (1L << 31)) return pl;
+  if (taps == 1 && g->SS == 1 && g->OS == 1 && g->OFFY == 0 && g->OFFX == 0 && g->C2 == 0 && g->Hs == g->Hq && g->Ws == g->Wq &&
+      g->Ho == g->Hq && g->Wo == g->Wq && g->Cpad % 64 == 0) {  // 1x1 layers: 64 channels per step
+    pl.kind = 1;
+    pl.lds = (size_t)sp * (kTP + pl.tco) * 128;
+    return pl;
+  }
+  auto lds_of = [&](int t) { return (size_t)sp * ((size_t)pg.ps_raw * kRowB + (size_t)t * pl.tco * kRowB); };
+  int tgs = 1;  // largest divisor of taps within the register / LDS budget
+  for (int t = 1; t <= split_tg(sp) && t <= taps; ++t)
+    if (taps % t == 0 && lds_of(t) <= 80 * 1024) tgs = t;
+  pl.tgs = tgs;
+  pl.ngroups = taps / tgs;
+  pl.lds = lds_of(tgs);
+  pl.pit = pg.ps_raw <= 384 ? 3 : 6;
+  // larger patches (the k=4 s=2 backward-data gathers, 648 positions) measured faster on the fp32 kernel
+  if (pl.lds <= 80 * 1024 && pg.ps_raw <= 640 && (long)pg.ipg * g->C * g->Hs * g->Ws < (1L << 31) &&
+      (long)sp * g->CoutPad * taps * g->Cpad < (1L << 31))
+    pl.kind = 2;
+  return pl;
+}
+
+static GatherProblem make_problem(const MtrssmConvGeom* g, const SplitPlan& pl, const float* src, const float* src2, const unsigned short* wq,
+                                  const float* bias, const float* actgrad_in, const float* add_in, float* out) {
+  GatherProblem p;
+  p.g = *g; p.src = src; p.src2 = src2; p.wq = wq; p.bias = bias; p.actgrad_in = actgrad_in; p.add_in = add_in; p.out = out;
+  p.tg = pl.tgs; p.ngroups = pl.ngroups; p.nx = pl.nx;
+  return p;
+}
+
+// launches pa (and pb when pb.nx > 0: same kernel, its workgroups appended to the grid)
+static int launch_split(const SplitPlan& pl, size_t lds, const GatherProblem& pa, const GatherProblem& pb, hipStream_t stream) {
+  const dim3 grid((unsigned)(pa.nx + pb.nx), pl.ny);
+  const int sp = pl.sp;
+#define MTRSSM_ATTR_ONCE(K_)                                                                                         \
+  {                                                                                                                   \
+    static bool attr_done = false;                                                                                    \
+    if (!attr_done) {                                                                                                 \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(K_), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
+      attr_done = true;                                                                                               \
+    }                                                                                                                 \
+  }
+  if (pl.kind == 1) {
+#define MTRSSM_1X1_LAUNCH(NT_, SP_)                                                                                  \
+  {                                                                                                                   \
+    MTRSSM_ATTR_ONCE((conv1x1_split_kernel<NT_, SP_>))                                                               \
+    set_last_kernel("mtrssm::conv1x1_split_kernel<" #NT_ ", " #SP_ ">");                                               \
+    hipLaunchKernelGGL((conv1x1_split_kernel<NT_, SP_>), grid, dim3(kConvThreads), lds, stream, pa, pb);              \
+    return launched("conv_gather_gemm(1x1)");                                                                         \
+  }
+    if (pl.tco == 64) { if (sp == 3) MTRSSM_1X1_LAUNCH(2, 3) else if (sp == 2) MTRSSM_1X1_LAUNCH(2, 2) else MTRSSM_1X1_LAUNCH(2, 1) }
+    else { if (sp == 3) MTRSSM_1X1_LAUNCH(1, 3) else if (sp == 2) MTRSSM_1X1_LAUNCH(1, 2) else MTRSSM_1X1_LAUNCH(1, 1) }
+#undef MTRSSM_1X1_LAUNCH
+  }
+#define MTRSSM_SPLIT_LAUNCH(NT_, SP_, PIT_)                                                                          \
+  {                                                                                                                   \
+    MTRSSM_ATTR_ONCE((conv_gather_split_kernel<NT_, SP_, PIT_>))                                                     \
+    set_last_kernel("mtrssm::conv_gather_split_kernel<" #NT_ ", " #SP_ ", " #PIT_ ">");                                \
+    hipLaunchKernelGGL((conv_gather_split_kernel<NT_, SP_, PIT_>), grid, dim3(kConvThreads), lds, stream, pa, pb);    \
+    return launched("conv_gather_gemm(split)");                                                                       \
+  }
+  const int pit = pl.pit;
+  if (pl.tco == 64) {
+    if (sp == 3) { if (pit == 3) MTRSSM_SPLIT_LAUNCH(2, 3, 3) else MTRSSM_SPLIT_LAUNCH(2, 3, 6) }
+    else if (sp == 2) { if (pit == 3) MTRSSM_SPLIT_LAUNCH(2, 2, 3) else MTRSSM_SPLIT_LAUNCH(2, 2, 6) }
+    else { if (pit == 3) MTRSSM_SPLIT_LAUNCH(2, 1, 3) else MTRSSM_SPLIT_LAUNCH(2, 1, 6) }
+  } else {
+    if (sp == 3) { if (pit == 3) MTRSSM_SPLIT_LAUNCH(1, 3, 3) else MTRSSM_SPLIT_LAUNCH(1, 3, 6) }
+    else if (sp == 2) { if (pit == 3) MTRSSM_SPLIT_LAUNCH(1, 2, 3) else MTRSSM_SPLIT_LAUNCH(1, 2, 6) }
+    else { if (pit == 3) MTRSSM_SPLIT_LAUNCH(1, 1, 3) else MTRSSM_SPLIT_LAUNCH(1, 1, 6) }
+  }
+#undef MTRSSM_SPLIT_LAUNCH
+#undef MTRSSM_ATTR_ONCE
+  set_error("conv_gather_gemm: no split kernel for this plan");
+  return MTRSSM_EINVAL;
+}
+
 int pack_conv_weight_launch(const float* w, int O, int I, int KH, int KW, long so, long si, long sh, long sw, int OPad, int IPad,
                             int pieces, float* wp, unsigned short* wq, hipStream_t stream) {
   if (!w || !wp || O <= 0 || I <= 0 || KH < 0 || KW < 0 || OPad < O || IPad < I || pieces < 0 || pieces > 3 || (pieces > 0 && !wq)) {
@@ -1070,66 +1170,12 @@ int conv_gather_gemm_launch(const MtrssmConvGeom* g, const float* src, const flo
       const long nx = (ptot + tpx - 1) / tpx;
       if (!tiles || pg.ipg >= 32) continue;
       const dim3 grid((unsigned)nx, ny);
-      if (g->mfma_split > 0 && wq && g->KH * g->KW == 1 && g->SS == 1 && g->OS == 1 && g->OFFY == 0 && g->OFFX == 0 && g->C2 == 0 &&
-          g->Hs == g->Hq && g->Ws == g->Wq && g->Ho == g->Hq && g->Wo == g->Wq && g->Cpad % 64 == 0 &&
-          (long)g->N * g->Cout * g->Ho * g->Wo < (1L << 31)) {
-        // 1x1 layers: 64 channels per step (conv_split.h: conv1x1_split_kernel)
-        const int sp = g->mfma_split;
-        const size_t lds_1 = (size_t)sp * (kTP + tco) * 128;
-        const dim3 grid1((unsigned)((ptot + kTP - 1) / kTP), ny);
-#define MTRSSM_1X1_LAUNCH(NT_, SP_)                                                                                            \
-  {                                                                                                                             \
-    static bool attr_done = false;                                                                                              \
-    if (!attr_done) {                                                                                                           \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_split_kernel<NT_, SP_>),                                  \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);                                         \
-      attr_done = true;                                                                                                         \
-    }                                                                                                                           \
-    set_last_kernel("mtrssm::conv1x1_split_kernel<" #NT_ ", " #SP_ ">");                                                         \
-    hipLaunchKernelGGL((conv1x1_split_kernel<NT_, SP_>), grid1, dim3(kConvThreads), lds_1, stream, *g, src, wq, bias, actgrad_in,  \
-                       add_in, out);                                                                                            \
-    return launched("conv_gather_gemm(1x1)");                                                                                   \
-  }
-        if (tco == 64) { if (sp == 3) MTRSSM_1X1_LAUNCH(2, 3) else if (sp == 2) MTRSSM_1X1_LAUNCH(2, 2) else MTRSSM_1X1_LAUNCH(2, 1) }
-        else { if (sp == 3) MTRSSM_1X1_LAUNCH(1, 3) else if (sp == 2) MTRSSM_1X1_LAUNCH(1, 2) else MTRSSM_1X1_LAUNCH(1, 1) }
-#undef MTRSSM_1X1_LAUNCH
-      }
-      if (g->mfma_split > 0 && wq) {
-        const int sp = g->mfma_split;
-        const int taps = g->KH * g->KW;
-        const int tg_cap = split_tg(sp);
-        auto lds_of = [&](int t) { return (size_t)sp * ((size_t)pg.ps_raw * kRowB + (size_t)t * tco * kRowB); };
-        int tgs = 1;  // largest divisor of taps within the register / LDS budget
-        for (int t = 1; t <= tg_cap && t <= taps; ++t)
-          if (taps % t == 0 && lds_of(t) <= 80 * 1024) tgs = t;
-        const int ngroups = taps / tgs;
-        const size_t lds_s = lds_of(tgs);
-        const int pit = pg.ps_raw <= 384 ? 3 : 6;
-        if (lds_s <= 80 * 1024 && pg.ps_raw <= 640 &&  /* larger patches (the k=4 s=2 backward-data gathers, 648 positions) measured faster on the fp32 kernel */ (sp >= 1 && sp <= 3) && (long)pg.ipg * g->C * g->Hs * g->Ws < (1L << 31) &&
-            (long)g->N * g->Cout * g->Ho * g->Wo < (1L << 31) && (long)sp * g->CoutPad * taps * g->Cpad < (1L << 31)) {
-#define MTRSSM_SPLIT_LAUNCH(NT_, SP_, PIT_)                                                                                     \
-  {                                                                                                                             \
-    static bool attr_done = false;                                                                                              \
-    if (!attr_done) {                                                                                                           \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gather_split_kernel<NT_, SP_, PIT_>),                        \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);                                         \
-      attr_done = true;                                                                                                         \
-    }                                                                                                                           \
-    set_last_kernel("mtrssm::conv_gather_split_kernel<" #NT_ ", " #SP_ ", " #PIT_ ">");                                          \
-    hipLaunchKernelGGL((conv_gather_split_kernel<NT_, SP_, PIT_>), grid, dim3(kConvThreads), lds_s, stream, *g, src, src2, wq,   \
-                       bias, actgrad_in, add_in, out, tgs, ngroups);                                                            \
-  }
-          if (tco == 64) {
-            if (sp == 3) { if (pit == 3) MTRSSM_SPLIT_LAUNCH(2, 3, 3) else MTRSSM_SPLIT_LAUNCH(2, 3, 6) }
-            else if (sp == 2) { if (pit == 3) MTRSSM_SPLIT_LAUNCH(2, 2, 3) else MTRSSM_SPLIT_LAUNCH(2, 2, 6) }
-            else { if (pit == 3) MTRSSM_SPLIT_LAUNCH(2, 1, 3) else MTRSSM_SPLIT_LAUNCH(2, 1, 6) }
-          } else {
-            if (sp == 3) { if (pit == 3) MTRSSM_SPLIT_LAUNCH(1, 3, 3) else MTRSSM_SPLIT_LAUNCH(1, 3, 6) }
-            else if (sp == 2) { if (pit == 3) MTRSSM_SPLIT_LAUNCH(1, 2, 3) else MTRSSM_SPLIT_LAUNCH(1, 2, 6) }
-            else { if (pit == 3) MTRSSM_SPLIT_LAUNCH(1, 1, 3) else MTRSSM_SPLIT_LAUNCH(1, 1, 6) }
-          }
-#undef MTRSSM_SPLIT_LAUNCH
-          return launched("conv_gather_gemm(split)");
+      {
+        const SplitPlan pl = plan_split(g, wq != nullptr);
+        if (pl.kind != 0) {
+          GatherProblem none{};
+          none.nx = 0;
+          return launch_split(pl, pl.lds, make_problem(g, pl, src, src2, wq, bias, actgrad_in, add_in, out), none, stream);
         }
       }
       if (lds > 64 * 1024) continue;
@@ -1149,6 +1195,27 @@ int conv_gather_gemm_launch(const MtrssmConvGeom* g, const float* src, const flo
     { set_last_kernel("mtrssm::conv_gather_gemm_kernel<1>"); hipLaunchKernelGGL(conv_gather_gemm_kernel<1>, grid, dim3(kConvThreads), 0, stream, *g, src, src2, wp, bias, actgrad_in, add_in, out); }
   }
   return launched("conv_gather_gemm");
+}
+
+// Two gather problems in one launch when they map to the same split kernel (the audio and the vision branch of one layer);
+// otherwise two launches.
+int conv_gather_gemm_pair_launch(const MtrssmConvGeom* ga, const float* srca, const float* src2a, const float* wpa, const unsigned short* wqa,
+                                 const float* biasa, const float* actgrada, const float* adda, float* outa, const MtrssmConvGeom* gb,
+                                 const float* srcb, const float* src2b, const float* wpb, const unsigned short* wqb, const float* biasb,
+                                 const float* actgradb, const float* addb, float* outb, hipStream_t stream) {
+  if (ga && gb && srca && srcb && outa && outb && !check_geom(ga, "conv_gather_gemm_pair") && !check_geom(gb, "conv_gather_gemm_pair") &&
+      !(ga->C2 > 0 && !src2a) && !(gb->C2 > 0 && !src2b)) {
+    const bool thin_a = (ga->Cout <= 8 || ga->C + ga->C2 <= 2) && ga->Cout <= 16;
+    const bool thin_b = (gb->Cout <= 8 || gb->C + gb->C2 <= 2) && gb->Cout <= 16;
+    if (!thin_a && !thin_b) {
+      const SplitPlan pa = plan_split(ga, wqa != nullptr), pb = plan_split(gb, wqb != nullptr);
+      if (pa.same_kernel(pb))
+        return launch_split(pa, pa.lds > pb.lds ? pa.lds : pb.lds, make_problem(ga, pa, srca, src2a, wqa, biasa, actgrada, adda, outa),
+                            make_problem(gb, pb, srcb, src2b, wqb, biasb, actgradb, addb, outb), stream);
+    }
+  }
+  if (int rc = conv_gather_gemm_launch(ga, srca, src2a, wpa, wqa, biasa, actgrada, adda, outa, stream)) return rc;
+  return conv_gather_gemm_launch(gb, srcb, src2b, wpb, wqb, biasb, actgradb, addb, outb, stream);
 }
 
 int channel_sum_launch(const float* x, int N, int C, int HW, float* out, hipStream_t stream);

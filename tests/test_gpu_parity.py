@@ -448,6 +448,62 @@ def test_two_stream_branches_change_nothing(lib_loaded: None) -> None:
         np.testing.assert_allclose(_np(runs[True][1][k]), _np(g), rtol=1e-5, atol=2e-6 * scale, err_msg=k)
 
 
+def test_paired_launches_change_nothing(lib_loaded: None) -> None:
+    """conv.paired (the audio and the vision stack's equal layers in one launch, the default) against one launch per
+    layer: the gathers are the same arithmetic per output tile, so forward values are bit-identical; gradients are equal
+    up to the arrival order of the weight-gradient kernels' fp32 atomics."""
+    from multimodal_mtrssm_amd import conv
+
+    # (1) the merged kernel itself, at a shape the split MFMA kernels take (64 -> 64 channels, 3x3 and 1x1)
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    def rnd(*shape: int, scale: float = 1.0) -> torch.Tensor:
+        return (torch.randn(*shape, generator=gen) * scale).to(DEV).requires_grad_(True)
+    res = {}
+    for paired in (False, True):
+        conv.PAIR_LAUNCH = paired
+        try:
+            gen.manual_seed(11)
+            xa, xv = rnd(96, 64, 16, 16), rnd(96, 64, 16, 16)
+            pa = (rnd(32, 64, 3, 3, scale=0.05), rnd(32, scale=0.1), rnd(64, 32, 1, 1, scale=0.1), rnd(64, scale=0.1))
+            pv = (rnd(32, 64, 3, 3, scale=0.05), rnd(32, scale=0.1), rnd(64, 32, 1, 1, scale=0.1), rnd(64, scale=0.1))
+            ya, yv = conv.residual_block_pair(xa, pa, xv, pv, act=1)
+            (ya.square().sum() + yv.sin().sum()).backward()
+            torch.cuda.synchronize()
+            res[paired] = [ya.detach(), yv.detach(), xa.grad, xv.grad, *(t.grad for t in pa), *(t.grad for t in pv)]
+        finally:
+            conv.PAIR_LAUNCH = True
+    for i, (a, b) in enumerate(zip(res[True], res[False], strict=True)):
+        if i < 4:
+            assert torch.equal(a, b), i
+        else:
+            np.testing.assert_allclose(_np(a), _np(b), rtol=1e-5, atol=2e-6 * float(b.abs().max()), err_msg=str(i))
+    # and against the unpaired single-block node
+    ya1 = conv.residual_block(xa.detach(), *(t.detach() for t in pa), act=1)
+    assert torch.equal(ya1, res[True][0])
+
+    # (2) the whole train step
+    case = CASES["mrssm_default"]
+    fx = load_golden("mrssm_default")
+    batch, noise = tuple(b.to(DEV) for b in golden_batch(fx)), _to(golden_noise(fx), DEV)
+    runs = {}
+    for paired in (False, True):
+        conv.PAIR_LAUNCH = paired
+        try:
+            model = product_from_case(case, build_model(case), DEV)
+            model.zero_grad(set_to_none=True)
+            out = model.shared_step(batch, noise)
+            out["loss"].backward()
+            torch.cuda.synchronize()
+            runs[paired] = ({k: float(v) for k, v in out.items()}, {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+        finally:
+            conv.PAIR_LAUNCH = True
+    for k, v in runs[False][0].items():
+        np.testing.assert_allclose(runs[True][0][k], v, rtol=2e-6, err_msg=k)
+    for k, g in runs[False][1].items():
+        scale = float(g.abs().max()) + 1e-12
+        np.testing.assert_allclose(_np(runs[True][1][k]), _np(g), rtol=1e-5, atol=2e-6 * scale, err_msg=k)
+
+
 def test_fp32_mfma_mode_train_step_matches_golden(lib_loaded: None) -> None:
     """The whole train step with the fp32 MFMA conv kernels ("f32" mode; every other GPU test of the step runs in the
     default "bf16x2" mode): same golden losses, same tolerance."""
