@@ -213,6 +213,24 @@ def _conv_transposed_gather(y: Tensor, w: Tensor, bias: Tensor | None, stride: i
     return out
 
 
+# Accumulation targets of the weight-gradient kernels (fp32 atomics) must start at zero.  They are carved out of a zeroed
+# chunk -- one fill per chunk instead of one per tensor (the train step has ~90 such targets of a few KB each); a chunk is
+# never handed out twice and is freed by the allocator when the last view of it dies.
+_ZERO_CHUNK_FLOATS = 2 << 20
+_ZERO_CHUNKS: dict[tuple, list] = {}
+
+
+def _zeros(n: int, device: torch.device) -> Tensor:
+    need = (n + 63) // 64 * 64  # 256-byte aligned slices
+    key = (device, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
+    st = _ZERO_CHUNKS.get(key)
+    if st is None or st[1] + need > st[0].numel():
+        st = _ZERO_CHUNKS[key] = [torch.zeros(max(_ZERO_CHUNK_FLOATS, need), device=device, dtype=torch.float32), 0]
+    out = st[0][st[1] : st[1] + n]
+    st[1] += need
+    return out
+
+
 def _weight_grad(a: Tensor, src: Tensor, coords: Tensor | None, kh: int, kw: int, stride: int, pad: int, pre_act_a: bool,
                  pre_act_src: bool, act: int, *, want_bias: bool = False) -> tuple[Tensor, Tensor | None]:  # noqa: FBT001
     """``dw[o][i][ky][kx] = sum preA(a)[n,o,y,x] * pre(src ++ coords)[n,i,y*s-p+ky,x*s-p+kx]`` -> ``[O][I][kh][kw]``.
@@ -223,8 +241,8 @@ def _weight_grad(a: Tensor, src: Tensor, coords: Tensor | None, kh: int, kw: int
     _, c, hs, ws = src.shape
     c2 = 0 if coords is None else coords.shape[0]
     opad, ipad = _pads(o, c + c2)
-    dwp = torch.zeros(opad, kh * kw, ipad, device=a.device, dtype=torch.float32)
-    dbias = torch.zeros(o, device=a.device, dtype=torch.float32) if want_bias else None
+    dwp = _zeros(opad * kh * kw * ipad, a.device).view(opad, kh * kw, ipad)
+    dbias = _zeros(o, a.device) if want_bias else None
     geom = _geom(N=n, C=c, Hs=hs, Ws=ws, C2=c2, Cpad=ipad, KH=kh, KW=kw, SS=stride, TS=1, OFFY=-pad, OFFX=-pad, Hq=hq, Wq=wq,
                  OS=1, QY=0, QX=0, Ho=hq, Wo=wq, Cout=o, CoutPad=opad, pre_act=int(pre_act_src), act=act)
     flops = 2.0 * n * hq * wq * o * kh * kw * (c + c2)
@@ -239,7 +257,7 @@ def _weight_grad(a: Tensor, src: Tensor, coords: Tensor | None, kh: int, kw: int
 def _channel_sum(x: Tensor) -> Tensor:
     lib = _lib.load()
     n, c, h, w = x.shape
-    out = torch.zeros(c, device=x.device, dtype=torch.float32)
+    out = _zeros(c, x.device)
     _lib.check(_lib.TIMERS.call("mtrssm_channel_sum", lib.mtrssm_channel_sum, _lib.ptr(x), n, c, h * w, _lib.ptr(out),
                                 _lib.stream_ptr(x.device)), "mtrssm_channel_sum")
     return out
