@@ -376,6 +376,12 @@ int mtrssm_conv_gather_gemm_pair(const MtrssmConvGeom* ga, const float* srca, co
  *   (thin / odd-geometry layers always read wp). */
 int mtrssm_pack_conv_weight(const float* w, int32_t O, int32_t I, int32_t KH, int32_t KW, int64_t so, int64_t si, int64_t sh,
                             int64_t sw, int32_t OPad, int32_t IPad, int32_t pieces, float* wp, uint16_t* wq, void* stream);
+/* The same for `count` weights in one launch (the train step packs every conv weight once, in both the forward and the
+ * backward-data layout, right after the optimizer changed them).  `table` is DEVICE memory: MTRSSM_PACK_DESC_WORDS int64 words
+ * per weight = { w, wp, wq (addresses), O, I, KH, KW, so, si, sh, sw, OPad, IPad, pieces, 0, 0 } with the meanings above;
+ * blocks_per_weight workgroups of 256 threads stride over each weight. */
+#define MTRSSM_PACK_DESC_WORDS 16
+int mtrssm_pack_conv_weights(const int64_t* table, int32_t count, int32_t blocks_per_weight, void* stream);
 int mtrssm_conv_weight_grad(const MtrssmConvGeom* g, const float* a, const float* src, const float* src2,
                             int32_t pre_act_a, float* dwp, float* dbias, void* stream);
 /* Last decoder layer (default.yaml:70-74, channels [.., 1]): out[N, Cout<=2, 2Hs, 2Ws] = bias + ConvTranspose2d_{k=4,s=2,p=1}(pre(src[N,C,Hs,Ws]))

@@ -35,33 +35,118 @@ _PACK_BUFFERS: dict[tuple, tuple[Tensor, Tensor | None]] = {}
 # Paired launches: the audio and the vision stack run the same layer on different planes; inside
 # ``paired()`` the gather launches are collected instead of issued and then go out two per launch
 # (``mtrssm_conv_gather_gemm_pair``), the k-th launch of the first callable with the k-th of the second.
-PAIR_LAUNCH = True
+PAIR_LAUNCH = os.environ.get("MTRSSM_PAIR_LAUNCH", "1") != "0"
 _DEFER: list[tuple] | None = None
+
+
+def _pack_buffers(w: Tensor) -> tuple[Tensor, Tensor | None]:
+    o, i, kh, kw = w.shape
+    opad, ipad = _pads(o, i)
+    wp = torch.zeros(opad, kh * kw, ipad, device=w.device, dtype=torch.float32)
+    wq = torch.zeros(_MFMA_SPLIT, opad, kh * kw, ipad, device=w.device, dtype=torch.int16) if _MFMA_SPLIT else None
+    return wp, wq
+
+
+def _pack_now(w: Tensor, wp: Tensor, wq: Tensor | None) -> None:
+    o, i, kh, kw = w.shape
+    so, si, sh, sw = w.stride()
+    _lib.check(_lib.TIMERS.call("mtrssm_pack_conv_weight", _lib.load().mtrssm_pack_conv_weight, _lib.raw_ptr(w), o, i, kh, kw, so, si,
+                                sh, sw, wp.shape[0], wp.shape[2], 0 if wq is None else wq.shape[0], _lib.ptr(wp), _lib.raw_ptr(wq),
+                                _lib.stream_ptr(w.device)), "mtrssm_pack_conv_weight")
+
+
+class _PackPlan:
+    """Every conv weight of a step packed by ONE launch (``mtrssm_pack_conv_weights``) instead of one per use (96 in the
+    MoPoE-MRSSM train step).  ``begin_step()`` -- called by ``shared_step`` -- packs the weight views the previous step asked
+    for, each into buffers of its own; ``pack_weight`` then finds them there.  An entry is trusted only if it was packed in
+    the current epoch and the tensor's version counter has not moved since; ``invalidate()`` (called by ``FlatAdamW.step``,
+    which writes parameters through raw pointers) starts a new epoch.  Anything else is packed on the spot, as before."""
+
+    def __init__(self) -> None:
+        # key -> [w (strong ref: keeps the address valid), wp, wq, version, epoch packed, epoch used, serial]
+        self.entries: dict[tuple, list] = {}
+        self.epoch = 0
+        self.stream = -1  # the stream begin_step packed on: only launches on that stream may read its copies
+        self.serial = 0
+        self.table: Tensor | None = None
+        self.table_serials: tuple = ()
+
+    def invalidate(self) -> None:
+        self.epoch += 1
+
+    @staticmethod
+    def key(w: Tensor) -> tuple:
+        return (w.data_ptr(), tuple(w.shape), w.stride(), _MFMA_SPLIT, w.device)
+
+    def begin_step(self, device: torch.device) -> None:
+        self.epoch += 1
+        # keep what the last step used (weights of modules that went away leave with their strong reference)
+        self.entries = {k: e for k, e in self.entries.items() if e[5] >= self.epoch - 2}
+        self.stream = torch.cuda.current_stream(device).cuda_stream
+        live = [(k, e) for k, e in self.entries.items() if k[4] == device and k[3] == _MFMA_SPLIT]
+        if not live:
+            return
+        serials = tuple(e[6] for _, e in live)
+        if serials != self.table_serials or self.table is None or self.table.device != device:
+            rows = []
+            for _, (w, wp, wq, *_rest) in live:
+                o, i, kh, kw = w.shape
+                rows.append([w.data_ptr(), wp.data_ptr(), 0 if wq is None else wq.data_ptr(), o, i, kh, kw, *w.stride(), wp.shape[0],
+                             wp.shape[2], 0 if wq is None else wq.shape[0], 0, 0])
+            self.table = torch.tensor(rows, dtype=torch.int64).to(device)
+            self.table_serials = serials
+        _lib.check(_lib.TIMERS.call("mtrssm_pack_conv_weights", _lib.load().mtrssm_pack_conv_weights, _lib.raw_ptr(self.table), len(live),
+                                    8, _lib.stream_ptr(device)), "mtrssm_pack_conv_weights")
+        for _, e in live:
+            e[3], e[4] = e[0]._version, self.epoch
+
+    def get(self, w: Tensor) -> tuple[Tensor, Tensor | None]:
+        k = self.key(w)
+        e = self.entries.get(k)
+        if e is None:
+            self.serial += 1
+            e = self.entries[k] = [w, *_pack_buffers(w), -1, -1, self.epoch, self.serial]
+        if e[4] != self.epoch or e[3] != w._version:
+            _pack_now(w, e[1], e[2])
+            e[3], e[4] = w._version, self.epoch
+        e[5] = self.epoch
+        return e[1], e[2]
+
+
+PACK_PLAN = os.environ.get("MTRSSM_PACK_PLAN", "1") != "0"
+_PLAN = _PackPlan()
+
+
+def begin_step(device: torch.device) -> None:
+    """Start of a train / validation step: pack every conv weight the previous step used, in one launch."""
+    if PACK_PLAN and device.type == "cuda":
+        _PLAN.begin_step(device)
+
+
+def invalidate_packs() -> None:
+    """Parameters were written behind autograd's back (``FlatAdamW.step``): packed copies are stale."""
+    _PLAN.invalidate()
 
 
 def pack_weight(w: Tensor) -> tuple[Tensor, Tensor | None]:
     """``w[O][I][kh][kw]`` (any strided view) -> zero-padded fp32 ``wp[OPad][kh*kw][IPad]`` (channel fastest) and, in a
-    bf16 MFMA mode, its bf16 pieces ``wq[pieces][OPad][kh*kw][IPad]`` (one ``mtrssm_pack_conv_weight`` launch).
+    bf16 MFMA mode, its bf16 pieces ``wq[pieces][OPad][kh*kw][IPad]`` (``mtrssm_pack_conv_weight``).
 
-    The buffers are cached per (shape, device, stream): every use is "pack, then enqueue the kernel that reads it" on
-    one stream, so a later pack of another same-shaped layer cannot overtake the earlier kernel.
+    Inside a step announced by ``begin_step`` the copies come from the step's one pack launch (``_PackPlan``).  Otherwise
+    the buffers are cached per (shape, device, stream): every use is "pack, then enqueue the kernel that reads it" on one
+    stream, so a later pack of another same-shaped layer cannot overtake the earlier kernel.
     """
     o, i, kh, kw = w.shape
-    opad, ipad = _pads(o, i)
+    if PACK_PLAN and w.is_cuda and kh * kw > 0 and torch.cuda.current_stream(w.device).cuda_stream == _PLAN.stream:
+        return _PLAN.get(w)
     slot = len(_DEFER) if _DEFER is not None else 0  # deferred (paired) launches: one buffer per pending job
     key = (o, i, kh, kw, _MFMA_SPLIT, slot, w.device, torch.cuda.current_stream(w.device).cuda_stream if w.is_cuda else 0)
     bufs = _PACK_BUFFERS.get(key)
     if bufs is None:
-        wp = torch.zeros(opad, kh * kw, ipad, device=w.device, dtype=torch.float32)
-        wq = torch.zeros(_MFMA_SPLIT, opad, kh * kw, ipad, device=w.device, dtype=torch.int16) if _MFMA_SPLIT else None
-        bufs = _PACK_BUFFERS[key] = (wp, wq)
-    wp, wq = bufs
+        bufs = _PACK_BUFFERS[key] = _pack_buffers(w)
     if kh * kw > 0:
-        so, si, sh, sw = w.stride()
-        _lib.check(_lib.TIMERS.call("mtrssm_pack_conv_weight", _lib.load().mtrssm_pack_conv_weight, _lib.raw_ptr(w), o, i, kh, kw, so, si,
-                                    sh, sw, opad, ipad, _MFMA_SPLIT, _lib.ptr(wp), _lib.raw_ptr(wq), _lib.stream_ptr(w.device)),
-                   "mtrssm_pack_conv_weight")
-    return wp, wq
+        _pack_now(w, *bufs)
+    return bufs
 
 
 # MFMA operand format of the patch-staged kernels (``MtrssmConvGeom.mfma_split``, include/mtrssm.h)

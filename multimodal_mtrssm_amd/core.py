@@ -272,6 +272,7 @@ class MoPoE_MRSSM(_Base):  # noqa: N801
         action_input = batch[0]
         audio_obs, vision_obs = self.get_observations_from_batch(batch)
         bound_run_ahead(audio_obs.device)
+        conv.begin_step(audio_obs.device)
         audio_embed, vision_embed = self._encode_both(audio_obs, vision_obs)
         u_init = None if noise is None else noise.get("u_init")
         state0 = self._initial_from_embed((audio_embed[:, 0] + vision_embed[:, 0]) / 2.0, u_init)
@@ -433,6 +434,7 @@ class MoPoE_MMTRSSM(MoPoE_MRSSM):  # noqa: N801
         action_input = batch[0]
         audio_obs, vision_obs = self.get_observations_from_batch(batch)
         bound_run_ahead(audio_obs.device)
+        conv.begin_step(audio_obs.device)
         audio_embed, vision_embed = self._encode_both(audio_obs, vision_obs)
         state0 = self._initial_from_embed((audio_embed[:, 0] + vision_embed[:, 0]) / 2.0, noise)
         out = self._rollout_embedded(action_input, audio_embed, vision_embed, state0, noise, sample_prior=False)

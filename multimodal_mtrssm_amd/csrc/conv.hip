@@ -1138,6 +1138,17 @@ int pack_conv_weight_launch(const float* w, int O, int I, int KH, int KW, long s
   return launched("pack_conv_weight");
 }
 
+int pack_conv_weights_launch(const int64_t* table, int count, int blocks_per_weight, hipStream_t stream) {
+  if (count == 0) return MTRSSM_OK;
+  if (!table || count < 0 || count > 65535 || blocks_per_weight < 1 || blocks_per_weight > 1024) {
+    set_error("pack_conv_weights: bad argument");
+    return MTRSSM_EINVAL;
+  }
+  static_assert(sizeof(long) == sizeof(int64_t), "descriptor words are 64-bit");
+  { set_last_kernel("mtrssm::pack_conv_weights_kernel"); hipLaunchKernelGGL(pack_conv_weights_kernel, dim3(blocks_per_weight, count), dim3(256), 0, stream, reinterpret_cast<const long*>(table)); }
+  return launched("pack_conv_weights");
+}
+
 int conv_gather_gemm_launch(const MtrssmConvGeom* g, const float* src, const float* src2, const float* wp, const unsigned short* wq,
                             const float* bias, const float* actgrad_in, const float* add_in, float* out, hipStream_t stream) {
   if (int rc = check_geom(g, "conv_gather_gemm")) return rc;

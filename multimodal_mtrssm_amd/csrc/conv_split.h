@@ -57,11 +57,12 @@ __device__ __forceinline__ unsigned swz_row(int row, int half) { return (unsigne
 
 // w[o][i][ky][kx] (any element strides) -> wp fp32 [OPad][taps][IPad] zero padded, and (pieces > 0) the bf16 pieces
 // wq [pieces][OPad][taps][IPad] of the same values.
-__global__ void pack_conv_weight_kernel(const float* __restrict__ w, int O, int I, int KH, int KW, long so, long si, long sh, long sw,
-                                        int OPad, int IPad, int pieces, float* __restrict__ wp, unsigned short* __restrict__ wq) {
+__device__ __forceinline__ void pack_conv_weight_slice(const float* __restrict__ w, int O, int I, int KH, int KW, long so, long si,
+                                                       long sh, long sw, int OPad, int IPad, int pieces, float* __restrict__ wp,
+                                                       unsigned short* __restrict__ wq, long first, long step) {
   const int taps = KH * KW;
   const long total = (long)OPad * taps * IPad;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+  for (long idx = first; idx < total; idx += step) {
     const int i = (int)(idx % IPad);
     const long ot = idx / IPad;
     const int tap = (int)(ot % taps), o = (int)(ot / taps);
@@ -75,6 +76,21 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, int O, int 
       r -= (float)h;
     }
   }
+}
+
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, int O, int I, int KH, int KW, long so, long si, long sh, long sw,
+                                        int OPad, int IPad, int pieces, float* __restrict__ wp, unsigned short* __restrict__ wq) {
+  pack_conv_weight_slice(w, O, I, KH, KW, so, si, sh, sw, OPad, IPad, pieces, wp, wq, (long)blockIdx.x * blockDim.x + threadIdx.x,
+                         (long)gridDim.x * blockDim.x);
+}
+
+// Every conv weight of a train step in ONE launch: blockIdx.y walks a table of MTRSSM_PACK_DESC_WORDS int64 words per weight
+// (include/mtrssm.h: mtrssm_pack_conv_weights).
+__global__ void pack_conv_weights_kernel(const long* __restrict__ table) {
+  const long* d = table + (size_t)blockIdx.y * MTRSSM_PACK_DESC_WORDS;
+  pack_conv_weight_slice(reinterpret_cast<const float*>(d[0]), (int)d[3], (int)d[4], (int)d[5], (int)d[6], d[7], d[8], d[9], d[10],
+                         (int)d[11], (int)d[12], (int)d[13], reinterpret_cast<float*>(d[1]), reinterpret_cast<unsigned short*>(d[2]),
+                         (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
 }
 
 // One gather problem of a launch.  A launch carries two (the audio and the vision branch run the same layer on different planes):

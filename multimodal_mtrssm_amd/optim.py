@@ -20,7 +20,7 @@ from __future__ import annotations
 import torch
 from torch import Tensor, nn
 
-from multimodal_mtrssm_amd import _lib
+from multimodal_mtrssm_amd import _lib, conv
 
 
 class FlatParameters:
@@ -98,6 +98,7 @@ class FlatAdamW:
             _lib.ptr(f.param), _lib.ptr(f.grad), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq), f.numel,
             _lib.ptr(self.sumsq), float(self.clip_norm), float(grad_scale), lr, self.betas[0], self.betas[1], self.eps,
             self.weight_decay, self.steps, stream), "mtrssm_adamw_step")
+        conv.invalidate_packs()  # the parameters changed behind autograd's version counters
         return self.sumsq
 
     def state_dict(self) -> dict[str, object]:

@@ -16,6 +16,7 @@ import torch
 import torch.distributed as dist
 from torch import Tensor
 
+from multimodal_mtrssm_amd import conv
 from multimodal_mtrssm_amd.optim import FlatParameters
 
 
@@ -31,6 +32,7 @@ class FlatDataParallel:
         """Make every rank start from rank ``src``'s weights (one broadcast of the flat buffer)."""
         if self.active:
             dist.broadcast(self.flat.param, src=src, group=self.group)
+            conv.invalidate_packs()
 
     def shard(self, batch: tuple[Tensor, ...]) -> tuple[Tensor, ...]:
         """This rank's contiguous slice of the global batch (rows are independent: no halo)."""

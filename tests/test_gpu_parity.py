@@ -504,6 +504,45 @@ def test_paired_launches_change_nothing(lib_loaded: None) -> None:
         np.testing.assert_allclose(_np(runs[True][1][k]), _np(g), rtol=1e-5, atol=2e-6 * scale, err_msg=k)
 
 
+def test_step_pack_plan_changes_nothing(lib_loaded: None) -> None:
+    """conv._PackPlan (every conv weight of a step packed by one launch at the start of shared_step, the default) against
+    one pack launch per use: packing is a pure re-layout, so four optimizer steps give bit-identical forward values; also a
+    weight edited between begin_step and its use must be picked up (version counter), as must the optimizer's raw writes."""
+    from multimodal_mtrssm_amd import conv
+    from multimodal_mtrssm_amd.optim import FlatAdamW, FlatParameters
+
+    case = CASES["mrssm_default"]
+    fx = load_golden("mrssm_default")
+    batch, noise = tuple(b.to(DEV) for b in golden_batch(fx)), _to(golden_noise(fx), DEV)
+    losses = {}
+    for plan in (False, True):
+        conv.PACK_PLAN = plan
+        try:
+            model = product_from_case(case, build_model(case), DEV)
+            flat = FlatParameters(model)
+            opt = FlatAdamW(flat, lr=1e-3)
+            trace = []
+            for _ in range(4):
+                opt.zero_grad()
+                out = model.shared_step(batch, noise)
+                out["loss"].backward()
+                opt.step()
+                trace.append(float(out["loss"]))
+            with torch.no_grad():  # an edit autograd can see, after the step's pack launch
+                conv.begin_step(torch.device(DEV))
+                model.audio_encoder.res[0].conv3.weight.mul_(0.5)
+                trace.append(float(model.shared_step(batch, noise)["loss"]))
+            losses[plan] = trace
+        finally:
+            conv.PACK_PLAN = True
+    assert losses[True][0] == losses[False][0]
+    # later steps differ only by the arrival order of the weight-gradient atomics feeding the optimizer
+    np.testing.assert_allclose(losses[True], losses[False], rtol=2e-5)
+    assert losses[True][1] < losses[True][0]  # and the optimizer's updates were seen by the next step's packs
+    if conv.PACK_PLAN:
+        assert conv._PLAN.entries, "the plan was never used"  # noqa: SLF001
+
+
 def test_fp32_mfma_mode_train_step_matches_golden(lib_loaded: None) -> None:
     """The whole train step with the fp32 MFMA conv kernels ("f32" mode; every other GPU test of the step runs in the
     default "bf16x2" mode): same golden losses, same tolerance."""
