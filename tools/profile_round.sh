@@ -1,0 +1,25 @@
+#!/bin/bash
+# usage (on the GPU box): tools/profile_round.sh   -> gpurun_out/final/{stats,pmc_fetch,pmc_write}/ + bench_*.json
+# The passes behind profiles/round1_*: kernel trace + stats of the default bench command, the two HBM counter passes
+# (separately, as MI355X_MICROARCH.md prescribes), then one plain bench line per mode.
+set -o pipefail
+ROOT=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd $ROOT && export PYTHONPATH=$ROOT
+OUT=gpurun_out/final
+rm -rf $OUT && mkdir -p $OUT
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench --output-format csv -- python3 bench.py --steps 25 --warmup 3 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.log || exit 1
+echo stats done
+rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o f --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1 || exit 1
+rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o w --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1 || exit 1
+echo pmc done
+python3 tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_summary.json "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline" > /dev/null || exit 1
+timeout -k 10 300 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err || exit 1
+echo default done
+timeout -k 10 200 python3 bench.py --no-cpu-baseline --conv-mfma bf16x3 > $OUT/bench_bf16x3.json 2>/dev/null || exit 1
+timeout -k 10 200 python3 bench.py --no-cpu-baseline --conv-mfma bf16 > $OUT/bench_bf16.json 2>/dev/null || exit 1
+timeout -k 10 200 python3 bench.py --no-cpu-baseline --conv-mfma f32 > $OUT/bench_f32.json 2>/dev/null || exit 1
+timeout -k 10 200 python3 bench.py --no-cpu-baseline --model mmtrssm > $OUT/bench_mmtrssm.json 2>/dev/null || exit 1
+timeout -k 10 200 python3 bench.py --no-cpu-baseline --force-dist > $OUT/bench_force_dist.json 2>/dev/null || exit 1
+echo modes done
+find $OUT/pmc_fetch $OUT/pmc_write -name "*.csv" -size +2M -delete
+ls $OUT $OUT/stats/*
