@@ -1240,6 +1240,24 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
   const long ptot = (long)g->N * g->Hq * g->Wq;
   const int taps = g->KH * g->KW;
   const int ctot = g->C + g->C2;
+  if (g->mfma_split >= 1 && taps == 1 && g->SS == 1 && g->OFFY == 0 && g->OFFX == 0 && g->C2 == 0 && g->Hs == g->Hq && g->Ws == g->Wq &&
+      (g->Hq * g->Wq) % 16 == 0 && g->Cout <= 128 && g->C <= 128 && g->C >= 8 && !((uintptr_t)a & 15) && !((uintptr_t)src & 15) &&
+      ptot < (1L << 31)) {
+    // 1x1 layers: both operands straight from HBM into MFMA registers (conv_split.h: conv1x1_weight_grad_split_kernel)
+    const int tiles_co = (g->Cout + 31) / 32, tiles_ci = (g->C + 31) / 32;
+    const int total = (int)(ptot / 16);
+    int splits = 256;  // one workgroup per CU (one wave per SIMD: the conversion VALU work fills it); more partial tiles = more atomics (36 / 44 / 50 us at 256 / 512 / 1024)
+    if (splits > total) splits = total;
+    const int per = (total + splits - 1) / splits;
+    const dim3 grid((unsigned)((total + per - 1) / per));
+    const dim3 block(64 * tiles_co * tiles_ci);
+    const int sp = g->mfma_split;
+    set_last_kernel(sp == 3 ? "mtrssm::conv1x1_weight_grad_split_kernel<3>" : sp == 2 ? "mtrssm::conv1x1_weight_grad_split_kernel<2>" : "mtrssm::conv1x1_weight_grad_split_kernel<1>");
+    if (sp == 3) hipLaunchKernelGGL((conv1x1_weight_grad_split_kernel<3>), grid, block, 0, stream, *g, a, src, pre_act_a, dwp, dbias, tiles_ci, per);
+    else if (sp == 2) hipLaunchKernelGGL((conv1x1_weight_grad_split_kernel<2>), grid, block, 0, stream, *g, a, src, pre_act_a, dwp, dbias, tiles_ci, per);
+    else hipLaunchKernelGGL((conv1x1_weight_grad_split_kernel<1>), grid, block, 0, stream, *g, a, src, pre_act_a, dwp, dbias, tiles_ci, per);
+    return launched("conv_weight_grad(1x1 split)");
+  }
   // ---- patch-staged kernel when the 64-pixel groups tile the frames exactly
   if (g->TS == 1 && g->Wq <= kGP && kGP % g->Wq == 0) {
     const PatchGeom pg(*g, kGP);

@@ -874,4 +874,93 @@ __global__ __launch_bounds__(2 * kConvThreads, 2) void conv_weight_grad_split_ke
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of the 1x1 layers: dW[co][ci] = sum_{n,px} preA(a[n,co,px]) pre(src[n,ci,px]) is a plain GEMM whose
+// k index (pixels) is the contiguous one in BOTH operands, which is exactly the MFMA register layout: lane (row = lane & 31,
+// k-group = lane >> 5) holds 8 consecutive pixels of one channel plane = two 16-byte global loads, converted to bf16 pieces
+// in registers.  No LDS, no staging waves, no barriers.  One wave per 32x32 output tile (up to 4 x 4 per workgroup), every
+// workgroup a slice of the pixel stream, one prefetched k-step (16 pixels) in flight per wave; partial tiles by fp32 atomics.
+// Rows / columns beyond Cout / C read a clamped plane and are never stored.
+// ------------------------------------------------------------------------------------------------
+template <int SPLIT>
+__global__ __launch_bounds__(1024) void conv1x1_weight_grad_split_kernel(
+    const MtrssmConvGeom g, const float* __restrict__ a, const float* __restrict__ src, const int pre_act_a, float* __restrict__ dwp,
+    float* __restrict__ dbias, const int tiles_ci, const int steps_per_wg) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int il = lane & 31, kl = lane >> 5;
+  const int tco = wave / tiles_ci, tci = wave - tco * tiles_ci;
+  const int plane = g.Hq * g.Wq, spp = plane >> 4;  // 16-pixel k-steps per frame (host: plane % 16 == 0)
+  const int total = g.N * spp;
+  const int s0 = blockIdx.x * steps_per_wg;
+  const int s1 = s0 + steps_per_wg < total ? s0 + steps_per_wg : total;
+  if (s0 >= s1) return;
+  const int co = tco * 32 + il, ci = tci * 32 + il;
+  const float* ap = a + (size_t)(co < g.Cout ? co : g.Cout - 1) * plane + 8 * kl;
+  const float* bp = src + (size_t)(ci < g.C ? ci : g.C - 1) * plane + 8 * kl;
+  const size_t fa = (size_t)g.Cout * plane, fb = (size_t)g.C * plane;
+
+  struct Step { float4 a0, a1, b0, b1; };
+  int n = s0 / spp, q = s0 - n * spp;  // frame and k-step within it of the NEXT load
+  auto load = [&](Step& t) {
+    const float4* pa = reinterpret_cast<const float4*>(ap + (size_t)n * fa + (q << 4));
+    const float4* pb = reinterpret_cast<const float4*>(bp + (size_t)n * fb + (q << 4));
+    t.a0 = pa[0]; t.a1 = pa[1]; t.b0 = pb[0]; t.b1 = pb[1];
+  };
+  auto advance = [&](int s) {  // (n, q) from step s to step s + 1, clamped to the last one (loads stay unconditional)
+    if (s + 1 < s1 && ++q == spp) { q = 0; ++n; }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float bsum = 0.f;
+  constexpr int D = 4;  // k-steps in flight per wave (4 x 16 B per lane each): one wave per SIMD has to cover the HBM latency alone
+  Step buf[D];
+  int ls = s0;  // step of the next load
+#pragma unroll
+  for (int d = 0; d < D; ++d) { load(buf[d]); advance(ls); ++ls; }
+#pragma unroll 1
+  for (int s = s0; s < s1; s += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const Step cur = buf[d];
+      load(buf[d]);
+      advance(ls);
+      ++ls;
+      if (s + d < s1) {  // wave-uniform
+        float xa[8] = {cur.a0.x, cur.a0.y, cur.a0.z, cur.a0.w, cur.a1.x, cur.a1.y, cur.a1.z, cur.a1.w};
+        float xb[8] = {cur.b0.x, cur.b0.y, cur.b0.z, cur.b0.w, cur.b1.x, cur.b1.y, cur.b1.z, cur.b1.w};
+#pragma unroll
+        for (int u = 0; u < 8; ++u) bsum += xa[u];
+        if (pre_act_a) act_inplace<8>(xa, g.act);
+        if (g.pre_act) act_inplace<8>(xb, g.act);
+        u16x8 qa[SPLIT], qb[SPLIT];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          unsigned short pa[SPLIT], pb[SPLIT];
+          split_bf16<SPLIT>(xa[u], pa);
+          split_bf16<SPLIT>(xb[u], pb);
+#pragma unroll
+          for (int p = 0; p < SPLIT; ++p) { qa[p][u] = pa[p]; qb[p][u] = pb[p]; }
+        }
+#pragma unroll
+        for (int ord = SPLIT - 1; ord >= 0; --ord)
+#pragma unroll
+          for (int sa = 0; sa <= ord; ++sa)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, qa[sa]), __builtin_bit_cast(bf16x8, qb[ord - sa]), acc, 0, 0, 0);
+      }
+    }
+  }
+  if (ci < g.C) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = tco * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
+      if (row < g.Cout) atomicAdd(&dwp[(size_t)row * g.Cpad + ci], acc[r]);
+    }
+  }
+  if (dbias != nullptr && tci == 0) {  // wave-uniform
+    bsum += __shfl_xor(bsum, 32, kWave);
+    if (kl == 0 && co < g.Cout) atomicAdd(&dbias[co], bsum);
+  }
+}
+
 }  // namespace mtrssm

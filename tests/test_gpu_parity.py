@@ -299,6 +299,12 @@ CONV_CASES = [
     (2, 3, 64, 64, 8, 3, 2, 1, False, True),    # 32x32 output: two-row groups, coordinate channels
     (9, 32, 4, 4, 64, 3, 1, 1, True, False),    # 4x4 planes: four frames per group, ragged last group
     (3, 64, 16, 4, 64, 3, 1, 1, True, False),   # 16x4 audio plane
+    (7, 64, 8, 8, 64, 1, 1, 0, True, False),    # 1x1 layers: register-direct weight gradient (conv1x1_weight_grad_split_kernel), 2 x 2 tiles
+    (5, 24, 16, 4, 48, 1, 1, 0, False, False),  # ... ragged channel counts (1 x 2 tiles), no activation
+    (3, 40, 4, 4, 20, 1, 1, 0, True, False),    # ... one-frame k-steps, 2 x 1 tiles
+    (70, 16, 8, 8, 64, 1, 1, 0, True, False),   # ... more k-steps than one per workgroup slice boundary (280 k-steps)
+    (6, 64, 8, 8, 128, 1, 1, 0, True, False),   # ... decoder residual 1x1 (64 -> 128): 4 x 2 tiles, 8 waves
+    (3, 128, 4, 4, 100, 1, 1, 0, True, False),  # ... 4 x 4 tiles, 16 waves, ragged Cout
 ]
 
 
