@@ -368,6 +368,9 @@ int mtrssm_conv_gather_gemm_pair(const MtrssmConvGeom* ga, const float* srca, co
                                  const float* biasa, const float* actgrada, const float* adda, float* outa,
                                  const MtrssmConvGeom* gb, const float* srcb, const float* src2b, const float* wpb, const uint16_t* wqb,
                                  const float* biasb, const float* actgradb, const float* addb, float* outb, void* stream);
+/* 1 if mtrssm_conv_gather_gemm_pair would run the two problems as one grid (same split-bf16 kernel for both; has_wq: both
+ * have bf16 pieces), 0 if it would fall back to two launches -- a host-side query, nothing is launched. */
+int mtrssm_conv_gather_pair_merges(const MtrssmConvGeom* ga, const MtrssmConvGeom* gb, int32_t has_wq);
 /* Packs a conv weight view w[O][I][KH][KW] (element strides so, si, sh, sw: any permuted / strided view of the module's
  * parameter, e.g. the per-parity-class tap subset of a ConvTranspose2d weight) into the kernels' layout:
  *   wp fp32 [OPad][KH*KW][IPad], zero padded;

@@ -30,7 +30,14 @@ import torch
 from torch import Tensor, nn
 
 from multimodal_mtrssm_amd import _lib
-from multimodal_mtrssm_amd.conv import conv2d, conv_transpose2d, residual_block, residual_block_pair
+from multimodal_mtrssm_amd.conv import (
+    conv2d,
+    conv2d_pair,
+    conv_transpose2d,
+    conv_transpose2d_pair,
+    residual_block,
+    residual_block_pair,
+)
 
 
 def _act(name: str) -> nn.Module:
@@ -81,20 +88,52 @@ def _res_pair(res_a: nn.ModuleList, res_b: nn.ModuleList, xa: Tensor, xb: Tensor
     return xa, xb
 
 
+def _same_layer(ma: nn.Module, mb: nn.Module) -> bool:
+    return (ma.weight.shape[0] == mb.weight.shape[0] and ma.weight.shape[2:] == mb.weight.shape[2:] and ma.stride == mb.stride
+            and ma.padding == mb.padding and getattr(ma, "output_padding", 0) == getattr(mb, "output_padding", 0))
+
+
+def _conv_pair(xa: Tensor, ma: nn.Conv2d, ca: Tensor | None, xb: Tensor, mb: nn.Conv2d, cb: Tensor | None, *, pre_act: bool,
+               act_a: int, act_b: int) -> tuple[Tensor, Tensor]:
+    if _same_layer(ma, mb) and act_a == act_b:
+        return conv2d_pair((xa, ma.weight, ma.bias, ma.stride[0], ma.padding[0], pre_act, act_a, ca),
+                           (xb, mb.weight, mb.bias, mb.stride[0], mb.padding[0], pre_act, act_b, cb))
+    return _conv(xa, ma, pre_act=pre_act, act=act_a, coords=ca), _conv(xb, mb, pre_act=pre_act, act=act_b, coords=cb)
+
+
 def encode_pair(enc_a: "Encoder", enc_b: "Encoder", xa: Tensor, xb: Tensor) -> tuple[Tensor, Tensor]:
-    """``(enc_a(xa), enc_b(xb))`` with the two residual stacks sharing their launches."""
+    """``(enc_a(xa), enc_b(xb))`` with the layers of the two stacks that have the same shape sharing their launches."""
     lead_a, lead_b = xa.shape[:-3], xb.shape[:-3]
-    xa, xb = enc_a.stem(xa), enc_b.stem(xb)
+    xa, ca = enc_a.prepare(xa)
+    xb, cb = enc_b.prepare(xb)
+    if len(enc_a.convs) == len(enc_b.convs) and (enc_a.res_in is None) == (enc_b.res_in is None):
+        for i, (ma, mb) in enumerate(zip(enc_a.convs, enc_b.convs, strict=True)):
+            xa, xb = _conv_pair(xa, ma, ca if i == 0 else None, xb, mb, cb if i == 0 else None, pre_act=i > 0, act_a=enc_a.act_id,
+                                act_b=enc_b.act_id)
+        if enc_a.res_in is not None:
+            xa, xb = _conv_pair(xa, enc_a.res_in, None, xb, enc_b.res_in, None, pre_act=True, act_a=enc_a.act_id, act_b=enc_b.act_id)
+    else:
+        xa, xb = enc_a.stem_convs(xa, ca), enc_b.stem_convs(xb, cb)
     xa, xb = _res_pair(enc_a.res, enc_b.res, xa, xb)
     return enc_a.head(xa, lead_a), enc_b.head(xb, lead_b)
 
 
 def decode_pair(dec_a: "Decoder", dec_b: "Decoder", fa: Tensor, fb: Tensor) -> tuple[Tensor, Tensor]:
-    """``(dec_a(fa), dec_b(fb))`` with the two residual stacks sharing their launches."""
+    """``(dec_a(fa), dec_b(fb))`` with the layers of the two stacks that have the same shape sharing their launches."""
     lead_a, lead_b = fa.shape[:-1], fb.shape[:-1]
     xa, xb = dec_a.stem(fa), dec_b.stem(fb)
     xa, xb = _res_pair(dec_a.res, dec_b.res, xa, xb)
-    return dec_a.tail(xa, lead_a), dec_b.tail(xb, lead_b)
+    if len(dec_a.deconvs) != len(dec_b.deconvs) or (len(dec_a.res) > 0) != (len(dec_b.res) > 0):
+        return dec_a.tail(xa, lead_a), dec_b.tail(xb, lead_b)
+    for i, (ma, mb) in enumerate(zip(dec_a.deconvs, dec_b.deconvs, strict=True)):
+        pre = i > 0 or len(dec_a.res) > 0
+        if _same_layer(ma, mb) and dec_a.act_id == dec_b.act_id:
+            xa, xb = conv_transpose2d_pair(
+                (xa, ma.weight, ma.bias, ma.stride[0], ma.padding[0], ma.output_padding[0], pre, dec_a.act_id),
+                (xb, mb.weight, mb.bias, mb.stride[0], mb.padding[0], mb.output_padding[0], pre, dec_b.act_id))
+        else:
+            xa, xb = _deconv(xa, ma, pre_act=pre, act=dec_a.act_id), _deconv(xb, mb, pre_act=pre, act=dec_b.act_id)
+    return dec_a.finish(xa, lead_a), dec_b.finish(xb, lead_b)
 
 
 class Encoder(nn.Module):
@@ -150,19 +189,25 @@ class Encoder(nn.Module):
             x = blk(x)
         return self.head(x, lead)
 
-    def stem(self, x: Tensor) -> Tensor:
-        """Strided convs (+ the conv into the residual stack) over the flattened frames."""
+    def prepare(self, x: Tensor) -> tuple[Tensor, Tensor | None]:
+        """Flattened fp32 frames and the coordinate planes of the first conv."""
         if len(self.linears) == 0:
             self.materialize(tuple(x.shape[-3:]))
             self.to(x.device)
         x = x.reshape(-1, *x.shape[-3:]).float()
         # the coordinate channels are frame-independent: the first conv gathers them from one [2,H,W] plane
-        coords = self._coord_channels(x) if self.coord_conv else None
+        return x, (self._coord_channels(x) if self.coord_conv else None)
+
+    def stem_convs(self, x: Tensor, coords: Tensor | None) -> Tensor:
         for i, conv in enumerate(self.convs):
             x = _conv(x, conv, pre_act=i > 0, act=self.act_id, coords=coords if i == 0 else None)
         if self.res_in is not None:
             x = _conv(x, self.res_in, pre_act=True, act=self.act_id)
         return x
+
+    def stem(self, x: Tensor) -> Tensor:
+        """Strided convs (+ the conv into the residual stack) over the flattened frames."""
+        return self.stem_convs(*self.prepare(x))
 
     def head(self, x: Tensor, lead: torch.Size) -> Tensor:
         x = self.act(x).flatten(start_dim=1)
@@ -226,5 +271,8 @@ class Decoder(nn.Module):
         for i, dc in enumerate(self.deconvs):
             # "act -> deconv" everywhere except a first deconv fed straight by the Linear (no residual stack)
             x = _deconv(x, dc, pre_act=i > 0 or len(self.res) > 0, act=self.act_id)
+        return self.finish(x, lead)
+
+    def finish(self, x: Tensor, lead: torch.Size) -> Tensor:
         x = self.out_act(x)
         return x.reshape(*lead, *x.shape[-3:])

@@ -232,6 +232,10 @@ def paired(fn_a, fn_b):  # noqa: ANN001, ANN201
         return ra, rb
     lib = _lib.load()
     for ja, jb in zip(jobs[:na], jobs[na:], strict=True):
+        if not lib.mtrssm_conv_gather_pair_merges(C.byref(ja[0]), C.byref(jb[0]), int(ja[4] is not None and jb[4] is not None)):
+            _launch_gather(ja)  # thin / fp32-kernel layers: nothing to merge
+            _launch_gather(jb)
+            continue
         fa, ba = _job_work(ja)
         fb, bb = _job_work(jb)
         _lib.check(_lib.TIMERS.call("mtrssm_conv_gather_gemm_pair", lib.mtrssm_conv_gather_gemm_pair, *_job_args(ja), *_job_args(jb),
@@ -482,6 +486,63 @@ def residual_block_pair(xa: Tensor, pa: tuple[Tensor, Tensor, Tensor, Tensor], x
 
 def residual_block(x: Tensor, w3: Tensor, b3: Tensor, w1: Tensor, b1: Tensor, *, act: int) -> Tensor:
     return _ResidualBlock.apply(x, w3, b3, w1, b1, int(act))
+
+
+class _BranchCtx:
+    """Stand-in for the autograd ctx of one branch inside a paired node."""
+
+    def __init__(self, needs: tuple = ()) -> None:
+        self.needs_input_grad = needs
+        self.saved_tensors: tuple = ()
+        self.cfg: tuple = ()
+
+    def save_for_backward(self, *tensors: Tensor) -> None:
+        self.saved_tensors = tensors
+
+
+def _pair_function(base: type) -> type:
+    """``base`` (``_Conv2d`` / ``_ConvTranspose2d``) for two branches as ONE node whose gathers go out as paired launches.
+    Valid because the only launches ``base`` issues besides gathers (weight gradient, bias sum) never read a gather's
+    output of the same call -- a deferred gather may therefore run after them."""
+
+    class _Pair(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, n, *args):  # noqa: ANN001, ANN002, ANN205
+            ca, cb = _BranchCtx(), _BranchCtx()
+            ya, yb = paired(lambda: base.forward(ca, *args[:n]), lambda: base.forward(cb, *args[n:]))
+            ctx.n, ctx.na, ctx.cfgs = n, len(ca.saved_tensors), (ca.cfg, cb.cfg)
+            ctx.save_for_backward(*ca.saved_tensors, *cb.saved_tensors)
+            return ya, yb
+
+        @staticmethod
+        def backward(ctx, ga, gb):  # noqa: ANN001, ANN205
+            saved, needs = ctx.saved_tensors, ctx.needs_input_grad[1:]
+            ca, cb = _BranchCtx(needs[: ctx.n]), _BranchCtx(needs[ctx.n :])
+            ca.saved_tensors, cb.saved_tensors = saved[: ctx.na], saved[ctx.na :]
+            ca.cfg, cb.cfg = ctx.cfgs
+            ra, rb = paired(lambda: base.backward(ca, ga), lambda: base.backward(cb, gb))
+            return (None, *ra, *rb)
+
+    _Pair.__name__ = f"_Pair{base.__name__}"
+    return _Pair
+
+
+_PairConv2d = _pair_function(_Conv2d)
+_PairConvTranspose2d = _pair_function(_ConvTranspose2d)
+
+
+def conv2d_pair(a: tuple, b: tuple) -> tuple[Tensor, Tensor]:
+    """Two ``conv2d`` calls (``(x, weight, bias, stride, padding, pre_act, act, coords)`` each) with shared launches."""
+    fa = (a[0], a[1], a[2], a[7], int(a[3]), int(a[4]), bool(a[5]), int(a[6]))
+    fb = (b[0], b[1], b[2], b[7], int(b[3]), int(b[4]), bool(b[5]), int(b[6]))
+    return _PairConv2d.apply(len(fa), *fa, *fb)
+
+
+def conv_transpose2d_pair(a: tuple, b: tuple) -> tuple[Tensor, Tensor]:
+    """Two ``conv_transpose2d`` calls (``(x, weight, bias, stride, padding, output_padding, pre_act, act)`` each)."""
+    fa = (a[0], a[1], a[2], int(a[3]), int(a[4]), int(a[5]), bool(a[6]), int(a[7]))
+    fb = (b[0], b[1], b[2], int(b[3]), int(b[4]), int(b[5]), bool(b[6]), int(b[7]))
+    return _PairConvTranspose2d.apply(len(fa), *fa, *fb)
 
 
 def conv2d(x: Tensor, weight: Tensor, bias: Tensor | None, *, stride: int, padding: int, pre_act: bool, act: int,  # noqa: PLR0913

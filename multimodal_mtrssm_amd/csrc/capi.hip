@@ -28,6 +28,7 @@ int conv_gather_gemm_pair_launch(const MtrssmConvGeom*, const float*, const floa
                                  const MtrssmConvGeom*, const float*, const float*, const float*, const unsigned short*, const float*, const float*, const float*, float*, hipStream_t);
 int pack_conv_weight_launch(const float*, int, int, int, int, long, long, long, long, int, int, int, float*, unsigned short*, hipStream_t);
 int pack_conv_weights_launch(const int64_t*, int, int, hipStream_t);
+int conv_gather_pair_merges(const MtrssmConvGeom*, const MtrssmConvGeom*, bool);
 int conv_weight_grad_launch(const MtrssmConvGeom*, const float*, const float*, const float*, int, float*, float*, hipStream_t);
 int channel_sum_launch(const float*, int, int, int, float*, hipStream_t);
 int convt_k4s2_thin_launch(int, int, int, int, int, const float*, const float*, const float*, int, int, float*, hipStream_t);
@@ -90,6 +91,9 @@ MTRSSM_API int mtrssm_conv_gather_gemm_pair(const MtrssmConvGeom* ga, const floa
 MTRSSM_API int mtrssm_pack_conv_weight(const float* w, int32_t O, int32_t I, int32_t KH, int32_t KW, int64_t so, int64_t si, int64_t sh,
                                        int64_t sw, int32_t OPad, int32_t IPad, int32_t pieces, float* wp, uint16_t* wq, void* stream) {
   return pack_conv_weight_launch(w, O, I, KH, KW, so, si, sh, sw, OPad, IPad, pieces, wp, wq, static_cast<hipStream_t>(stream));
+}
+MTRSSM_API int mtrssm_conv_gather_pair_merges(const MtrssmConvGeom* ga, const MtrssmConvGeom* gb, int32_t has_wq) {
+  return conv_gather_pair_merges(ga, gb, has_wq != 0);
 }
 MTRSSM_API int mtrssm_pack_conv_weights(const int64_t* table, int32_t count, int32_t blocks_per_weight, void* stream) {
   return pack_conv_weights_launch(table, count, blocks_per_weight, static_cast<hipStream_t>(stream));

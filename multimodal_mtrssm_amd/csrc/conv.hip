@@ -1210,20 +1210,25 @@ int conv_gather_gemm_launch(const MtrssmConvGeom* g, const float* src, const flo
 
 // Two gather problems in one launch when they map to the same split kernel (the audio and the vision branch of one layer);
 // otherwise two launches.
+// 1 when the two problems run the same split kernel and therefore go out as ONE grid (mtrssm_conv_gather_pair_merges)
+int conv_gather_pair_merges(const MtrssmConvGeom* ga, const MtrssmConvGeom* gb, bool has_wq) {
+  if (!ga || !gb || check_geom(ga, "conv_gather_gemm_pair") || check_geom(gb, "conv_gather_gemm_pair")) return 0;
+  const bool thin_a = (ga->Cout <= 8 || ga->C + ga->C2 <= 2) && ga->Cout <= 16;
+  const bool thin_b = (gb->Cout <= 8 || gb->C + gb->C2 <= 2) && gb->Cout <= 16;
+  if (thin_a || thin_b) return 0;
+  const SplitPlan pa = plan_split(ga, has_wq), pb = plan_split(gb, has_wq);
+  return pa.same_kernel(pb) ? 1 : 0;
+}
+
 int conv_gather_gemm_pair_launch(const MtrssmConvGeom* ga, const float* srca, const float* src2a, const float* wpa, const unsigned short* wqa,
                                  const float* biasa, const float* actgrada, const float* adda, float* outa, const MtrssmConvGeom* gb,
                                  const float* srcb, const float* src2b, const float* wpb, const unsigned short* wqb, const float* biasb,
                                  const float* actgradb, const float* addb, float* outb, hipStream_t stream) {
-  if (ga && gb && srca && srcb && outa && outb && !check_geom(ga, "conv_gather_gemm_pair") && !check_geom(gb, "conv_gather_gemm_pair") &&
-      !(ga->C2 > 0 && !src2a) && !(gb->C2 > 0 && !src2b)) {
-    const bool thin_a = (ga->Cout <= 8 || ga->C + ga->C2 <= 2) && ga->Cout <= 16;
-    const bool thin_b = (gb->Cout <= 8 || gb->C + gb->C2 <= 2) && gb->Cout <= 16;
-    if (!thin_a && !thin_b) {
-      const SplitPlan pa = plan_split(ga, wqa != nullptr), pb = plan_split(gb, wqb != nullptr);
-      if (pa.same_kernel(pb))
-        return launch_split(pa, pa.lds > pb.lds ? pa.lds : pb.lds, make_problem(ga, pa, srca, src2a, wqa, biasa, actgrada, adda, outa),
-                            make_problem(gb, pb, srcb, src2b, wqb, biasb, actgradb, addb, outb), stream);
-    }
+  if (srca && srcb && outa && outb && !(ga && ga->C2 > 0 && !src2a) && !(gb && gb->C2 > 0 && !src2b) &&
+      conv_gather_pair_merges(ga, gb, wqa != nullptr && wqb != nullptr)) {
+    const SplitPlan pa = plan_split(ga, true), pb = plan_split(gb, true);
+    return launch_split(pa, pa.lds > pb.lds ? pa.lds : pb.lds, make_problem(ga, pa, srca, src2a, wqa, biasa, actgrada, adda, outa),
+                        make_problem(gb, pb, srcb, src2b, wqb, biasb, actgradb, addb, outb), stream);
   }
   if (int rc = conv_gather_gemm_launch(ga, srca, src2a, wpa, wqa, biasa, actgrada, adda, outa, stream)) return rc;
   return conv_gather_gemm_launch(gb, srcb, src2b, wpb, wqb, biasb, actgradb, addb, outb, stream);

@@ -512,7 +512,7 @@ def test_paired_launches_change_nothing(lib_loaded: None) -> None:
 
 def test_step_pack_plan_changes_nothing(lib_loaded: None) -> None:
     """conv._PackPlan (every conv weight of a step packed by one launch at the start of shared_step, the default) against
-    one pack launch per use: packing is a pure re-layout, so four optimizer steps give bit-identical forward values; also a
+    one pack launch per use: packing is a pure re-layout, so the first step's loss agrees to the last bits (fp32 atomics in the NLL sum); also a
     weight edited between begin_step and its use must be picked up (version counter), as must the optimizer's raw writes."""
     from multimodal_mtrssm_amd import conv
     from multimodal_mtrssm_amd.optim import FlatAdamW, FlatParameters
@@ -541,7 +541,7 @@ def test_step_pack_plan_changes_nothing(lib_loaded: None) -> None:
             losses[plan] = trace
         finally:
             conv.PACK_PLAN = True
-    assert losses[True][0] == losses[False][0]
+    np.testing.assert_allclose(losses[True][0], losses[False][0], rtol=1e-6)  # same packed values; the NLL sum uses fp32 atomics
     # later steps differ only by the arrival order of the weight-gradient atomics feeding the optimizer
     np.testing.assert_allclose(losses[True], losses[False], rtol=2e-5)
     assert losses[True][1] < losses[True][0]  # and the optimizer's updates were seen by the next step's packs
