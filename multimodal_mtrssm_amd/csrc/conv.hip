@@ -1236,6 +1236,12 @@ int conv_gather_gemm_pair_launch(const MtrssmConvGeom* ga, const float* srca, co
 
 int channel_sum_launch(const float* x, int N, int C, int HW, float* out, hipStream_t stream);
 
+// MTRSSM_NO_DIRECT_WGRAD=1: the patch-staged kernels for every layer (A/B runs of the register-direct 3x3 kernel)
+static bool no_direct_wgrad() {
+  static const bool off = getenv("MTRSSM_NO_DIRECT_WGRAD") != nullptr;
+  return off;
+}
+
 int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float* src, const float* src2, int pre_act_a,
                             float* dwp, float* dbias, hipStream_t stream) {
   if (int rc = check_geom(g, "conv_weight_grad")) return rc;
@@ -1262,6 +1268,31 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
     else if (sp == 2) hipLaunchKernelGGL((conv1x1_weight_grad_split_kernel<2>), grid, block, 0, stream, *g, a, src, pre_act_a, dwp, dbias, tiles_ci, per);
     else hipLaunchKernelGGL((conv1x1_weight_grad_split_kernel<1>), grid, block, 0, stream, *g, a, src, pre_act_a, dwp, dbias, tiles_ci, per);
     return launched("conv_weight_grad(1x1 split)");
+  }
+  if (g->mfma_split >= 1 && g->KH == 3 && g->KW == 3 && g->SS == 1 && g->TS == 1 && g->OFFY == -1 && g->OFFX == -1 && g->C2 == 0 &&
+      g->Hs == g->Hq && g->Ws == g->Wq && (g->Wq == 8 || g->Wq == 4) && (g->Hq * g->Wq) % 16 == 0 && g->C <= 64 && g->C >= 8 &&
+      g->Cout <= 65535 * 64 && !((uintptr_t)a & 15) && !((uintptr_t)src & 15) && ptot < (1L << 31) && !no_direct_wgrad()) {
+    // 3x3 layers of the residual stacks: register-direct (conv_split.h: conv3x3_weight_grad_split_kernel)
+    const int cogroups = (g->Cout + 63) / 64;
+    const int tiles_co = g->Cout > 32 ? 2 : 1, tiles_ci = (g->C + 31) / 32;
+    const int nt = tiles_co * tiles_ci;
+    const int total = (int)(ptot / 16);
+    int splits = 1024 / (nt * cogroups);  // one wave per SIMD over the chip
+    if (splits < 1) splits = 1;
+    if (splits > total) splits = total;
+    const int per = (total + splits - 1) / splits;
+    const dim3 grid((unsigned)((total + per - 1) / per), cogroups);
+    const dim3 block(64 * nt);
+    const int sp = g->mfma_split;
+#define MTRSSM_W33_LAUNCH(SP_, W_)                                                                                               \
+  {                                                                                                                             \
+    set_last_kernel("mtrssm::conv3x3_weight_grad_split_kernel<" #SP_ ", " #W_ ">");                                              \
+    hipLaunchKernelGGL((conv3x3_weight_grad_split_kernel<SP_, W_>), grid, block, 0, stream, *g, a, src, pre_act_a, dwp, dbias, tiles_ci, per); \
+  }
+    if (g->Wq == 8) { if (sp == 3) MTRSSM_W33_LAUNCH(3, 8) else if (sp == 2) MTRSSM_W33_LAUNCH(2, 8) else MTRSSM_W33_LAUNCH(1, 8) }
+    else { if (sp == 3) MTRSSM_W33_LAUNCH(3, 4) else if (sp == 2) MTRSSM_W33_LAUNCH(2, 4) else MTRSSM_W33_LAUNCH(1, 4) }
+#undef MTRSSM_W33_LAUNCH
+    return launched("conv_weight_grad(3x3 split)");
   }
   // ---- patch-staged kernel when the 64-pixel groups tile the frames exactly
   if (g->TS == 1 && g->Wq <= kGP && kGP % g->Wq == 0) {

@@ -963,4 +963,132 @@ __global__ __launch_bounds__(1024) void conv1x1_weight_grad_split_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of the 3x3 / stride 1 / pad 1 layers on 8- or 4-pixel-wide planes (the residual stacks: 8x8 vision,
+// 16x4 audio), the same register-direct scheme: a lane's 8 pixels are PXR = 8 / W whole plane rows of its channel, and every
+// tap's shifted copy of them lies in a window of PXR + 2 rows that the lane loads itself (16-byte loads), activates,
+// zeroes outside the frame and splits ONCE; the nine B fragments are then static selections of window elements.  One
+// wave per (32 co) x (32 ci) x 9 taps (nine accumulator tiles), up to 2 x 2 waves per workgroup, blockIdx.y walks
+// 64-channel groups of Cout; partial tiles by fp32 atomics in the dwp layout [co][tap][Cpad].
+// ------------------------------------------------------------------------------------------------
+template <int SPLIT, int W>
+__global__ __launch_bounds__(kConvThreads, 1) void conv3x3_weight_grad_split_kernel(
+    const MtrssmConvGeom g, const float* __restrict__ a, const float* __restrict__ src, const int pre_act_a, float* __restrict__ dwp,
+    float* __restrict__ dbias, const int tiles_ci, const int steps_per_wg) {
+  constexpr int PXR = 8 / W, R = PXR + 2, NV = R * W, RV = W / 4;  // window rows, values, 16-byte loads per row
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int il = lane & 31, kl = lane >> 5;
+  // (two k-halves of the slice on two waves per SIMD, met in LDS, were measured slower: 135 vs 116 us -- 256 registers per
+  // wave spill next to 144 accumulators)
+  const int tco = wave / tiles_ci, tci = wave - tco * tiles_ci;
+  const int H = g.Hq, plane = H * W, spp = plane >> 4;  // host: Wq == W, plane % 16 == 0
+  const int total = g.N * spp;
+  const int s0 = blockIdx.x * steps_per_wg;
+  const int s1 = s0 + steps_per_wg < total ? s0 + steps_per_wg : total;
+  if (s0 >= s1) return;
+  const int co = blockIdx.y * 64 + tco * 32 + il, ci = tci * 32 + il;
+  const float* ap = a + (size_t)(co < g.Cout ? co : g.Cout - 1) * plane + 8 * kl;
+  const float* bp = src + (size_t)(ci < g.C ? ci : g.C - 1) * plane;
+  const size_t fa = (size_t)g.Cout * plane, fb = (size_t)g.C * plane;
+
+  struct Step { float4 a0, a1; float4 w[R * RV]; int y0; };
+  int n = s0 / spp, q = s0 - n * spp;  // frame and k-step within it of the NEXT load
+  auto load = [&](Step& t) {
+    const float4* pa = reinterpret_cast<const float4*>(ap + (size_t)n * fa + (q << 4));
+    t.a0 = pa[0]; t.a1 = pa[1];
+    t.y0 = ((q << 4) + 8 * kl) / W;  // first plane row of this lane's pixels
+    const float* fr = bp + (size_t)n * fb;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      int y = t.y0 - 1 + r;
+      y = y < 0 ? 0 : (y >= H ? H - 1 : y);  // clamped; zeroed after the activation
+      const float4* pr = reinterpret_cast<const float4*>(fr + y * W);
+#pragma unroll
+      for (int v = 0; v < RV; ++v) t.w[r * RV + v] = pr[v];
+    }
+  };
+  auto advance = [&](int s) {  // (n, q) from step s to step s + 1, clamped to the last one (loads stay unconditional)
+    if (s + 1 < s1 && ++q == spp) { q = 0; ++n; }
+  };
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float bsum = 0.f;
+  Step cur, nxt;  // (two k-steps in flight instead of one: no change, 122 vs 120 us -- not bound by the load latency)
+  load(cur);
+  advance(s0);
+#pragma unroll 1
+  for (int s = s0; s < s1; ++s) {
+    load(nxt);
+    advance(s + 1);
+    float xa[8] = {cur.a0.x, cur.a0.y, cur.a0.z, cur.a0.w, cur.a1.x, cur.a1.y, cur.a1.z, cur.a1.w};
+#pragma unroll
+    for (int u = 0; u < 8; ++u) bsum += xa[u];
+    if (pre_act_a) act_inplace<8>(xa, g.act);
+    u16x8 qa[SPLIT];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      unsigned short pa[SPLIT];
+      split_bf16<SPLIT>(xa[u], pa);
+#pragma unroll
+      for (int p = 0; p < SPLIT; ++p) qa[p][u] = pa[p];
+    }
+    // the whole window is activated, zeroed outside the frame and split once; the nine fragments are static selections
+    // (converting row by row inside the tap loop measured slower: 128 vs 116 us)
+    float wv[NV];
+#pragma unroll
+    for (int i = 0; i < R * RV; ++i) { wv[4 * i] = cur.w[i].x; wv[4 * i + 1] = cur.w[i].y; wv[4 * i + 2] = cur.w[i].z; wv[4 * i + 3] = cur.w[i].w; }
+    if (g.pre_act) act_inplace<NV>(wv, g.act);
+    unsigned short pb[SPLIT][NV];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int y = cur.y0 - 1 + r;
+      const bool in = y >= 0 && y < H;
+#pragma unroll
+      for (int x = 0; x < W; ++x) {
+        unsigned short pc[SPLIT];
+        split_bf16<SPLIT>(in ? wv[r * W + x] : 0.f, pc);
+#pragma unroll
+        for (int p = 0; p < SPLIT; ++p) pb[p][r * W + x] = pc[p];
+      }
+    }
+    u16x8 qb[9][SPLIT];
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int r = e / W + ty, x = e % W + tx - 1;  // window row / column of pixel e under this tap
+#pragma unroll
+          for (int p = 0; p < SPLIT; ++p)
+            qb[ty * 3 + tx][p][e] = (x < 0 || x >= W) ? (unsigned short)0 : pb[p][r * W + (x < 0 ? 0 : (x >= W ? W - 1 : x))];
+        }
+    // product-major: consecutive MFMAs go to different accumulator tiles, so none waits for its predecessor
+#pragma unroll
+    for (int ord = SPLIT - 1; ord >= 0; --ord)
+#pragma unroll
+      for (int sa = 0; sa <= ord; ++sa)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, qa[sa]), __builtin_bit_cast(bf16x8, qb[t][ord - sa]), acc[t], 0, 0, 0);
+    cur = nxt;
+  }
+  if (ci < g.C) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = blockIdx.y * 64 + tco * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
+        if (row < g.Cout) atomicAdd(&dwp[((size_t)row * 9 + t) * g.Cpad + ci], acc[t][r]);
+      }
+  }
+  if (dbias != nullptr && tci == 0) {  // wave-uniform
+    bsum += __shfl_xor(bsum, 32, kWave);
+    if (kl == 0 && co < g.Cout) atomicAdd(&dbias[co], bsum);
+  }
+}
+
 }  // namespace mtrssm

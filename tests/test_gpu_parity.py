@@ -299,6 +299,9 @@ CONV_CASES = [
     (2, 3, 64, 64, 8, 3, 2, 1, False, True),    # 32x32 output: two-row groups, coordinate channels
     (9, 32, 4, 4, 64, 3, 1, 1, True, False),    # 4x4 planes: four frames per group, ragged last group
     (3, 64, 16, 4, 64, 3, 1, 1, True, False),   # 16x4 audio plane
+    (5, 24, 8, 8, 40, 3, 1, 1, False, False),   # 3x3 on 8-wide planes: register-direct weight gradient (conv3x3_weight_grad_split_kernel), ragged channels
+    (11, 64, 2, 8, 32, 3, 1, 1, True, False),   # ... one k-step per frame (2 x 8 plane): every window row but two is outside
+    (70, 16, 16, 4, 64, 3, 1, 1, True, False),  # ... 4-wide audio plane, many frames per workgroup slice
     (7, 64, 8, 8, 64, 1, 1, 0, True, False),    # 1x1 layers: register-direct weight gradient (conv1x1_weight_grad_split_kernel), 2 x 2 tiles
     (5, 24, 16, 4, 48, 1, 1, 0, False, False),  # ... ragged channel counts (1 x 2 tiles), no activation
     (3, 40, 4, 4, 20, 1, 1, 0, True, False),    # ... one-frame k-steps, 2 x 1 tiles
