@@ -1294,6 +1294,24 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
 #undef MTRSSM_W33_LAUNCH
     return launched("conv_weight_grad(3x3 split)");
   }
+  if (g->mfma_split >= 1 && g->Cout <= 32 && taps * ctot <= 32 && g->Wq >= 8 && (g->Wq & (g->Wq - 1)) == 0 && (g->Hq * g->Wq) % 16 == 0 &&
+      !((uintptr_t)a & 15) && ptot < (1L << 31) && (long)g->N * g->C * g->Hs * g->Ws < (1L << 40) && !no_direct_wgrad()) {
+    // thin strided layers: one MFMA tile, A straight from HBM, B gathered per lane (conv_split.h: conv_weight_grad_thin_split_kernel)
+    int log2_wq = 0;
+    while ((1 << log2_wq) < g->Wq) ++log2_wq;
+    const int total = (int)(ptot / 16);
+    int waves = 4096;  // 4 per SIMD: 17 loads in flight per lane each
+    if (waves > total) waves = total;
+    const int per = (total + waves - 1) / waves;
+    waves = (total + per - 1) / per;
+    const dim3 grid((unsigned)((waves + 3) / 4));
+    const int sp = g->mfma_split;
+    set_last_kernel(sp == 3 ? "mtrssm::conv_weight_grad_thin_split_kernel<3>" : sp == 2 ? "mtrssm::conv_weight_grad_thin_split_kernel<2>" : "mtrssm::conv_weight_grad_thin_split_kernel<1>");
+    if (sp == 3) hipLaunchKernelGGL((conv_weight_grad_thin_split_kernel<3>), grid, dim3(kConvThreads), 0, stream, *g, a, src, src2, pre_act_a, dwp, dbias, per, log2_wq);
+    else if (sp == 2) hipLaunchKernelGGL((conv_weight_grad_thin_split_kernel<2>), grid, dim3(kConvThreads), 0, stream, *g, a, src, src2, pre_act_a, dwp, dbias, per, log2_wq);
+    else hipLaunchKernelGGL((conv_weight_grad_thin_split_kernel<1>), grid, dim3(kConvThreads), 0, stream, *g, a, src, src2, pre_act_a, dwp, dbias, per, log2_wq);
+    return launched("conv_weight_grad(thin split)");
+  }
   // ---- patch-staged kernel when the 64-pixel groups tile the frames exactly
   if (g->TS == 1 && g->Wq <= kGP && kGP % g->Wq == 0) {
     const PatchGeom pg(*g, kGP);

@@ -1091,4 +1091,104 @@ __global__ __launch_bounds__(kConvThreads, 1) void conv3x3_weight_grad_split_ker
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of the thin strided layers (first encoder conv 3 -> 8, last decoder deconv 16 -> 1: at most 32 output
+// channels and at most 32 (tap, channel) columns, big planes): ONE 32x32 MFMA tile.  The A operand (`a`, contiguous in the
+// summation index) goes straight from HBM into the MFMA layout as in the 1x1 kernel; lane `col` of the B operand gathers
+// its own tap / channel: 8 pixels of one output row = 8 loads SS floats apart from one source row (neighbouring lanes hit
+// the same lines).  Every wave owns a slice of the pixel stream and adds its partial tile (<= 1024 values) atomically.
+// ------------------------------------------------------------------------------------------------
+template <int SPLIT>
+__global__ __launch_bounds__(kConvThreads) void conv_weight_grad_thin_split_kernel(
+    const MtrssmConvGeom g, const float* __restrict__ a, const float* __restrict__ src, const float* __restrict__ src2,
+    const int pre_act_a, float* __restrict__ dwp, float* __restrict__ dbias, const int steps_per_wave, const int log2_wq) {
+  const int lane = threadIdx.x & 63;
+  const int il = lane & 31, kl = lane >> 5;
+  const int plane_a = g.Hq * g.Wq, plane_s = g.Hs * g.Ws;
+  const int total = (int)(((long)g.N * plane_a) >> 4);  // 16-pixel k-steps (host: plane_a % 16 == 0, Wq % 8 == 0, Wq = 2^log2_wq)
+  const int gw = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const int s0 = gw * steps_per_wave;
+  const int s1 = s0 + steps_per_wave < total ? s0 + steps_per_wave : total;
+  if (s0 >= s1) return;  // wave-uniform
+  const int ctot = g.C + g.C2, taps = g.KH * g.KW, ncols = taps * ctot;
+  const int row = il < g.Cout ? il : g.Cout - 1;
+  const bool col_ok = il < ncols;
+  const int col = col_ok ? il : 0;
+  const int tap = col / ctot, c = col - tap * ctot;
+  const int ty = tap / g.KW, tx = tap - ty * g.KW;
+  const bool own = c < g.C;
+  const float* cplane = own ? src + (size_t)c * plane_s : src2 + (size_t)(c - g.C) * plane_s;
+  const size_t fa = (size_t)g.Cout * plane_a, fb = own ? (size_t)g.C * plane_s : 0;
+  const float* ap = a + (size_t)row * plane_a + 8 * kl;
+
+  struct Step { float4 a0, a1; float b[8]; unsigned ok; };
+  long p = (long)s0 << 4;
+  int n = (int)(p / plane_a), rem = (int)(p - (long)n * plane_a);  // frame and pixel within it of the NEXT load
+  auto load = [&](Step& t) {
+    const float4* pa = reinterpret_cast<const float4*>(ap + (size_t)n * fa + rem);
+    t.a0 = pa[0]; t.a1 = pa[1];
+    const int q = rem + 8 * kl;
+    const int y = q >> log2_wq, x0 = q & (g.Wq - 1);
+    const int sy = y * g.SS + ty * g.TS + g.OFFY;
+    const bool rok = col_ok && sy >= 0 && sy < g.Hs;
+    const float* rp = cplane + (size_t)n * fb + (size_t)(rok ? sy : 0) * g.Ws;
+    unsigned ok = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int sx = (x0 + e) * g.SS + tx * g.TS + g.OFFX;
+      const bool in = rok && sx >= 0 && sx < g.Ws;
+      ok |= in ? 1u << e : 0u;
+      t.b[e] = rp[in ? sx : 0];
+    }
+    t.ok = ok;
+  };
+  auto advance = [&](int s) {  // to step s + 1, clamped to the last one (loads stay unconditional)
+    if (s + 1 < s1) { rem += 16; if (rem >= plane_a) { rem -= plane_a; ++n; } }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float bsum = 0.f;
+  Step cur, nxt;
+  load(cur);
+  advance(s0);
+#pragma unroll 1
+  for (int s = s0; s < s1; ++s) {
+    load(nxt);
+    advance(s + 1);
+    float xa[8] = {cur.a0.x, cur.a0.y, cur.a0.z, cur.a0.w, cur.a1.x, cur.a1.y, cur.a1.z, cur.a1.w};
+    float xb[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { bsum += xa[e]; xb[e] = cur.b[e]; }
+    if (pre_act_a) act_inplace<8>(xa, g.act);
+    if (g.pre_act) act_inplace<8>(xb, g.act);
+    u16x8 qa[SPLIT], qb[SPLIT];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      unsigned short pa[SPLIT], pb[SPLIT];
+      split_bf16<SPLIT>(xa[e], pa);
+      split_bf16<SPLIT>((cur.ok >> e) & 1u ? xb[e] : 0.f, pb);  // zero padding applies to the activated tensor
+#pragma unroll
+      for (int k = 0; k < SPLIT; ++k) { qa[k][e] = pa[k]; qb[k][e] = pb[k]; }
+    }
+#pragma unroll
+    for (int ord = SPLIT - 1; ord >= 0; --ord)
+#pragma unroll
+      for (int sa = 0; sa <= ord; ++sa)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, qa[sa]), __builtin_bit_cast(bf16x8, qb[ord - sa]), acc, 0, 0, 0);
+    cur = nxt;
+  }
+  if (col_ok) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int orow = (r & 3) + 8 * (r >> 2) + 4 * kl;
+      if (orow < g.Cout) atomicAdd(&dwp[((size_t)orow * taps + tap) * g.Cpad + c], acc[r]);
+    }
+  }
+  if (dbias != nullptr) {
+    bsum += __shfl_xor(bsum, 32, kWave);
+    if (kl == 0 && il < g.Cout) atomicAdd(&dbias[il], bsum);
+  }
+}
+
 }  // namespace mtrssm

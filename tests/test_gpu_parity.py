@@ -299,6 +299,9 @@ CONV_CASES = [
     (2, 3, 64, 64, 8, 3, 2, 1, False, True),    # 32x32 output: two-row groups, coordinate channels
     (9, 32, 4, 4, 64, 3, 1, 1, True, False),    # 4x4 planes: four frames per group, ragged last group
     (3, 64, 16, 4, 64, 3, 1, 1, True, False),   # 16x4 audio plane
+    (4, 1, 64, 64, 8, 3, 2, 1, False, True),    # first vision layer: thin gathered weight gradient (conv_weight_grad_thin_split_kernel), 27 columns
+    (3, 1, 128, 32, 8, 3, 2, 1, False, True),   # ... first audio layer (64 x 16 output plane)
+    (5, 2, 16, 16, 6, 3, 2, 1, True, False),    # ... with activation, 18 columns, 8 x 8 output plane
     (5, 24, 8, 8, 40, 3, 1, 1, False, False),   # 3x3 on 8-wide planes: register-direct weight gradient (conv3x3_weight_grad_split_kernel), ragged channels
     (11, 64, 2, 8, 32, 3, 1, 1, True, False),   # ... one k-step per frame (2 x 8 plane): every window row but two is outside
     (70, 16, 16, 4, 64, 3, 1, 1, True, False),  # ... 4-wide audio plane, many frames per workgroup slice
