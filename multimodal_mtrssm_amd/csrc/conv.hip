@@ -1300,16 +1300,16 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
     int log2_wq = 0;
     while ((1 << log2_wq) < g->Wq) ++log2_wq;
     const int total = (int)(ptot / 16);
-    int waves = 4096;  // 4 per SIMD: 17 loads in flight per lane each
+    int waves = 4096;  // 4 per SIMD: 17 loads in flight per lane each; 16 waves per workgroup share one set of atomics
     if (waves > total) waves = total;
     const int per = (total + waves - 1) / waves;
     waves = (total + per - 1) / per;
-    const dim3 grid((unsigned)((waves + 3) / 4));
+    const dim3 grid((unsigned)((waves + 15) / 16));
     const int sp = g->mfma_split;
     set_last_kernel(sp == 3 ? "mtrssm::conv_weight_grad_thin_split_kernel<3>" : sp == 2 ? "mtrssm::conv_weight_grad_thin_split_kernel<2>" : "mtrssm::conv_weight_grad_thin_split_kernel<1>");
-    if (sp == 3) hipLaunchKernelGGL((conv_weight_grad_thin_split_kernel<3>), grid, dim3(kConvThreads), 0, stream, *g, a, src, src2, pre_act_a, dwp, dbias, per, log2_wq);
-    else if (sp == 2) hipLaunchKernelGGL((conv_weight_grad_thin_split_kernel<2>), grid, dim3(kConvThreads), 0, stream, *g, a, src, src2, pre_act_a, dwp, dbias, per, log2_wq);
-    else hipLaunchKernelGGL((conv_weight_grad_thin_split_kernel<1>), grid, dim3(kConvThreads), 0, stream, *g, a, src, src2, pre_act_a, dwp, dbias, per, log2_wq);
+    if (sp == 3) hipLaunchKernelGGL((conv_weight_grad_thin_split_kernel<3>), grid, dim3(1024), 0, stream, *g, a, src, src2, pre_act_a, dwp, dbias, per, log2_wq);
+    else if (sp == 2) hipLaunchKernelGGL((conv_weight_grad_thin_split_kernel<2>), grid, dim3(1024), 0, stream, *g, a, src, src2, pre_act_a, dwp, dbias, per, log2_wq);
+    else hipLaunchKernelGGL((conv_weight_grad_thin_split_kernel<1>), grid, dim3(1024), 0, stream, *g, a, src, src2, pre_act_a, dwp, dbias, per, log2_wq);
     return launched("conv_weight_grad(thin split)");
   }
   // ---- patch-staged kernel when the 64-pixel groups tile the frames exactly

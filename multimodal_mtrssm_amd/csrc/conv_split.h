@@ -1096,10 +1096,10 @@ __global__ __launch_bounds__(kConvThreads, 1) void conv3x3_weight_grad_split_ker
 // channels and at most 32 (tap, channel) columns, big planes): ONE 32x32 MFMA tile.  The A operand (`a`, contiguous in the
 // summation index) goes straight from HBM into the MFMA layout as in the 1x1 kernel; lane `col` of the B operand gathers
 // its own tap / channel: 8 pixels of one output row = 8 loads SS floats apart from one source row (neighbouring lanes hit
-// the same lines).  Every wave owns a slice of the pixel stream and adds its partial tile (<= 1024 values) atomically.
+// the same lines).  Every wave owns a slice of the pixel stream; the 16 waves of a workgroup meet in one LDS tile first.
 // ------------------------------------------------------------------------------------------------
 template <int SPLIT>
-__global__ __launch_bounds__(kConvThreads) void conv_weight_grad_thin_split_kernel(
+__global__ __launch_bounds__(1024) void conv_weight_grad_thin_split_kernel(
     const MtrssmConvGeom g, const float* __restrict__ a, const float* __restrict__ src, const float* __restrict__ src2,
     const int pre_act_a, float* __restrict__ dwp, float* __restrict__ dbias, const int steps_per_wave, const int log2_wq) {
   const int lane = threadIdx.x & 63;
@@ -1109,7 +1109,12 @@ __global__ __launch_bounds__(kConvThreads) void conv_weight_grad_thin_split_kern
   const int gw = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   const int s0 = gw * steps_per_wave;
   const int s1 = s0 + steps_per_wave < total ? s0 + steps_per_wave : total;
-  if (s0 >= s1) return;  // wave-uniform
+  const bool active = s0 < s1;  // wave-uniform; idle waves still meet the barriers below
+  // every wave's partial tile goes through ONE tile in LDS (ds_add_f32) so that a workgroup of 16 waves sends one set of
+  // global atomics: they all land on the same <= 1024 addresses, and 4096 sets of them cost more than the whole pixel stream
+  __shared__ float red[16 * 64 + 32];
+  for (int i = threadIdx.x; i < 16 * 64 + 32; i += blockDim.x) red[i] = 0.f;
+  __syncthreads();
   const int ctot = g.C + g.C2, taps = g.KH * g.KW, ncols = taps * ctot;
   const int row = il < g.Cout ? il : g.Cout - 1;
   const bool col_ok = il < ncols;
@@ -1150,8 +1155,10 @@ __global__ __launch_bounds__(kConvThreads) void conv_weight_grad_thin_split_kern
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   float bsum = 0.f;
   Step cur, nxt;
-  load(cur);
-  advance(s0);
+  if (active) {
+    load(cur);
+    advance(s0);
+  }
 #pragma unroll 1
   for (int s = s0; s < s1; ++s) {
     load(nxt);
@@ -1178,16 +1185,22 @@ __global__ __launch_bounds__(kConvThreads) void conv_weight_grad_thin_split_kern
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, qa[sa]), __builtin_bit_cast(bf16x8, qb[ord - sa]), acc, 0, 0, 0);
     cur = nxt;
   }
-  if (col_ok) {
+  if (active) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int orow = (r & 3) + 8 * (r >> 2) + 4 * kl;
-      if (orow < g.Cout) atomicAdd(&dwp[((size_t)orow * taps + tap) * g.Cpad + c], acc[r]);
-    }
-  }
-  if (dbias != nullptr) {
+    for (int r = 0; r < 16; ++r) atomicAdd(&red[r * 64 + lane], acc[r]);
     bsum += __shfl_xor(bsum, 32, kWave);
-    if (kl == 0 && il < g.Cout) atomicAdd(&dbias[il], bsum);
+    if (kl == 0) atomicAdd(&red[16 * 64 + il], bsum);
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    if (col_ok) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int orow = (r & 3) + 8 * (r >> 2) + 4 * kl;
+        if (orow < g.Cout) atomicAdd(&dwp[((size_t)orow * taps + tap) * g.Cpad + c], red[r * 64 + lane]);
+      }
+    }
+    if (dbias != nullptr && kl == 0 && il < g.Cout) atomicAdd(&dbias[il], red[16 * 64 + il]);
   }
 }
 
