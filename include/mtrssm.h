@@ -338,6 +338,12 @@ int mtrssm_mmtrssm_rollout_bwd(const MtrssmMmtrssmDims* dims, const MtrssmMmtrss
  *   dwp[co][ty*KW+tx][c] += sum_{n, y<Hq, x<Wq} preA(a[n,co,y,x]) * pre(S[n,c,y*SS+ty*TS+OFFY,x*SS+tx*TS+OFFX])
  * with a of shape [N, Cout, Hq, Wq] (geometry must have OS=1, QY=QX=0).  When dbias != NULL (allowed only with
  * pre_act_a == 0) it also accumulates the bias gradient dbias[co] += sum_{n,y,x} a[n,co,y,x] in the same pass.
+ * Kernel selection (mfma_split > 0; csrc/conv_split.h): 1x1 layers and 3x3 / stride 1 / pad 1 layers on 8- or 4-pixel-wide
+ * planes read both operands straight from HBM into the MFMA register layout (k = pixels is contiguous in NCHW); layers with
+ * <= 32 output channels and <= 32 (tap, channel) columns on power-of-two-wide planes run one MFMA tile with a per-lane
+ * gathered operand; everything else stages 64-pixel groups through LDS (persistent workgroups); mfma_split = 0 and odd
+ * geometries use the fp32 kernels of csrc/conv.hip.  All of them accumulate with fp32 atomics: results are equal up to the
+ * arrival order of the partial sums.
  * ------------------------------------------------------------------------------------------ */
 typedef struct MtrssmConvGeom {
   int32_t N;                    /* frames (B*T) */
