@@ -215,7 +215,20 @@ def main() -> None:  # noqa: PLR0914, PLR0915
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+        # RCCL prints a version banner on stdout when its communicator comes up; stdout carries the ONE JSON line, so the
+        # banner goes to stderr (fd-level: the library writes through C stdio)
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+            warm = torch.zeros(1, device=device)
+            dist.all_reduce(warm)
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     import multimodal_mtrssm_amd as mt
     from multimodal_mtrssm_amd import conv, scan
