@@ -432,6 +432,45 @@ def test_encoder_decoder_match_oracle(name: str, fp32_grade_mode: str, lib_loade
         np.testing.assert_allclose(_np(mine(xg[:, 0])), _np(yg[:, 0]), rtol=1e-5, atol=1e-6)
 
 
+def test_paired_stacks_of_different_shape_fall_back(lib_loaded: None) -> None:
+    """cnn.encode_pair / decode_pair with two stacks that do NOT match layer for layer (other channel counts, other number
+    of residual blocks): the walk falls back to single launches where shapes differ and gives what the modules give alone."""
+    import copy
+
+    import multimodal_mtrssm_amd as mt
+    from multimodal_mtrssm_amd import cnn
+
+    d = CASES["mrssm_default"].dims
+    torch.manual_seed(9)
+    cfg_a = copy.deepcopy(dict(d.enc_audio))
+    cfg_b = copy.deepcopy(dict(d.enc_vision))
+    cfg_b["channels"] = [c // 2 for c in cfg_b["channels"]]
+    cfg_b["num_residual_blocks"] = cfg_b.get("num_residual_blocks", 0) + 1
+    ea, eb = mt.Encoder(cfg_a).to(DEV), mt.Encoder(cfg_b).to(DEV)
+    xa = torch.randn(2, 3, *CASES["mrssm_default"].audio_shape).to(DEV).requires_grad_()
+    xb = torch.randn(2, 3, *CASES["mrssm_default"].vision_shape).to(DEV).requires_grad_()
+    ya1, yb1 = ea(xa), eb(xb)  # the first call builds the layers on the input's device
+    (ya1.sum() + yb1.square().sum()).backward()
+    want = [ya1.detach(), yb1.detach(), xa.grad.clone(), xb.grad.clone(), *(p.grad.clone() for p in (*ea.parameters(), *eb.parameters()))]
+    xa.grad = xb.grad = None
+    for p in (*ea.parameters(), *eb.parameters()):
+        p.grad = None
+    ya2, yb2 = cnn.encode_pair(ea, eb, xa, xb)
+    (ya2.sum() + yb2.square().sum()).backward()
+    got = [ya2.detach(), yb2.detach(), xa.grad, xb.grad, *(p.grad for p in (*ea.parameters(), *eb.parameters()))]
+    for i, (g, w) in enumerate(zip(got, want, strict=True)):
+        np.testing.assert_allclose(_np(g), _np(w), rtol=1e-5, atol=2e-6 * float(w.abs().max() + 1e-12), err_msg=str(i))
+
+    da_cfg, db_cfg = copy.deepcopy(dict(d.dec_audio)), copy.deepcopy(dict(d.dec_vision))
+    db_cfg["num_residual_blocks"] = 0
+    da, db = mt.Decoder(da_cfg).to(DEV), mt.Decoder(db_cfg).to(DEV)
+    f = torch.randn(2, 3, d.deter + d.stoch).to(DEV)
+    ra, rb = da(f), db(f)
+    pa, pb = cnn.decode_pair(da, db, f, f)
+    np.testing.assert_allclose(_np(pa), _np(ra), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(_np(pb), _np(rb), rtol=1e-6, atol=1e-6)
+
+
 def test_two_stream_branches_change_nothing(lib_loaded: None) -> None:
     """core.fork_join (audio / vision encoders and decoders on two HIP streams, opt-in) against the same step on one
     stream: the same losses and gradients up to the arrival order of fp32 atomics (NLL reduction, weight-gradient kernels)."""
