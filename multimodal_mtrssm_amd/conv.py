@@ -60,12 +60,15 @@ class _PackPlan:
     MoPoE-MRSSM train step).  ``begin_step()`` -- called by ``shared_step`` -- packs the weight views the previous step asked
     for, each into buffers of its own; ``pack_weight`` then finds them there.  An entry is trusted only if it was packed in
     the current epoch and the tensor's version counter has not moved since; ``invalidate()`` (called by ``FlatAdamW.step``,
-    which writes parameters through raw pointers) starts a new epoch.  Anything else is packed on the spot, as before."""
+    which writes parameters through raw pointers) starts a new epoch in which every use packs on the spot, as before, until
+    the next ``begin_step``.  Not seen: in-place edits through ``.data`` between a ``begin_step`` and a later use in the same
+    epoch (``.data`` has its own version counter) -- call ``invalidate_packs()`` after such an edit."""
 
     def __init__(self) -> None:
         # key -> [w (strong ref: keeps the address valid), wp, wq, version, epoch packed, epoch used, serial]
         self.entries: dict[tuple, list] = {}
         self.epoch = 0
+        self.step_epoch = -1  # the epoch begin_step opened; after invalidate() nothing is trusted until the next begin_step
         self.stream = -1  # the stream begin_step packed on: only launches on that stream may read its copies
         self.serial = 0
         self.table: Tensor | None = None
@@ -80,6 +83,7 @@ class _PackPlan:
 
     def begin_step(self, device: torch.device) -> None:
         self.epoch += 1
+        self.step_epoch = self.epoch
         # keep what the last step used (weights of modules that went away leave with their strong reference)
         self.entries = {k: e for k, e in self.entries.items() if e[5] >= self.epoch - 2}
         self.stream = torch.cuda.current_stream(device).cuda_stream
@@ -106,7 +110,7 @@ class _PackPlan:
         if e is None:
             self.serial += 1
             e = self.entries[k] = [w, *_pack_buffers(w), -1, -1, self.epoch, self.serial]
-        if e[4] != self.epoch or e[3] != w._version:
+        if e[4] != self.epoch or e[3] != w._version or self.epoch != self.step_epoch:
             _pack_now(w, e[1], e[2])
             e[3], e[4] = w._version, self.epoch
         e[5] = self.epoch
