@@ -1,8 +1,8 @@
 """bench.py -- seq-steps/s of the MoPoE-MRSSM train step on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: starts its own N worker processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W                   (or under a launcher: RANK / WORLD_SIZE from the env)
 
 One "step" = one full train step (encoders -> initial state -> T-step scan -> decoders -> Gaussian NLL +
 KL -> backward -> [one RCCL all-reduce] -> global-norm clip + AdamW) on one synthetic batch that is already
@@ -12,8 +12,9 @@ frames); the dims BASELINE leaves open are build-chosen and printed in ``config`
 sequence batch data-parallel (weak scaling: 64 sequences per GPU), one process per GPU.
 
 Rank 0 prints ONE JSON line.  ``roofline`` is for the dominant hand-written kernel of the step (HIP events
-on the launch stream inside the timed region); ``cpu_baseline`` times the oracle (``oracle/ref_model.py``,
-the op-for-op eager restatement of the reference loop) on this box's host cores on a bounded sample.
+on the launch stream, 3 steps right after the timed region); ``cpu_baseline`` times the oracle
+(``oracle/ref_model.py``, the op-for-op eager restatement of the reference loop) on this box's host cores at the
+SAME batch (B = 64); ``elbo_rel_delta`` is the loss of the trained weights against that oracle on a 2-row sub-batch.
 """
 
 from __future__ import annotations
@@ -30,9 +31,6 @@ import torch.distributed as dist
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
-# Before HIP initialises: the step uses two compute streams (+ RCCL's); with the default of 4 hardware queues the side
-# stream can land on the default stream's queue and the two modality branches serialise (measured: 24.4 vs 20.8 ms / step).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz
@@ -106,30 +104,31 @@ def host_cores() -> int:
     return max(1, min(n, 16))
 
 
-def cpu_baseline(seconds_budget: float = 20.0) -> dict[str, object]:
-    """The oracle's train step (fwd + bwd + clip + AdamW) on the host cores, same dims, bounded sample."""
-    from oracle.cases import decoder_config, encoder_config
-    from oracle.ref_model import MRSSMDims, OracleMRSSM
+def oracle_model(kind: str):  # noqa: ANN201
+    """The oracle (oracle/ref_model.py) at the bench's exact dims -- the CHECKER: used by cpu_baseline() and elbo_delta() only."""
+    from oracle.cases import CASES, build_model
 
+    case = CASES["mrssm_bench" if kind == "mrssm" else "mmtrssm_bench"]
+    return case, build_model(case)
+
+
+def cpu_baseline(kind: str, seconds_budget: float = 30.0) -> dict[str, object]:
+    """The oracle's train step (fwd + bwd + clip + AdamW) on the host cores at the bench's OWN batch (B = 64, T = 50, the
+    same synthetic tensors rank 0 trains on): like for like with `value`.  One warm-up step, then as
+    many timed steps as fit the budget (at least one, at most three); the median is reported."""
+    case, model = oracle_model(kind)
     w = WORKLOAD
     cores = host_cores()
     torch.set_num_threads(cores)
-    feat = w["deter"] + w["classes"] * w["cats"]
-    dims = MRSSMDims(deter=w["deter"], hidden=w["hidden"], classes=w["classes"], cats=w["cats"], action=w["action"],
-                     embed=w["embed"], enc_audio=encoder_config(w["audio"], w["embed"]),
-                     enc_vision=encoder_config(w["vision"], w["embed"]), dec_audio=decoder_config(feat, w["audio"]),
-                     dec_vision=decoder_config(feat, w["vision"]))
-    torch.manual_seed(42)
-    model = OracleMRSSM(dims)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
-    b = 2  # 2 sequences x 50 steps = 100 seq-steps per CPU train step: a bounded sample of the same workload
-    batch = synthetic_batch(b, "cpu", 1)
-    noise = {"u_init": torch.rand(b, w["cats"]), "u_prior": torch.rand(b, w["steps"], w["cats"]),
-             "u_post": torch.rand(b, w["steps"], w["cats"])}
+    b = w["batch_per_gpu"]
+    batch = synthetic_batch(b, "cpu", 1000)
+    from oracle.cases import build_noise
+    noise = build_noise(case, 7, batch=b, steps=w["steps"])
 
     def step() -> None:
         opt.zero_grad()
-        out = model.shared_step(batch, noise, wasteful=True)
+        out = model.shared_step(batch, noise, wasteful=True) if kind == "mrssm" else model.shared_step(batch, noise)
         out["loss"].backward()
         torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
         opt.step()
@@ -138,15 +137,36 @@ def cpu_baseline(seconds_budget: float = 20.0) -> dict[str, object]:
     step()  # warm-up
     warm = time.perf_counter() - t0
     times: list[float] = []
-    while len(times) < 5 and (len(times) < 1 or (len(times) + 1) * max(times) + warm < seconds_budget):
+    while len(times) < 3 and (not times or warm + sum(times) + max(times) < seconds_budget):
         t0 = time.perf_counter()
         step()
         times.append(time.perf_counter() - t0)
     med = sorted(times)[len(times) // 2]
     return {"value": b * w["steps"] / med, "unit": "seq-steps/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/ref_model.py train step (fwd+bwd+clip+AdamW, reference's discarded draws included), "
-                      f"B={b} T={w['steps']} same dims and frame sizes, median of {len(times)} after 1 warm-up "
+            "sample": f"oracle/ref_model.py train step (fwd+bwd+clip+AdamW; the reference's discarded draws included for MRSSM), "
+                      f"B={b} T={w['steps']}: the bench's own batch, dims and frame sizes; median of {len(times)} after 1 warm-up "
                       f"({warm:.1f}s), {cores} torch threads"}
+
+
+def elbo_delta(model, batch: tuple[torch.Tensor, ...], kind: str, rows: int = 2) -> dict[str, object]:  # noqa: ANN001
+    """ELBO delta vs the reference path (BASELINE metric's second half; ``core.py:187-221`` / mmtrssm ``core.py:563-606``):
+    the model's CURRENT weights are copied by state-dict name into the oracle, both run ``shared_step`` on the first ``rows``
+    sequences of the training batch with the same injected uniforms (seed screened so that no draw sits within 1e-4 of a CDF
+    edge), and every loss term's relative difference is reported.  Outside the timed region; rank 0 only."""
+    from oracle.cases import screened_noise
+
+    case, oracle = oracle_model(kind)
+    oracle.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()}, strict=True)
+    sub = tuple(x[:rows] for x in batch)
+    cpu_sub = tuple(x.cpu() for x in sub)
+    torch.set_num_threads(host_cores())
+    noise, margin, seed = screened_noise(case, oracle, cpu_sub)
+    with torch.no_grad():
+        ref = oracle.shared_step(cpu_sub, noise)
+        out = model.shared_step(sub, {k: v.to(sub[0].device) for k, v in noise.items()})
+    rel = {k: abs(float(out[k]) - float(ref[k])) / max(abs(float(ref[k])), 1e-12) for k in out}
+    return {"loss": rel["loss"], "terms": rel, "reference_loss": float(ref["loss"]), "rows": rows, "noise_seed": seed,
+            "sampling_margin": margin, "tolerance": 1e-4, "ok": bool(max(rel.values()) <= 1e-4)}
 
 
 def feed_benchmark(device: str, batches: int = 20) -> dict[str, object]:
@@ -183,35 +203,74 @@ def feed_benchmark(device: str, batches: int = 20) -> dict[str, object]:
             "what": f"6-tuple batch B={b} T={t} from {n} HBM-resident episodes x {t_full} steps; gather + TakeFirstN + GaussianNoise fused (mtrssm_episode_gather) + torch.randn"}
 
 
-def main() -> None:  # noqa: PLR0914, PLR0915
+def _free_port() -> int:
+    import socket
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def launch_workers(n: int, script: Path | None = None, argv: list[str] | None = None) -> int:
+    """``python bench.py --gpus N`` from a plain shell: start N worker processes (one per GPU) as a CHILD
+    ``torch.distributed.run`` job -- before this process has touched the GPU (importing torch does not) -- and pass rank 0's
+    JSON line through (the children inherit stdout).  Returns the job's exit code (non-zero if any rank failed).
+    ``script`` / ``argv`` default to this file and this process's own arguments (tests/test_parallel_gloo.py drives a CPU
+    worker through the same code)."""
+    import subprocess
+
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, n))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(Path(script or __file__).resolve()), *(sys.argv[1:] if argv is None else argv)]
+    return subprocess.run(cmd, env=env, check=False).returncode
+
+
+def parse_args() -> argparse.Namespace:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-elbo-check", action="store_true")
     ap.add_argument("--model", choices=("mrssm", "mmtrssm"), default="mrssm",
                     help="mrssm = BASELINE configs[1] (the metric's config); mmtrssm = configs[2] (MTState variant)")
-    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even for one rank (exercises the N>1 code path)")
-    ap.add_argument("--two-streams", action="store_true",
-                    help="run the audio / vision branches on two HIP streams (core.fork_join): -9 % step time, but about one run in "
-                         "fifteen stalled on the GPU on this stack (profiles/round1_notes.md); default: one stream")
-    ap.add_argument("--single-stream", action="store_true", help="(default; kept for the commands quoted in profiles/)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the process group even for one rank (exercises the N>1 code path)")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="nccl = RCCL over xGMI (the product path); gloo only to rehearse the launcher and the sharded step on a box with fewer GPUs")
+    ap.add_argument("--share-device", action="store_true",
+                    help="rehearsal only: every rank uses cuda:0 (needs --backend gloo: RCCL refuses two ranks on one GPU)")
+    ap.add_argument("--single-stream", action="store_true", help="(default and only mode; kept for the commands quoted in profiles/round1_*)")
     ap.add_argument("--conv-mfma", choices=("bf16x2", "bf16x3", "f32", "bf16"), default="bf16x2",
                     help="conv MFMA operand format: bf16x2 = two bf16 pieces per fp32 operand, three products, fp32 accumulate (the mode "
                          "the parity tests run in; errors vs golden 7e-7 / 1.3e-7 / 8e-6, tests/mode_errors.py), bf16x3 = three pieces, "
                          "six products (~2^-24), f32 = fp32 MFMA, bf16 = plain bf16 operands (outside the posterior tolerance: dtype bf16)")
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+DTYPE_LABEL = {"bf16x2": "bf16x2-split, fp32 accumulate", "bf16x3": "bf16x3-split, fp32 accumulate", "f32": "f32", "bf16": "bf16"}
+
+
+def main() -> None:  # noqa: PLR0914, PLR0915
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_workers(args.gpus))  # nothing above touched the GPU
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        msg = f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
+        msg = f"--gpus {args.gpus} but WORLD_SIZE={world}"
         raise SystemExit(msg)
+    if args.share_device and args.backend != "gloo":
+        raise SystemExit("--share-device needs --backend gloo")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(local_rank)
-    device = f"cuda:{local_rank}"
+    dev_index = 0 if args.share_device else local_rank
+    torch.cuda.set_device(dev_index)
+    device = f"cuda:{dev_index}"
     use_dist = world > 1 or args.force_dist
+    rccl_ranks = 0
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -221,10 +280,15 @@ def main() -> None:  # noqa: PLR0914, PLR0915
         saved_fd = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
-            warm = torch.zeros(1, device=device)
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+            else:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            warm = torch.ones(1, device=device)
             dist.all_reduce(warm)
             torch.cuda.synchronize()
+            rccl_ranks = int(warm.item()) if args.backend == "nccl" else 0  # ranks that took part in a real RCCL all-reduce
+            assert int(warm.item()) == dist.get_world_size()
         finally:
             sys.stdout.flush()
             os.dup2(saved_fd, 1)
@@ -235,8 +299,6 @@ def main() -> None:  # noqa: PLR0914, PLR0915
     from multimodal_mtrssm_amd.optim import FlatParameters
 
     conv.set_mfma_mode(args.conv_mfma)
-    from multimodal_mtrssm_amd import core as _core
-    _core.BRANCH_STREAMS = bool(args.two_streams) and not args.single_stream
 
     w = WORKLOAD
     model = build_model(device, args.model)
@@ -244,12 +306,15 @@ def main() -> None:  # noqa: PLR0914, PLR0915
     dp = mt.FlatDataParallel(flat)
     dp.broadcast_parameters(0)
     opt = mt.FlatAdamW(flat, lr=1e-3, clip_norm=10.0)
-    b = w["batch_per_gpu"]
+    b, t = w["batch_per_gpu"], w["steps"]
     batch = synthetic_batch(b, device, seed=1000 + rank)  # each rank owns its own 64 sequences (weak scaling)
-    torch.manual_seed(7 + rank)
+    # sampling uniforms keyed by GLOBAL batch row: the same generator state on every rank, the whole
+    # global batch drawn, this rank's rows kept -- a row's trajectory does not depend on the number of ranks
+    noise_source = dp.noise_source(seed=7)
+    shapes = model.noise_shapes(b, t)
 
     def train_step() -> dict[str, torch.Tensor]:
-        noise = None  # uniforms are drawn on the device inside shared_step (torch.rand), as in training
+        noise = noise_source.draw(shapes)
         opt.zero_grad()
         out = model.shared_step(batch, noise)
         out["loss"].backward()
@@ -264,64 +329,55 @@ def main() -> None:  # noqa: PLR0914, PLR0915
 
     for _ in range(args.warmup):
         train_step()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]  # one event per STEP (none per launch)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        marks[i].record()
         scalars = train_step()
+    marks[args.steps].record()
     barrier()
     elapsed = time.perf_counter() - t0
-    # Kernel durations, right AFTER the timed region (HIP events around every launch cost the step ~3 %, and with two
-    # streams a stream's events bracket "previous work of this stream done" .. "kernel done", which includes the wait for
-    # the other stream's kernel to leave room and is not rocprofv3's begin..end of the kernel):
-    #   pass A, 3 steps as timed (two streams when enabled) -> `two_stream_event_avg_us`;
-    #   pass B, 3 steps with the two modality branches on ONE stream -> a kernel's own duration: the `roofline` figures
-    #   (agrees with rocprofv3 --kernel-trace --stats of `bench.py --single-stream`, profiles/).
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = step_ms[len(step_ms) // 2]
+    # Kernel durations, right AFTER the timed region (HIP events around every launch cost the step ~3 %): 3 more steps
+    # with an event pair around each library launch, on the launch stream (agrees with rocprofv3 --kernel-trace --stats
+    # of this command, profiles/).
     kernel_ms: dict[str, dict[str, float]] = {}
-    serial_ms: dict[str, dict[str, float]] = {}
     if rank == 0:
-        def timed_pass() -> dict[str, dict[str, float]]:
-            scan.KERNEL_TIMERS.enable()
-            for _ in range(3):
-                train_step()
-            torch.cuda.synchronize()
-            out = scan.KERNEL_TIMERS.summary()
-            scan.KERNEL_TIMERS.disable()
-            return out
-
-        kernel_ms = timed_pass()
-        if _core.BRANCH_STREAMS:
-            _core.BRANCH_STREAMS = False
+        scan.KERNEL_TIMERS.enable()
+        for _ in range(3):
             train_step()
-            serial_ms = timed_pass()
-            _core.BRANCH_STREAMS = True
-    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.cuda.synchronize()
+        kernel_ms = scan.KERNEL_TIMERS.summary()
+        scan.KERNEL_TIMERS.disable()
+    tt = torch.tensor([elapsed, median_ms], device=device, dtype=torch.float64)
     if use_dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed, median_ms = float(tt[0].item()), float(tt[1].item())
 
     if rank == 0:
-        seq_steps = b * world * w["steps"]
+        seq_steps = b * world * t
         ms = elapsed / args.steps * 1e3
-        # dominant hand-written kernel of the step = the device kernel with the largest total time inside the timed
-        # region (HIP events on the launch stream).  Its algorithmic work is stated by the caller of each launch
-        # (conv.py / scan.py): conv kernels are MFMA-bound (fp32 MFMA, exact fp32), the scan is latency-bound and is
-        # priced against HBM.
-        name, row_timed = max(kernel_ms.items(), key=lambda kv: kv[1]["total_ms"]) if kernel_ms else ("none", None)
-        row = serial_ms.get(name, row_timed)  # the kernel's own duration (one stream) when the timed region used two
+        # dominant hand-written kernel of the step = the device kernel with the largest total time (HIP events on the
+        # launch stream).  Its algorithmic work is stated by the caller of each launch (conv.py / scan.py): conv kernels
+        # are MFMA-bound, the scan is latency-bound and is priced against HBM.
+        timed = {k: v for k, v in kernel_ms.items() if v["flops"] or v["bytes"]}
+        name, row = max(timed.items(), key=lambda kv: kv[1]["total_ms"]) if timed else ("none", None)
         n_steps = 3
         roof: dict[str, object] = {"kernel": name}
         if row:
             secs = row["total_ms"] * 1e-3
-            if "conv_" in name and "thin" not in name:
+            if "conv" in name and "thin" not in name:
                 # algorithmic FLOPs (each multiply-add counted once) against the rate at which the MFMA pipe can deliver
                 # them in this operand format: fp32 MFMA 157.3 TFLOP/s; split kernels issue `products` bf16 MFMAs per
-                # algorithmic block, so their ceiling is the dense bf16 peak / products (bf16x3: 2500 / 6 = 416.7).
+                # algorithmic block, so their ceiling is the dense bf16 peak / products (bf16x2: 2500 / 3 = 833).
                 split = "split_kernel" in name
                 products = MFMA_PRODUCTS[args.conv_mfma] if split else 1
                 peak = MFMA_BF16_PEAK_TFLOPS / products if split else MFMA_F32_PEAK_TFLOPS
                 achieved = row["flops"] / secs / 1e12
                 roof.update(bound="mfma", achieved=achieved, peak=peak, unit="TFLOP/s", frac=achieved / peak,
-                            mfma_products_per_block=products,
+                            mfma_products_per_block=products, frac_of_raw_bf16_peak=achieved / MFMA_BF16_PEAK_TFLOPS,
                             hbm_frac=row["bytes"] / secs / 1e9 / HBM_PEAK_GBS)
             else:
                 achieved = row["bytes"] / secs / 1e9
@@ -330,16 +386,10 @@ def main() -> None:  # noqa: PLR0914, PLR0915
                         algorithmic_flops_per_launch=row["flops"] / row["launches"],
                         algorithmic_bytes_per_launch=row["bytes"] / row["launches"],
                         share_of_step=row["total_ms"] / n_steps / ms)
-            if name in serial_ms:
-                roof["measured"] = ("kernel duration by HIP events on ONE stream, 3 steps right after the timed region (agrees with "
-                                    "rocprofv3 of `bench.py --single-stream`); the timed region itself carries no events (they cost ~3 %) "
-                                    "and runs the audio / vision branches on two streams, where a stream's events would also count the "
-                                    "wait behind the other stream's kernel (two_stream_event_avg_us, 3 more steps)")
-                roof["two_stream_event_avg_us"] = row_timed["avg_ms"] * 1e3
         roof["kernels"] = {k: {"launches_per_step": v["launches"] / 3, "avg_us": round(v["avg_ms"] * 1e3, 1),
                                "ms_per_step": round(v["total_ms"] / 3, 3),
                                "tflops": round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 2) if v["total_ms"] else None}
-                           for k, v in sorted((serial_ms or kernel_ms).items(), key=lambda kv: -kv[1]["total_ms"])}
+                           for k, v in sorted(kernel_ms.items(), key=lambda kv: -kv[1]["total_ms"])}
         line = {
             "metric": "seq-steps/s (BxT) MoPoE-MRSSM train step" if args.model == "mrssm" else "seq-steps/s (BxT) MoPoE-MMTRSSM train step",
             "value": seq_steps / (elapsed / args.steps),
@@ -348,34 +398,46 @@ def main() -> None:  # noqa: PLR0914, PLR0915
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms,
+            "ms_per_step_median": median_ms,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "bf16" if args.conv_mfma == "bf16" else "f32",
+            "dtype": DTYPE_LABEL[args.conv_mfma],
             "data": "synthetic",
             "config": {
                 "workload": ("BASELINE configs[1]: MoPoE-MRSSM train step, B=64/GPU T=50 deter=200 stoch=30, vision 1x64x64 + audio 1x128x32 + action 4"
                              if args.model == "mrssm" else
                              "BASELINE configs[2]: MoPoE-MMTRSSM (MTState, tau 2/4) train step, B=64/GPU T=50 ld=hd=200 ls=hs=30, same frames"),
-                "global_batch": b * world, "seq_len": w["steps"], "parallelism": f"dp{world}",
+                "global_batch": b * world, "seq_len": t, "parallelism": f"dp{world}",
                 "hidden": w["hidden"], "embed": w["embed"], "categoricals_x_classes": f"{w['cats']}x{w['classes']}",
                 "enc_channels": [8, 16, 32], "dec_channels": [32, 16, 1], "residual_blocks": 3, "activation": "ELU",
-                "optimizer": "AdamW lr 1e-3 + clip 10 (fused HIP)", "params": flat.numel,
-                "streams": 2 if _core.BRANCH_STREAMS else 1,
-                "conv_mfma": {"bf16x3": "fp32 operands as 3 bf16 pieces, 6 bf16-MFMA products, fp32 accumulate (~2^-24 per product)",
-                              "bf16x2": "fp32 operands as 2 bf16 pieces, 3 bf16-MFMA products, fp32 accumulate; the mode of the parity tests "
-                                        "(vs golden: losses 7e-7 rel, posterior 1.3e-7, gradients 8e-6 of max)",
+                "optimizer": "AdamW lr 1e-3 + clip 10 (fused HIP)", "params": flat.numel, "streams": 1,
+                "backend": (args.backend if use_dist else "none"), "rccl_ranks": rccl_ranks,
+                "noise": "uniforms keyed by global batch row (parallel.GlobalRowNoise)",
+                "conv_mfma": {"bf16x3": "fp32 tensors; conv MFMA operands as 3 bf16 pieces, 6 bf16-MFMA products, fp32 accumulate (~2^-24 per product)",
+                              "bf16x2": "fp32 tensors; conv MFMA operands as 2 bf16 pieces (16 significant bits), 3 bf16-MFMA products, fp32 "
+                                        "accumulate; the mode of the parity tests (vs golden: losses 7e-7 rel, posterior 1.3e-7, gradients 8e-6 "
+                                        "of max); scan, losses and optimizer in fp32",
                               "f32": "fp32 MFMA", "bf16": "bf16 operands, fp32 accumulate; tensors, scan, losses, optimizer fp32"}[args.conv_mfma],
             },
             "loss": float(scalars["loss"]),
             "roofline": roof,
         }
+        if not args.no_elbo_check:
+            # "ELBO delta vs ref" (the metric's second half): the trained weights of THIS run against the oracle on a 2-row
+            # sub-batch, outside the timed region
+            delta = elbo_delta(model, batch, args.model)
+            line["elbo_rel_delta"] = delta["loss"]
+            line["elbo_check"] = delta
         if world == 1:
             line["data_feed"] = feed_benchmark(device)
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline()
+            base = cpu_baseline(args.model)
+            line["cpu_baseline"] = base
+            line["speedup_vs_cpu"] = line["value"] / base["value"]
         print(json.dumps(line), flush=True)
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
 
 

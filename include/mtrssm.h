@@ -435,6 +435,17 @@ int mtrssm_sumsq(const float* x, int64_t n, float* out, void* stream);
 int mtrssm_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                       const float* sumsq, float clip_norm, float grad_scale, float lr, float beta1,
                       float beta2, float eps, float weight_decay, int32_t step, void* stream);
+/* The same step with its scalars in device memory, so that it can sit inside a captured hipGraph (FlatAdamW's path):
+ *   state[4] (device floats): [0] learning rate (the host writes it when a scheduler changes it), [1] steps taken,
+ *   [2] 1 - beta1^step, [3] sqrt(1 - beta2^step).  mtrssm_adamw_prepare = zero `sumsq`, sum(grad^2) into it, step += 1 and the
+ *   two bias corrections; mtrssm_adamw_apply = clip + AdamW reading `state`.
+ *   active (n bytes, may be NULL = all): 0 marks elements of parameters that never received a gradient; they are left
+ *   untouched (no decay, no moments) as torch.optim.AdamW does for `.grad is None` -- MMTRSSM's l_posterior and dummy
+ *   transition (mmtrssm/mopoe_mmtrssm/core.py:143-151,188). */
+int mtrssm_adamw_prepare(const float* grad, int64_t n, float* sumsq, float* state, float beta1, float beta2, void* stream);
+int mtrssm_adamw_apply(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const uint8_t* active, int64_t n,
+                       const float* sumsq, const float* state, float clip_norm, float grad_scale, float beta1, float beta2,
+                       float eps, float weight_decay, void* stream);
 
 #ifdef __cplusplus
 }

@@ -99,6 +99,8 @@ SYMBOLS: dict[str, tuple[type | None, list[type]]] = {
     "mtrssm_gaussian_nll_bwd": (C.c_int, [_p, _p, _p, C.c_int64, C.c_int64, _p, _p]),
     "mtrssm_sumsq": (C.c_int, [_p, C.c_int64, _p, _p]),
     "mtrssm_adamw_step": (C.c_int, [_p, _p, _p, _p, C.c_int64, _p, _f, _f, _f, _f, _f, _f, _f, _i, _p]),
+    "mtrssm_adamw_prepare": (C.c_int, [_p, C.c_int64, _p, _p, _f, _f, _p]),
+    "mtrssm_adamw_apply": (C.c_int, [_p, _p, _p, _p, _p, C.c_int64, _p, _p, _f, _f, _f, _f, _f, _f, _p]),
 }
 
 _LIB: C.CDLL | None = None

@@ -42,72 +42,11 @@ except ImportError:  # this image: a LightningModule-shaped nn.Module
 
 Noise = dict[str, Tensor | None]
 
-# The audio and vision branches (encoders; decoders + their NLL) are independent.  Each conv kernel is a few rounds of
-# workgroup tiles with a partly empty last round, so the two branches can run on two HIP streams and
-# fill each other's tails (-9 % step time, values unchanged); autograd replays the backward of each branch on the stream
-# its forward ran on.  OFF by default: on this stack (ROCm 7.2, torch 2.10) about one 65-step run in fifteen stopped
-# making progress on the GPU with the two streams on -- 6 of 84 runs with the encoders' branch on two streams, 0 of 30 with
-# only the decoders', 0 of 36 on one stream (profiles/round1_notes.md).  `bench.py --two-streams` / BRANCH_STREAMS = True
-# turn it on.
-BRANCH_STREAMS = False
-_SIDE_STREAMS: dict[int, torch.cuda.Stream] = {}
-
-
-# With two streams and the host several steps ahead of the GPU, the cross-stream waits stopped making progress on the GPU
-# (reproducible hang after 25-45 queued steps, profiles/round1_notes.md); at most MAX_INFLIGHT_STEPS shared_step calls are
-# therefore kept in flight.  The GPU never idles for it: the host needs ~14 ms per step, the GPU ~21.
-MAX_INFLIGHT_STEPS = 2
-_INFLIGHT: dict[int, list[torch.cuda.Event]] = {}
-
-
-def bound_run_ahead(dev: torch.device) -> None:
-    if not BRANCH_STREAMS or dev.type != "cuda":
-        return
-    q = _INFLIGHT.setdefault(dev.index or 0, [])
-    ev = torch.cuda.Event()
-    ev.record(torch.cuda.current_stream(dev))
-    q.append(ev)
-    if len(q) > MAX_INFLIGHT_STEPS:
-        q.pop(0).synchronize()
-
-
-def _tensors(x: object):  # noqa: ANN202
-    if isinstance(x, Tensor):
-        yield x
-    elif isinstance(x, (tuple, list)):
-        for y in x:
-            yield from _tensors(y)
-    elif isinstance(x, dict):
-        for y in x.values():
-            yield from _tensors(y)
-
-
-def fork_join(side_fn, main_fn, *inputs: Tensor):  # noqa: ANN001, ANN201
-    """``(side_fn(), main_fn())`` with ``side_fn`` on a second stream of the current device (ordered after everything
-    already enqueued on the current stream, joined before returning)."""
-    dev = next((t.device for t in inputs if t.is_cuda), None)
-    if not BRANCH_STREAMS or dev is None:
-        return side_fn(), main_fn()
-    cur = torch.cuda.current_stream(dev)
-    side = _SIDE_STREAMS.get(dev.index)
-    if side is None:
-        side = _SIDE_STREAMS[dev.index] = torch.cuda.Stream(dev)
-    side.wait_stream(cur)
-    for t in inputs:
-        if t.is_cuda:
-            t.record_stream(side)
-    with torch.cuda.stream(side):
-        a = side_fn()
-    b = main_fn()
-    cur.wait_stream(side)
-    for t in _tensors(a):
-        t.record_stream(cur)
-    return a, b
-
-
 def _pairable(a: nn.Module, b: nn.Module, kind: type) -> bool:
-    """Paired launches (``conv.paired``) replace the two-stream overlap on one stream, for this package's own stacks."""
-    return conv.PAIR_LAUNCH and not BRANCH_STREAMS and isinstance(a, kind) and isinstance(b, kind)
+    """Paired launches (``conv.paired``): the audio and the vision stack's equal layers share one grid (this package's own
+    stacks only).  Everything runs on ONE stream: a two-stream variant of the step was removed in round 2 (it bought nothing
+    once the layers were paired and stalled the GPU in about one run in fifteen, profiles/round1_notes.md)."""
+    return conv.PAIR_LAUNCH and isinstance(a, kind) and isinstance(b, kind)
 
 
 def _st_onehot(dist: MultiOneHot, u: Tensor | None) -> Tensor:
@@ -190,7 +129,7 @@ class MoPoE_MRSSM(_Base):  # noqa: N801
         """Both encoders over all B*T frames; equal-shaped residual blocks of the two stacks share launches."""
         if _pairable(self.audio_encoder, self.vision_encoder, cnn.Encoder):
             return cnn.encode_pair(self.audio_encoder, self.vision_encoder, audio_obs, vision_obs)
-        return fork_join(lambda: self.audio_encoder(audio_obs), lambda: self.vision_encoder(vision_obs), audio_obs, vision_obs)
+        return self.audio_encoder(audio_obs), self.vision_encoder(vision_obs)
 
     def _reconstruction_losses(self, feature: Tensor, targets: dict[str, Tensor]) -> dict[str, Tensor]:
         """``decode_state`` + ``compute_reconstruction_loss`` (``mrssm core.py:262-308``)."""
@@ -199,10 +138,8 @@ class MoPoE_MRSSM(_Base):  # noqa: N801
             audio = likelihood(prediction=pa, target=targets["recon/audio"], event_ndims=3)
             vision = likelihood(prediction=pv, target=targets["recon/vision"], event_ndims=3)
             return {"recon": audio + vision, "recon/audio": audio, "recon/vision": vision}
-        audio, vision = fork_join(
-            lambda: likelihood(prediction=self.audio_decoder(feature), target=targets["recon/audio"], event_ndims=3),
-            lambda: likelihood(prediction=self.vision_decoder(feature), target=targets["recon/vision"], event_ndims=3),
-            feature, targets["recon/audio"], targets["recon/vision"])
+        audio = likelihood(prediction=self.audio_decoder(feature), target=targets["recon/audio"], event_ndims=3)
+        vision = likelihood(prediction=self.vision_decoder(feature), target=targets["recon/vision"], event_ndims=3)
         return {"recon": audio + vision, "recon/audio": audio, "recon/vision": vision}
 
     # -- states ---------------------------------------------------------------------------------
@@ -216,6 +153,12 @@ class MoPoE_MRSSM(_Base):  # noqa: N801
         """``core.py:121-135``: fused embedding -> ``init_proj`` -> prior head -> sampled State."""
         u = None if noise is None else noise.get("u_init")
         return self._initial_from_embed(self.encode_observation(observation), u).to(self.device)
+
+    def noise_shapes(self, batch: int, steps: int) -> dict[str, tuple[int, ...]]:
+        """Uniforms one ``shared_step`` consumes (one per categorical and draw; row = batch row).  Data-parallel runs
+        draw them for the GLOBAL batch and slice rows (``parallel.GlobalRowNoise``) so results do not depend on the rank count."""
+        k = self.transition.distribution_factory.category_size
+        return {"u_init": (batch, k), "u_post": (batch, steps, k)}
 
     def _rollout_embedded(self, actions: Tensor, audio_embed: Tensor, vision_embed: Tensor, prev_state: State,
                           noise: Noise | None, *, sample_prior: bool) -> dict[str, Tensor]:
@@ -271,7 +214,6 @@ class MoPoE_MRSSM(_Base):  # noqa: N801
         """``core.py:187-221``: ``loss = recon + kl_coeff * KL(post || prior)``."""
         action_input = batch[0]
         audio_obs, vision_obs = self.get_observations_from_batch(batch)
-        bound_run_ahead(audio_obs.device)
         conv.begin_step(audio_obs.device)
         audio_embed, vision_embed = self._encode_both(audio_obs, vision_obs)
         u_init = None if noise is None else noise.get("u_init")
@@ -373,6 +315,10 @@ class MoPoE_MMTRSSM(MoPoE_MRSSM):  # noqa: N801
         obs_embed = self.encode_observation(observation) if isinstance(observation, tuple) else observation
         return self._initial_from_embed(obs_embed, noise).to(obs_embed.device)
 
+    def noise_shapes(self, batch: int, steps: int) -> dict[str, tuple[int, ...]]:  # type: ignore[override]
+        kl, kh = self.l_dist.category_size, self.h_dist.category_size
+        return {"u_init_h": (batch, kh), "u_init_l": (batch, kl), "u_post_l": (batch, steps, kl), "u_post_h": (batch, steps, kh)}
+
     @staticmethod
     def _state_dict_of(state: MTState) -> dict[str, Tensor]:
         return {"deter_l": state.deter_l, "deter_h": state.deter_h, "hidden_l": state.hidden_l, "hidden_h": state.hidden_h,
@@ -433,7 +379,6 @@ class MoPoE_MMTRSSM(MoPoE_MRSSM):  # noqa: N801
         """``mmtrssm core.py:563-606``: ``loss = recon + kl_coeff KL_l + kl_coeff w_kl_h KL_h``."""
         action_input = batch[0]
         audio_obs, vision_obs = self.get_observations_from_batch(batch)
-        bound_run_ahead(audio_obs.device)
         conv.begin_step(audio_obs.device)
         audio_embed, vision_embed = self._encode_both(audio_obs, vision_obs)
         state0 = self._initial_from_embed((audio_embed[:, 0] + vision_embed[:, 0]) / 2.0, noise)

@@ -36,6 +36,9 @@ int nll_fwd_launch(const float*, const float*, int64_t, int64_t, float*, hipStre
 int nll_bwd_launch(const float*, const float*, const float*, int64_t, int64_t, float*, hipStream_t);
 int sumsq_launch(const float*, int64_t, float*, hipStream_t);
 int adamw_launch(float*, const float*, float*, float*, int64_t, const float*, float, float, float, float, float, float, float, int, hipStream_t);
+int adamw_prepare_launch(const float*, int64_t, float*, float*, float, float, hipStream_t);
+int adamw_apply_launch(float*, const float*, float*, float*, const unsigned char*, int64_t, const float*, const float*, float, float, float, float,
+                       float, float, hipStream_t);
 
 }  // namespace mtrssm
 
@@ -72,6 +75,15 @@ MTRSSM_API int mtrssm_adamw_step(float* param, const float* grad, float* exp_avg
                                  int32_t step, void* stream) {
   return adamw_launch(param, grad, exp_avg, exp_avg_sq, n, sumsq, clip_norm, grad_scale, lr, beta1, beta2, eps, weight_decay, step,
                       static_cast<hipStream_t>(stream));
+}
+MTRSSM_API int mtrssm_adamw_prepare(const float* grad, int64_t n, float* sumsq, float* state, float beta1, float beta2, void* stream) {
+  return adamw_prepare_launch(grad, n, sumsq, state, beta1, beta2, static_cast<hipStream_t>(stream));
+}
+MTRSSM_API int mtrssm_adamw_apply(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const uint8_t* active, int64_t n,
+                                  const float* sumsq, const float* state, float clip_norm, float grad_scale, float beta1, float beta2,
+                                  float eps, float weight_decay, void* stream) {
+  return adamw_apply_launch(param, grad, exp_avg, exp_avg_sq, active, n, sumsq, state, clip_norm, grad_scale, beta1, beta2, eps,
+                            weight_decay, static_cast<hipStream_t>(stream));
 }
 MTRSSM_API int mtrssm_conv_gather_gemm(const MtrssmConvGeom* g, const float* src, const float* src2, const float* wp, const uint16_t* wq,
                                        const float* bias, const float* actgrad_in, const float* add_in, float* out, void* stream) {

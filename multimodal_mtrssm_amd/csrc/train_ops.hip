@@ -102,6 +102,57 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
   }
 }
 
+// Graph-safe variant: the learning rate and the step count live in device memory (`state`: [0] lr, [1] steps taken,
+// [2] 1 - b1^step, [3] sqrt(1 - b2^step)), so a captured train step replays with the right bias correction and sees a
+// scheduler's new lr without re-capture.  `active` (one byte per element, may be null) marks the parameters that have ever
+// received a gradient: torch.optim.AdamW skips parameters whose .grad is None (no decay, no moments) -- MMTRSSM's
+// l_posterior and dummy transition (mmtrssm/mopoe_mmtrssm/core.py:143-151,188).
+__global__ void sumsq_tick_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out, float* __restrict__ state,
+                                  float b1, float b2) {
+  __shared__ float red[kThreads / kWave];
+  if (blockIdx.x == 0 && threadIdx.x == 0 && state) {  // one optimizer step = one launch of this kernel
+    const float step = state[1] + 1.f;
+    state[1] = step;
+    state[2] = 1.f - powf(b1, step);
+    state[3] = sqrtf(1.f - powf(b2, step));
+  }
+  const int64_t n4 = n / 4;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 v = x4[i];
+    acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  if (blockIdx.x == 0)
+    for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) acc += x[i] * x[i];
+  const float tot = block_sum(acc, red);
+  if (threadIdx.x == 0) atomicAdd(out, tot);
+}
+
+__global__ void adamw_masked_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                    const unsigned char* __restrict__ active, int64_t n, const float* __restrict__ sumsq,
+                                    const float* __restrict__ state, float clip, float gscale, float b1, float b2, float eps,
+                                    float wd) {
+  const float lr = state[0], bc1 = state[2], bc2_sqrt = state[3];
+  float coef = gscale;
+  if (clip > 0.f && sumsq) {
+    const float norm = sqrtf(sumsq[0]) * gscale;
+    coef *= fminf(1.f, clip / (norm + 1e-6f));
+  }
+  const float step = lr / bc1;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    if (active && !active[i]) continue;
+    const float gi = g[i] * coef;
+    float pi = p[i] * (1.f - lr * wd);
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    pi -= step * mi / (sqrtf(vi) / bc2_sqrt + eps);
+    p[i] = pi;
+  }
+}
+
 static int grid_for(int64_t n) {
   int64_t g = (n + kThreads - 1) / kThreads;
   return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
@@ -155,6 +206,25 @@ int adamw_launch(float* p, const float* g, float* m, float* v, int64_t n, const 
   set_last_kernel("mtrssm::adamw_kernel");
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(kThreads), 0, s, p, g, m, v, n, sumsq, clip, gscale, lr, b1, b2, eps, wd, bc1, bc2_sqrt);
   return check_launch("adamw_step");
+}
+
+int adamw_prepare_launch(const float* g, int64_t n, float* sumsq, float* state, float b1, float b2, hipStream_t s) {
+  if (!g || !sumsq || !state || n <= 0) { set_error("adamw_prepare: bad argument"); return MTRSSM_EINVAL; }
+  if ((uintptr_t)g & 15) { set_error("adamw_prepare: grad must be 16-byte aligned"); return MTRSSM_EINVAL; }
+  hipError_t e = hipMemsetAsync(sumsq, 0, sizeof(float), s);
+  if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return MTRSSM_ELAUNCH; }
+  set_last_kernel("mtrssm::sumsq_tick_kernel");
+  hipLaunchKernelGGL(sumsq_tick_kernel, dim3(grid_for(n / 4)), dim3(kThreads), 0, s, g, n, sumsq, state, b1, b2);
+  return check_launch("adamw_prepare");
+}
+
+int adamw_apply_launch(float* p, const float* g, float* m, float* v, const unsigned char* active, int64_t n, const float* sumsq,
+                       const float* state, float clip, float gscale, float b1, float b2, float eps, float wd, hipStream_t s) {
+  if (!p || !g || !m || !v || !state || n <= 0) { set_error("adamw_apply: bad argument"); return MTRSSM_EINVAL; }
+  set_last_kernel("mtrssm::adamw_masked_kernel");
+  hipLaunchKernelGGL(adamw_masked_kernel, dim3(grid_for(n)), dim3(kThreads), 0, s, p, g, m, v, active, n, sumsq, state, clip, gscale,
+                     b1, b2, eps, wd);
+  return check_launch("adamw_apply");
 }
 
 // ------------------------------------------------------------------------------------------------

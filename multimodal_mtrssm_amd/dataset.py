@@ -144,34 +144,54 @@ class _Stream:
 class DeviceEpisodeLoader:
     """Iterable of 6-tuple batches over device-resident episodes (what ``train_dataloader`` / ``val_dataloader`` return).
 
-    ``shuffle`` draws a fresh device permutation per epoch; ``rank`` / ``world`` give each data-parallel rank a disjoint
-    slice of it (rows of one global batch, as ``FlatDataParallel.shard`` would cut them).  The last batch may be short
+    ``shuffle`` draws a fresh permutation per epoch from a CPU generator seeded ``seed + epoch`` -- the SAME order on every
+    data-parallel rank -- and ``rank`` / ``world`` give each rank a disjoint slice of every global batch (the rows
+    ``FlatDataParallel.shard`` would cut).  All ranks yield the same number of equally sized batches: a batch whose size
+    is not a multiple of ``world`` is padded by wrapping to the head of the epoch's order (``DistributedSampler``'s rule),
+    so the per-step all-reduce never waits for a rank that ran out of rows.  With one rank the last batch may be short
     (the reference's DataLoader keeps it too)."""
 
-    def __init__(self, streams: tuple[_Stream, _Stream, _Stream], batch_size: int, *, shuffle: bool, rank: int = 0, world: int = 1) -> None:
+    def __init__(self, streams: tuple[_Stream, _Stream, _Stream], batch_size: int, *, shuffle: bool, rank: int = 0, world: int = 1,  # noqa: PLR0913
+                 seed: int = 0) -> None:
         self.streams = streams
         self.batch_size = int(batch_size)
         self.shuffle = shuffle
-        self.rank, self.world = rank, world
+        self.rank, self.world = int(rank), int(world)
+        self.seed, self.epoch = int(seed), 0
         self.n = int(streams[0].store.shape[0])
 
     def __len__(self) -> int:
         return (self.n + self.batch_size - 1) // self.batch_size
+
+    def set_epoch(self, epoch: int) -> None:
+        self.epoch = int(epoch)
 
     def batch(self, idx: Tensor, noise: tuple[Tensor | None, Tensor | None, Tensor | None] = (None, None, None)) -> tuple[Tensor, ...]:
         """The 6-tuple for episode indices ``idx`` (int64, on the device); ``noise`` injects the standard normals."""
         pairs = [s.batch(idx, n) for s, n in zip(self.streams, noise, strict=True)]
         return (pairs[0][0], pairs[1][0], pairs[2][0], pairs[0][1], pairs[1][1], pairs[2][1])
 
-    def __iter__(self) -> Iterator[tuple[Tensor, ...]]:
+    def index_batches(self) -> Iterator[Tensor]:
+        """This rank's episode indices, batch by batch, for the current epoch (then the epoch counter advances)."""
         dev = self.streams[0].store.device
-        order = torch.randperm(self.n, device=dev) if self.shuffle else torch.arange(self.n, device=dev)
+        if self.shuffle:
+            g = torch.Generator().manual_seed(self.seed + self.epoch)
+            order = torch.randperm(self.n, generator=g).to(dev)
+        else:
+            order = torch.arange(self.n, device=dev)
+        self.epoch += 1
         for lo in range(0, self.n, self.batch_size):
             rows = order[lo: lo + self.batch_size]
             if self.world > 1:
+                pad = (-rows.numel()) % self.world
+                if pad:
+                    rows = torch.cat([rows, order[torch.arange(pad, device=dev) % self.n]])
                 rows = rows[self.rank:: self.world]
-            if rows.numel():
-                yield self.batch(rows.contiguous())
+            yield rows.contiguous()
+
+    def __iter__(self) -> Iterator[tuple[Tensor, ...]]:
+        for rows in self.index_batches():
+            yield self.batch(rows)
 
 
 class EpisodeDataModule(_Base):

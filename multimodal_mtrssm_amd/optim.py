@@ -10,9 +10,11 @@ loss scalars), so that
 
 Semantics follow the reference's trainer config: ``torch.optim.AdamW(lr=1e-3)`` (betas 0.9/0.999, eps
 1e-8, weight_decay 1e-2) and ``gradient_clip_val: 10`` by global norm
-(``mrssm/mopoe_mrssm/configs/default.yaml:103-107,119``).  One difference: parameters that never receive
-a gradient (MMTRSSM's dead ``l_posterior`` / dummy ``transition``, SURVEY.md section 2 "Hazard") see a zero
-gradient here rather than being skipped, i.e. they still decay.
+(``mrssm/mopoe_mrssm/configs/default.yaml:103-107,119``), including torch's rule that a parameter whose
+``.grad`` is None is skipped entirely (no decay, no moments): parameters that never receive a gradient (MMTRSSM's
+dead ``l_posterior`` / dummy ``transition``, SURVEY.md section 2 "Hazard") are masked out of the fused step, so a
+checkpoint trained here equals torch's on those tensors too.  The learning rate and the step count live in
+device memory, so the whole step can sit inside a captured hipGraph (``graph.CapturedTrainStep``).
 """
 
 from __future__ import annotations
@@ -49,22 +51,65 @@ class FlatParameters:
         self.grad = self.grad_full[:total]
         self.tail = self.grad_full[total:]
         self.params = params
+        self.offsets = offsets
+        # which parameters have EVER been handed a gradient by autograd (torch.optim skips `.grad is None` parameters; with
+        # pre-set gradient views "None" cannot be observed, so a one-shot hook per parameter records the first accumulation)
+        self.touched = [False] * len(params)
+        self.touched_version = 0
+        self._hooks: list = []
         with torch.no_grad():
-            for p, off in zip(params, offsets, strict=True):
+            for i, (p, off) in enumerate(zip(params, offsets, strict=True)):
                 view = self.param[off : off + p.numel()].view_as(p)
                 view.copy_(p.data)
                 p.data = view
                 p.grad = self.grad[off : off + p.numel()].view_as(p)
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._touch_hook(i)))
+        self._grad_ptrs = [p.grad.data_ptr() for p in params]
+
+    def _touch_hook(self, i: int):  # noqa: ANN202
+        def hook(_p: Tensor) -> None:
+            self.mark_touched(i)
+        return hook
+
+    def mark_touched(self, i: int) -> None:
+        """Parameter ``i`` received a gradient (autograd's accumulation hook, or a kernel that wrote its flat view)."""
+        if not self.touched[i]:
+            self.touched[i] = True
+            self.touched_version += 1
+
+    def prune_hooks(self) -> None:
+        """Drop the one-shot hooks of parameters already seen (called between steps, never from inside backward)."""
+        for i, h in enumerate(self._hooks):
+            if h is not None and self.touched[i]:
+                h.remove()
+                self._hooks[i] = None
+
+    def index_of(self, p: Tensor) -> int | None:
+        """Index of the parameter whose flat view starts at ``p``'s address (None if ``p`` is not one of them)."""
+        if not hasattr(self, "_by_ptr"):
+            self._by_ptr = {q.data_ptr(): i for i, q in enumerate(self.params)}
+        return self._by_ptr.get(p.data_ptr())
+
+    def active_mask(self) -> Tensor | None:
+        """One byte per flat element: 1 where the parameter has ever received a gradient; None when all have."""
+        if all(self.touched):
+            return None
+        mask = torch.zeros(self.numel, dtype=torch.uint8)
+        for p, off, t in zip(self.params, self.offsets, self.touched, strict=True):
+            if t:
+                mask[off : off + p.numel()] = 1
+        return mask.to(self.param.device)
 
     def zero_grad(self) -> None:
         self.grad_full.zero_()
 
     def check_views(self) -> None:
-        """Raise if something replaced a ``.grad`` (e.g. ``zero_grad(set_to_none=True)``)."""
-        base = self.grad_full.untyped_storage().data_ptr()
-        for p in self.params:
-            if p.grad is None or p.grad.untyped_storage().data_ptr() != base:
-                msg = "a parameter's .grad no longer aliases the flat gradient buffer; use FlatParameters.zero_grad()"
+        """Raise if something replaced a ``.grad`` (e.g. a stock ``model.zero_grad()``, whose set_to_none=True makes autograd
+        allocate fresh gradients that the flat optimizer step would never see)."""
+        for p, want in zip(self.params, self._grad_ptrs, strict=True):
+            if p.grad is None or p.grad.data_ptr() != want:
+                msg = ("a parameter's .grad no longer aliases the flat gradient buffer (model.zero_grad() / set_to_none?); "
+                       "use FlatParameters.zero_grad() or FlatAdamW.zero_grad()")
                 raise RuntimeError(msg)
 
 
@@ -80,24 +125,52 @@ class FlatAdamW:
         self.sumsq = torch.zeros(1, device=flat.param.device, dtype=torch.float32)
         self.steps = 0
         self.param_groups = [{"lr": lr}]  # lr schedulers (ReduceLROnPlateau, yaml 109-114) mutate this
+        # device-resident scalars read by the kernels: [lr, steps taken, 1 - b1^step, sqrt(1 - b2^step)]
+        self.state = torch.tensor([lr, 0.0, 0.0, 0.0], dtype=torch.float32).to(flat.param.device)
+        self._lr_on_device = float(lr)
+        self._mask: Tensor | None = None
+        self._mask_version = -1
 
     def zero_grad(self, set_to_none: bool = False) -> None:  # noqa: FBT001, FBT002
         del set_to_none  # the views must survive
         self.flat.zero_grad()
 
+    def sync_lr(self) -> None:
+        """Upload ``param_groups[0]["lr"]`` if a scheduler changed it (an eager fill; call it OUTSIDE a graph capture)."""
+        lr = float(self.param_groups[0]["lr"])
+        if lr != self._lr_on_device:
+            self.state[0:1].fill_(lr)
+            self._lr_on_device = lr
+
+    def active_mask(self) -> Tensor | None:
+        if self._mask_version != self.flat.touched_version:
+            self.flat.prune_hooks()
+            self._mask = self.flat.active_mask()
+            self._mask_version = self.flat.touched_version
+        return self._mask
+
     @torch.no_grad()
-    def step(self, grad_scale: float = 1.0) -> Tensor:
-        """Clip by global norm (after ``grad_scale``), then AdamW.  Returns the device scalar sum(g^2)."""
+    def step(self, grad_scale: float = 1.0, *, check: bool = True) -> Tensor:
+        """Clip by global norm (after ``grad_scale``), then AdamW.  Returns the device scalar sum(g^2).
+
+        Two launches (+ one 4-byte memset), no host-side scalar in either: safe inside a hipGraph capture (call
+        ``sync_lr()`` before replays when a scheduler may have changed the rate; ``check`` then has to be False)."""
         lib = _lib.load()
         f = self.flat
+        if check:
+            f.check_views()
+            self.sync_lr()
         stream = _lib.stream_ptr(f.param.device)
         self.steps += 1
-        lr = float(self.param_groups[0]["lr"])
-        _lib.check(lib.mtrssm_sumsq(_lib.ptr(f.grad), f.numel, _lib.ptr(self.sumsq), stream), "mtrssm_sumsq")
-        _lib.check(lib.mtrssm_adamw_step(
-            _lib.ptr(f.param), _lib.ptr(f.grad), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq), f.numel,
-            _lib.ptr(self.sumsq), float(self.clip_norm), float(grad_scale), lr, self.betas[0], self.betas[1], self.eps,
-            self.weight_decay, self.steps, stream), "mtrssm_adamw_step")
+        mask = self.active_mask()
+        _lib.check(_lib.TIMERS.call("mtrssm_adamw_prepare", lib.mtrssm_adamw_prepare, _lib.ptr(f.grad), f.numel, _lib.ptr(self.sumsq),
+                                    _lib.ptr(self.state), self.betas[0], self.betas[1], stream, nbytes=4.0 * f.numel),
+                   "mtrssm_adamw_prepare")
+        _lib.check(_lib.TIMERS.call(
+            "mtrssm_adamw_apply", lib.mtrssm_adamw_apply, _lib.ptr(f.param), _lib.ptr(f.grad), _lib.ptr(self.exp_avg),
+            _lib.ptr(self.exp_avg_sq), _lib.raw_ptr(mask), f.numel, _lib.ptr(self.sumsq), _lib.ptr(self.state), float(self.clip_norm),
+            float(grad_scale), self.betas[0], self.betas[1], self.eps, self.weight_decay, stream, nbytes=28.0 * f.numel),
+            "mtrssm_adamw_apply")
         conv.invalidate_packs()  # the parameters changed behind autograd's version counters
         return self.sumsq
 
@@ -109,6 +182,8 @@ class FlatAdamW:
         self.exp_avg_sq.copy_(state["exp_avg_sq"])  # type: ignore[arg-type]
         self.steps = int(state["steps"])  # type: ignore[arg-type]
         self.param_groups[0]["lr"] = float(state["lr"])  # type: ignore[arg-type]
+        self.state.copy_(torch.tensor([float(state["lr"]), float(self.steps), 0.0, 0.0]))  # type: ignore[arg-type]
+        self._lr_on_device = float(state["lr"])  # type: ignore[arg-type]
 
 
 class ReduceLROnPlateau:
@@ -159,6 +234,7 @@ def load_reference_checkpoint(module: nn.Module, path: str, *, strict: bool = Tr
     state = ckpt["state_dict"] if isinstance(ckpt, dict) and "state_dict" in ckpt else ckpt
     with torch.no_grad():  # parameters may be views of a FlatParameters buffer: copy in place
         missing, unexpected = module.load_state_dict(state, strict=strict)
+    conv.invalidate_packs()  # packed conv-weight copies of the old values must not outlive the load
     rest = {k: v for k, v in ckpt.items() if k != "state_dict"} if isinstance(ckpt, dict) and "state_dict" in ckpt else {}
     rest["missing_keys"], rest["unexpected_keys"] = list(missing), list(unexpected)
     return rest

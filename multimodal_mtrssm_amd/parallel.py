@@ -20,6 +20,35 @@ from multimodal_mtrssm_amd import conv
 from multimodal_mtrssm_amd.optim import FlatParameters
 
 
+class GlobalRowNoise:
+    """Sampling uniforms keyed by (seed, draw number, GLOBAL batch row): SURVEY.md section 8e.
+
+    Every rank holds a generator in the same state and draws the uniforms of the whole global batch
+    (``[B_global, ...]`` per key, keys in sorted order -- a few hundred KB), then keeps its own rows.  Row g
+    of the global batch therefore sees the same numbers whether the job runs on 1, 2 or 8 ranks, and B=64 on one
+    rank equals 2 x 32 on two ranks bit for bit.  ``out`` lets a caller keep the result in fixed buffers (the captured
+    train step reads them; the draw itself stays outside the capture)."""
+
+    def __init__(self, seed: int, world: int, rank: int, device: torch.device | str) -> None:
+        self.world, self.rank = int(world), int(rank)
+        self.device = torch.device(device)
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(int(seed))
+
+    def draw(self, shapes: dict[str, tuple[int, ...]], out: dict[str, Tensor] | None = None) -> dict[str, Tensor]:
+        """``shapes``: per key the shape for THIS rank's rows (first extent = local batch); equal on every rank."""
+        res: dict[str, Tensor] = {}
+        for key in sorted(shapes):
+            local = tuple(shapes[key])
+            full = torch.rand((local[0] * self.world, *local[1:]), generator=self.gen, device=self.device, dtype=torch.float32)
+            mine = full[self.rank * local[0] : (self.rank + 1) * local[0]]
+            if out is not None:
+                out[key].copy_(mine)
+                mine = out[key]
+            res[key] = mine
+        return res
+
+
 class FlatDataParallel:
     def __init__(self, flat: FlatParameters, process_group: dist.ProcessGroup | None = None) -> None:
         self.flat = flat
@@ -42,6 +71,10 @@ class FlatDataParallel:
             raise ValueError(msg)
         per = b // self.world
         return tuple(x[self.rank * per : (self.rank + 1) * per] for x in batch)
+
+    def noise_source(self, seed: int, device: torch.device | str | None = None) -> GlobalRowNoise:
+        """A ``GlobalRowNoise`` for this rank: pass ``source.draw(model.noise_shapes(B_local, T))`` as ``shared_step``'s ``noise``."""
+        return GlobalRowNoise(seed, self.world, self.rank, self.flat.param.device if device is None else device)
 
     @property
     def grad_scale(self) -> float:

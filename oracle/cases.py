@@ -159,6 +159,18 @@ CASES: dict[str, Case] = {
         "mmtrssm_large", "mmtrssm",
         _mmtrssm_dims(512, (8, 16), 512, (8, 16), 512, 4, 512, (1, 16, 8), (1, 8, 8), **_SMALL), 3, 4, (1, 16, 8), (1, 8, 8), query=2,
     ),
+    # BASELINE configs[1] / configs[2] EXACTLY as bench.py builds them (bench.WORKLOAD): 1x128x32 audio + 1x64x64 vision
+    # frames, conv channels [8,16,32] / [32,16,1], 3 residual blocks (64 / 128 intermediate channels), deter = hidden = 200,
+    # stoch 6 x 5, action 4, embed 256, T = 50.  Two sequences: the oracle finishes fwd + bwd in seconds.  No fixture
+    # (4 M weights): GPU-vs-oracle only; the tests screen the noise seed for a sampling margin as gen_golden.py does.
+    "mrssm_bench": Case(
+        "mrssm_bench", "mrssm",
+        _mrssm_dims(200, 200, 5, 6, 4, 256, (1, 128, 32), (1, 64, 64)), 2, 50, (1, 128, 32), (1, 64, 64), query=25,
+    ),
+    "mmtrssm_bench": Case(
+        "mmtrssm_bench", "mmtrssm",
+        _mmtrssm_dims(200, (5, 6), 200, (5, 6), 200, 4, 256, (1, 128, 32), (1, 64, 64)), 2, 50, (1, 128, 32), (1, 64, 64), query=25,
+    ),
 }
 
 GOLDEN_CASES = ("mrssm_default", "mrssm_nonsquare", "mrssm_cfg2dims", "mmtrssm_default", "mmtrssm_cfg3dims")
@@ -232,6 +244,26 @@ def min_margin(case: Case, out: dict[str, Tensor], noise: dict[str, Tensor]) -> 
         _, probs = cat_probs(logits.detach(), cats, classes)
         worst = min(worst, float(sampling_margin(probs, u).min()))
     return worst
+
+
+def screened_noise(case: Case, model: torch.nn.Module, batch: tuple[Tensor, ...], *, margin: float = 1e-4, first_seed: int = 100,
+                   tries: int = 40) -> tuple[dict[str, Tensor], float, int]:
+    """The first noise seed whose every draw keeps ``margin`` from the CDF edges under ``model`` (oracle forward passes
+    only).  Discrete samples fork the trajectory, so a comparison against a second implementation is meaningful only when
+    no draw sits within that implementation's rounding distance (~1e-6) of an edge.  Returns (noise, margin, seed)."""
+    best: tuple[dict[str, Tensor], float, int] | None = None
+    b, t = batch[0].shape[:2]
+    for seed in range(first_seed, first_seed + tries):
+        noise = build_noise(case, seed, batch=b, steps=t)
+        with torch.no_grad():
+            out = model.shared_step(batch, noise)
+        m = min_margin(case, out, noise)
+        if best is None or m > best[1]:
+            best = (noise, m, seed)
+        if m >= margin:
+            break
+    assert best is not None
+    return best
 
 
 def with_sizes(case: Case, batch: int, steps: int) -> Case:

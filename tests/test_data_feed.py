@@ -141,6 +141,38 @@ def test_datamodule_host_logic_on_cpu(tmp_path: Path) -> None:
         ds.load_tensor(tmp_path / "x.txt")
 
 
+def test_data_parallel_loader_shards_are_disjoint_and_equal() -> None:
+    """ADVICE r1 (dataset.py:168): with shuffle=True every rank must cut the SAME epoch permutation, run the same number
+    of steps and hold equally many rows per step, also when n is not a multiple of batch_size * world (n=10, bs=4, world=4:
+    an unequal tail would leave a rank without rows and deadlock the per-step all-reduce)."""
+    for n, bs, world in ((10, 4, 4), (13, 6, 2), (7, 8, 3), (12, 4, 2)):
+        ident = tr.Compose([])
+        streams = tuple(ds._Stream(torch.arange(n, dtype=torch.float32).reshape(n, 1, 1).expand(n, 3, w).contiguous(), ident, ident)  # noqa: SLF001
+                        for w in (4, 2, 2))
+        loaders = [ds.DeviceEpisodeLoader(streams, bs, shuffle=True, rank=r, world=world, seed=11) for r in range(world)]
+        for epoch in range(2):
+            per_rank = [list(ld.index_batches()) for ld in loaders]
+            steps = {len(b) for b in per_rank}
+            assert steps == {(n + bs - 1) // bs}, (n, bs, world, steps)
+            seen: list[int] = []
+            for step in range(len(per_rank[0])):
+                sizes = {int(b[step].numel()) for b in per_rank}
+                assert len(sizes) == 1 and sizes.pop() > 0  # equal, non-empty shards: the all-reduce average is unbiased
+                rows = torch.cat([b[step] for b in per_rank]).tolist()
+                seen += rows
+            # every episode is visited; duplicates only from the wrap-around padding of a ragged batch
+            assert set(seen) == set(range(n))
+            pad = sum((-min(bs, n - lo)) % world for lo in range(0, n, bs))
+            assert len(seen) == n + pad
+        # the next epoch is another permutation, again identical across ranks
+        a = torch.cat(list(loaders[0].index_batches()))
+        loaders[0].set_epoch(0)
+        b = torch.cat(list(loaders[0].index_batches()))
+        assert not torch.equal(a, b) or n <= 2
+    one = ds.DeviceEpisodeLoader(streams, 5, shuffle=False)
+    assert [int(b.numel()) for b in one.index_batches()] == [5, 5, 2]  # single rank keeps the short tail (reference DataLoader)
+
+
 # ---------------------------------------------------------------------------------------------
 # MI355X: the fused gather kernel
 # ---------------------------------------------------------------------------------------------

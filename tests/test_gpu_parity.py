@@ -15,7 +15,8 @@ import numpy as np
 import pytest
 import torch
 
-from oracle.cases import CASES, GOLDEN_CASES, build_batch, build_model, build_noise, with_sizes
+from oracle.cases import CASES, GOLDEN_CASES, build_batch, build_model, build_noise, screened_noise, with_sizes
+from oracle.ref_model import cat_probs
 from tests.conftest import check_weight_sums, golden_batch, golden_noise, load_golden, product_from_case
 
 pytestmark = pytest.mark.gpu
@@ -284,6 +285,88 @@ def test_full_size_properties(name: str, lib_loaded: None) -> None:
 
 
 # ---------------------------------------------------------------------------------------------
+# the EXACT model bench.py times (BASELINE configs[1] / configs[2] at their stated frame sizes, T = 50)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["mrssm_bench", "mmtrssm_bench"])
+def test_bench_model_matches_oracle(name: str, lib_loaded: None) -> None:
+    """bench.py's model (1x128x32 + 1x64x64 frames, channels [8,16,32], 3 residual blocks, deter 200, stoch 6x5, T = 50) on
+    two sequences against the oracle: losses <= 1e-4 relative (north_star), posterior / prior probabilities <= 1e-5, every
+    one-hot sample exact, EVERY gradient <= 2e-4 of its tensor's largest entry.  The noise seed is screened so that no draw
+    sits within 1e-4 of a CDF edge (two fp32 implementations differ by ~1e-6 there)."""
+    torch.set_num_threads(8)
+    case = CASES[name]
+    oracle = build_model(case)
+    batch = build_batch(case)
+    noise, margin, _seed = screened_noise(case, oracle, batch)
+    assert margin >= 1e-4, margin
+    ref = oracle.shared_step(batch, noise)
+    ref["loss"].backward()
+    model = product_from_case(case, oracle, DEV)
+    gbatch, gnoise = tuple(b.to(DEV) for b in batch), _to(noise, DEV)
+    out = model.shared_step(gbatch, gnoise)
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    assert set(out) == {k for k in ref if not k.startswith("_")}
+    for k in out:
+        np.testing.assert_allclose(float(out[k]), float(ref[k]), rtol=1e-4, err_msg=k)
+    want = {k: p.grad for k, p in oracle.named_parameters() if p.grad is not None}
+    got = dict(model.named_parameters())
+    assert len(want) > 90
+    for k, g in want.items():
+        scale = float(g.abs().max()) + 1e-12
+        np.testing.assert_allclose(_np(got[k].grad), g.numpy(), rtol=2e-4, atol=2e-4 * scale, err_msg=f"grad {k}")
+    d = case.dims
+    with torch.no_grad():
+        state0 = model.initial_state((gbatch[1][:, 0], gbatch[2][:, 0]), gnoise)
+        post, prior = model.rollout_representation(actions=gbatch[0], observations=(gbatch[1], gbatch[2]), prev_state=state0, noise=gnoise)
+    if case.kind == "mrssm":
+        pairs = [(post.distribution.probs, ref["_post_logits"], post.stoch, ref["_post_stoch"], d.cats, d.classes),
+                 (prior.distribution.probs, ref["_prior_logits"], prior.stoch, ref["_prior_stoch"], d.cats, d.classes)]
+        np.testing.assert_allclose(_np(post.deter), ref["_deter"].detach().numpy(), atol=1e-5)
+    else:
+        pairs = [(post.distribution_l.probs, ref["_post_logits_l"], post.stoch_l, ref["_post_stoch_l"], d.ls_cats, d.ls_classes),
+                 (post.distribution_h.probs, ref["_post_logits_h"], post.stoch_h, ref["_post_stoch_h"], d.hs_cats, d.hs_classes),
+                 (prior.distribution_l.probs, ref["_prior_logits_l"], prior.stoch_l, ref["_prior_stoch_l"], d.ls_cats, d.ls_classes),
+                 (prior.distribution_h.probs, ref["_prior_logits_h"], prior.stoch_h, ref["_prior_stoch_h"], d.hs_cats, d.hs_classes)]
+        np.testing.assert_allclose(_np(post.deter_l), ref["_deter_l"].detach().numpy(), atol=1e-5)
+        np.testing.assert_allclose(_np(post.deter_h), ref["_deter_h"].detach().numpy(), atol=1e-5)
+    for probs, ref_logits, stoch, ref_stoch, cats, classes in pairs:
+        _, want_p = cat_probs(ref_logits.detach(), cats, classes)
+        np.testing.assert_allclose(_np(probs), want_p.numpy(), atol=1e-5)
+        assert (_index(stoch, cats, classes) == _index(ref_stoch.detach(), cats, classes)).all()
+
+
+@pytest.mark.parametrize("name", ["mrssm_bench", "mmtrssm_bench"])
+def test_bench_model_full_batch_properties(name: str, lib_loaded: None) -> None:
+    """The same model at the bench's batch (B = 64, T = 50, real frame sizes): a 12-row sub-batch reproduces its rows of the
+    full batch bit for bit (forward AND the loss terms' per-row inputs), a prefix of the sequence is the shorter rollout, and
+    the train step's loss equals the mean over two 32-row halves run with the global rows' noise -- what data-parallel
+    sharding relies on."""
+    case = with_sizes(CASES[name], 64, 50)
+    model = product_from_case(case, build_model(case), DEV)
+    batch = tuple(b.to(DEV) for b in build_batch(case))
+    noise = _to(build_noise(case), DEV)
+    with torch.no_grad():
+        state0 = model.initial_state((batch[1][:, 0], batch[2][:, 0]), noise)
+        post, _ = model.rollout_representation(actions=batch[0], observations=(batch[1], batch[2]), prev_state=state0, noise=noise)
+        rows = slice(21, 33)
+        sub_noise = {k: v[rows] for k, v in noise.items()}
+        post_sub, _ = model.rollout_representation(actions=batch[0][rows], observations=(batch[1][rows], batch[2][rows]),
+                                                   prev_state=state0[rows], noise=sub_noise)
+        half_noise = {k: (v[:, :20] if v.dim() == 3 else v) for k, v in noise.items()}
+        post_half, _ = model.rollout_representation(actions=batch[0][:, :20], observations=(batch[1][:, :20], batch[2][:, :20]),
+                                                    prev_state=state0, noise=half_noise)
+        a, b, c = (("deter", "stoch", "deter") if case.kind == "mrssm" else ("deter_l", "stoch_h", "deter_h"))
+        assert torch.equal(getattr(post_sub, a), getattr(post, a)[rows])
+        assert torch.equal(getattr(post_sub, b), getattr(post, b)[rows])
+        assert torch.equal(getattr(post_half, c), getattr(post, c)[:, :20])
+        full = model.shared_step(batch, noise)
+        halves = [model.shared_step(tuple(x[h] for x in batch), {k: v[h] for k, v in noise.items()}) for h in (slice(0, 32), slice(32, 64))]
+    for k in full:
+        np.testing.assert_allclose(float(full[k]), 0.5 * (float(halves[0][k]) + float(halves[1][k])), rtol=2e-6, err_msg=k)
+
+
+# ---------------------------------------------------------------------------------------------
 # conv kernels (MFMA implicit GEMM) vs torch CPU convolutions
 # ---------------------------------------------------------------------------------------------
 CONV_CASES = [
@@ -471,34 +554,6 @@ def test_paired_stacks_of_different_shape_fall_back(lib_loaded: None) -> None:
     np.testing.assert_allclose(_np(pb), _np(rb), rtol=1e-6, atol=1e-6)
 
 
-def test_two_stream_branches_change_nothing(lib_loaded: None) -> None:
-    """core.fork_join (audio / vision encoders and decoders on two HIP streams, opt-in) against the same step on one
-    stream: the same losses and gradients up to the arrival order of fp32 atomics (NLL reduction, weight-gradient kernels)."""
-    from multimodal_mtrssm_amd import core
-
-    case = CASES["mrssm_default"]
-    fx = load_golden("mrssm_default")
-    batch, noise = tuple(b.to(DEV) for b in golden_batch(fx)), _to(golden_noise(fx), DEV)
-    runs = {}
-    for two in (False, True):
-        core.BRANCH_STREAMS = two
-        try:
-            model = product_from_case(case, build_model(case), DEV)
-            for _ in range(4):  # more calls than core.MAX_INFLIGHT_STEPS: the run-ahead bound is exercised too
-                model.zero_grad(set_to_none=True)
-                out = model.shared_step(batch, noise)
-                out["loss"].backward()
-            torch.cuda.synchronize()
-            runs[two] = ({k: float(v) for k, v in out.items()}, {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
-        finally:
-            core.BRANCH_STREAMS = False
-    for k, v in runs[False][0].items():  # the NLL reduction uses fp32 atomics: equal up to their arrival order
-        np.testing.assert_allclose(runs[True][0][k], v, rtol=2e-6, err_msg=k)
-    for k, g in runs[False][1].items():
-        scale = float(g.abs().max()) + 1e-12
-        np.testing.assert_allclose(_np(runs[True][1][k]), _np(g), rtol=1e-5, atol=2e-6 * scale, err_msg=k)
-
-
 def test_paired_launches_change_nothing(lib_loaded: None) -> None:
     """conv.paired (the audio and the vision stack's equal layers in one launch, the default) against one launch per
     layer: the gathers are the same arithmetic per output tile, so forward values are bit-identical; gradients are equal
@@ -660,29 +715,53 @@ def test_gaussian_nll_kernel(shape: tuple[int, ...], lib_loaded: None) -> None:
         mt.likelihood(prediction=p, target=tgt.to(DEV)[1:], event_ndims=3)
 
 
+class _WithDeadLayer(torch.nn.Module):
+    def __init__(self) -> None:
+        super().__init__()
+        self.a = torch.nn.Linear(13, 7)
+        self.dead = torch.nn.Linear(5, 5)  # registered, never called: MMTRSSM's l_posterior / dummy transition
+        self.b = torch.nn.Linear(7, 3)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.b(torch.tanh(self.a(x)))
+
+
 def test_flat_adamw_matches_torch(lib_loaded: None) -> None:
+    """Fused clip + AdamW over the flat buffer against torch.optim.AdamW + clip_grad_norm_, including torch's rule that a
+    parameter whose .grad is None is skipped (no weight decay): the dead layer must stay bit-identical to its initial value
+    (mmtrssm/mopoe_mmtrssm/core.py:143-151,188), and a scheduler's lr change must reach the device-resident rate."""
     import multimodal_mtrssm_amd as mt
     from multimodal_mtrssm_amd.optim import FlatParameters
 
     torch.manual_seed(0)
-    net = torch.nn.Sequential(torch.nn.Linear(13, 7), torch.nn.Tanh(), torch.nn.Linear(7, 3)).to(DEV)
-    twin = torch.nn.Sequential(torch.nn.Linear(13, 7), torch.nn.Tanh(), torch.nn.Linear(7, 3)).to(DEV)
+    net, twin = _WithDeadLayer().to(DEV), _WithDeadLayer().to(DEV)
     twin.load_state_dict(net.state_dict())
+    dead0 = [p.detach().clone() for p in net.dead.parameters()]
     flat = FlatParameters(net)
     opt = mt.FlatAdamW(flat, lr=1e-2, clip_norm=0.5)
     ref = torch.optim.AdamW(twin.parameters(), lr=1e-2)
     x = torch.randn(32, 13, device=DEV)
-    for _ in range(5):
+    for it in range(6):
+        if it == 3:  # what ReduceLROnPlateau does
+            opt.param_groups[0]["lr"] = 5e-3
+            ref.param_groups[0]["lr"] = 5e-3
         opt.zero_grad()
         net(x).square().sum().backward()
-        flat.check_views()
         opt.step()
         ref.zero_grad()
         twin(x).square().sum().backward()
         torch.nn.utils.clip_grad_norm_(twin.parameters(), 0.5)
         ref.step()
-    for a, b in zip(net.parameters(), twin.parameters(), strict=True):
-        np.testing.assert_allclose(_np(a), _np(b), rtol=2e-5, atol=1e-6)
+    for (k, a), b in zip(net.named_parameters(), twin.parameters(), strict=True):
+        np.testing.assert_allclose(_np(a), _np(b), rtol=2e-5, atol=1e-6, err_msg=k)
+    for p, p0, q in zip(net.dead.parameters(), dead0, twin.dead.parameters(), strict=True):
+        assert torch.equal(p, p0) and torch.equal(q, p0)  # neither optimizer decays a parameter that never had a gradient
+    assert float(opt.state[1]) == 6.0 and abs(float(opt.state[0]) - 5e-3) < 1e-9
+    # a stock zero_grad() (set_to_none=True) breaks the view contract: the next step must refuse, not step on zeros
+    net.zero_grad()
+    net(x).square().sum().backward()
+    with pytest.raises(RuntimeError, match="no longer aliases"):
+        opt.step()
 
 
 def test_cpu_tensors_are_refused(lib_loaded: None) -> None:

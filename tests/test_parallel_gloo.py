@@ -89,6 +89,37 @@ def test_two_rank_flat_allreduce_matches_single_process(tmp_path: Path) -> None:
     assert float(dead.abs().max()) == 0.0  # never-touched parameters contribute zeros
 
 
+def test_bench_launcher_runs_two_ranks_and_noise_is_rank_count_invariant(tmp_path: Path) -> None:
+    """`bench.py --gpus N` starts its own workers.  The launcher code (`bench.launch_workers`: a child
+    `torch.distributed.run` job on 127.0.0.1) drives a CPU worker (tests/dp_worker.py, gloo) through two sharded train steps;
+    the same worker run in-process on ONE rank with the full batch must see, row for row, the same uniforms
+    (`GlobalRowNoise`: keyed by global batch row) and end with the same parameters."""
+    sys.path.insert(0, str(ROOT))
+    import bench
+    from tests import dp_worker
+
+    rc = bench.launch_workers(2, script=ROOT / "tests" / "dp_worker.py", argv=[str(tmp_path), "8"])
+    assert rc == 0
+    r0 = torch.load(tmp_path / "rank0of2.pt", weights_only=True)
+    r1 = torch.load(tmp_path / "rank1of2.pt", weights_only=True)
+    env = {k: os.environ.pop(k, None) for k in ("WORLD_SIZE", "RANK")}
+    try:
+        dp_worker.run(str(tmp_path), 8)
+    finally:
+        os.environ.update({k: v for k, v in env.items() if v is not None})
+    one = torch.load(tmp_path / "rank0of1.pt", weights_only=True)
+    for step in range(2):
+        for key in ("u", "v"):
+            both = torch.cat([r0["noise"][step][key], r1["noise"][step][key]])
+            assert torch.equal(both, one["noise"][step][key]), (step, key)  # bit for bit
+    assert torch.equal(r0["param"], r1["param"])
+    torch.testing.assert_close(r0["param"], one["param"], rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(r0["loss"], one["loss"], rtol=1e-6, atol=1e-7)
+    assert r0["touched"] == one["touched"] == [True, True, True, True, False, False]
+    # a failing rank fails the launcher
+    assert bench.launch_workers(2, script=ROOT / "tests" / "dp_worker.py", argv=[str(tmp_path / "missing"), "8"]) != 0
+
+
 def test_shard_rejects_uneven_batches() -> None:
     sys.path.insert(0, str(ROOT))
     from multimodal_mtrssm_amd.optim import FlatParameters

@@ -1,6 +1,5 @@
 """Host-side profile of the train step (profiling helper): cProfile over a few steps, top functions by own time."""
 import cProfile, pstats, sys, os, io
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
