@@ -241,6 +241,9 @@ def parse_args() -> argparse.Namespace:
                     help="nccl = RCCL over xGMI (the product path); gloo only to rehearse the launcher and the sharded step on a box with fewer GPUs")
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (needs --backend gloo: RCCL refuses two ranks on one GPU)")
+    ap.add_argument("--graph", choices=("on", "off"), default="off",
+                    help="on: the train step (zero_grad, forward, backward, and with one rank the optimizer) is captured once in a "
+                         "hipGraph and replayed (graph.CapturedTrainStep); off: every launch enqueued by the host each step")
     ap.add_argument("--single-stream", action="store_true", help="(default and only mode; kept for the commands quoted in profiles/round1_*)")
     ap.add_argument("--conv-mfma", choices=("bf16x2", "bf16x3", "f32", "bf16"), default="bf16x2",
                     help="conv MFMA operand format: bf16x2 = two bf16 pieces per fp32 operand, three products, fp32 accumulate (the mode "
@@ -313,7 +316,7 @@ def main() -> None:  # noqa: PLR0914, PLR0915
     noise_source = dp.noise_source(seed=7)
     shapes = model.noise_shapes(b, t)
 
-    def train_step() -> dict[str, torch.Tensor]:
+    def eager_step() -> dict[str, torch.Tensor]:
         noise = noise_source.draw(shapes)
         opt.zero_grad()
         out = model.shared_step(batch, noise)
@@ -321,6 +324,13 @@ def main() -> None:  # noqa: PLR0914, PLR0915
         scalars = dp.sync({k: out[k] for k in out})
         opt.step(grad_scale=dp.grad_scale)
         return scalars
+
+    train_step = eager_step
+    if args.graph == "on":
+        from multimodal_mtrssm_amd.graph import CapturedTrainStep
+
+        captured = CapturedTrainStep(model, flat, opt, dp, batch, noise_source)
+        train_step = captured.step
 
     def barrier() -> None:
         if use_dist:
@@ -346,9 +356,10 @@ def main() -> None:  # noqa: PLR0914, PLR0915
     kernel_ms: dict[str, dict[str, float]] = {}
     if rank == 0:
         scan.KERNEL_TIMERS.enable()
-        for _ in range(3):
-            train_step()
-        torch.cuda.synchronize()
+    for _ in range(3):  # EVERY rank takes these steps (each holds an all-reduce); only rank 0 times its launches
+        eager_step()  # never the captured graph: events cannot be recorded into a replay
+    torch.cuda.synchronize()
+    if rank == 0:
         kernel_ms = scan.KERNEL_TIMERS.summary()
         scan.KERNEL_TIMERS.disable()
     tt = torch.tensor([elapsed, median_ms], device=device, dtype=torch.float64)
@@ -412,6 +423,7 @@ def main() -> None:  # noqa: PLR0914, PLR0915
                 "hidden": w["hidden"], "embed": w["embed"], "categoricals_x_classes": f"{w['cats']}x{w['classes']}",
                 "enc_channels": [8, 16, 32], "dec_channels": [32, 16, 1], "residual_blocks": 3, "activation": "ELU",
                 "optimizer": "AdamW lr 1e-3 + clip 10 (fused HIP)", "params": flat.numel, "streams": 1,
+                "launch": "one hipGraph replay per step" if args.graph == "on" else "eager (host enqueues every launch)",
                 "backend": (args.backend if use_dist else "none"), "rccl_ranks": rccl_ranks,
                 "noise": "uniforms keyed by global batch row (parallel.GlobalRowNoise)",
                 "conv_mfma": {"bf16x3": "fp32 tensors; conv MFMA operands as 3 bf16 pieces, 6 bf16-MFMA products, fp32 accumulate (~2^-24 per product)",

@@ -418,13 +418,14 @@ int mtrssm_episode_gather(const float* store, const int64_t* idx, const float* n
  * Gaussian NLL with unit scale, fused reduction.  Replaces objective.likelihood
  * (objective.py:7-23) as used by compute_reconstruction_loss (mrssm/mopoe_mrssm/core.py:279-308):
  *   nll = mean_n sum_e [ 0.5 (target - pred)^2 + 0.5 log(2 pi) ],  n = B*T frames, e = C*H*W.
- * fwd writes partial sums to `partials` (caller-zeroed, >= 1024 floats) and the scalar to `out`;
- * bwd writes d pred = g_out * (pred - target) / n.
+ * `act` (MTRSSM_ACT_IDENTITY or MTRSSM_ACT_TANH) is the decoder's out_activation (default.yaml: Tanh), applied to `pred`
+ * while it is read: pred then holds the decoder's RAW last-layer output and the activated reconstruction is never written.
+ * fwd zeroes `out` and accumulates the scalar there; bwd writes d pred = g_out * (act(pred) - target) * act'(pred) / n.
  * ------------------------------------------------------------------------------------------ */
-int mtrssm_gaussian_nll_fwd(const float* pred, const float* target, int64_t frames, int64_t event,
+int mtrssm_gaussian_nll_fwd(const float* pred, const float* target, int64_t frames, int64_t event, int32_t act,
                             float* out, void* stream);
 int mtrssm_gaussian_nll_bwd(const float* pred, const float* target, const float* g_out,
-                            int64_t frames, int64_t event, float* g_pred, void* stream);
+                            int64_t frames, int64_t event, int32_t act, float* g_pred, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused AdamW over one flat fp32 parameter buffer, with global-norm gradient clipping
@@ -446,6 +447,30 @@ int mtrssm_adamw_prepare(const float* grad, int64_t n, float* sumsq, float* stat
 int mtrssm_adamw_apply(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const uint8_t* active, int64_t n,
                        const float* sumsq, const float* state, float clip_norm, float grad_scale, float beta1, float beta2,
                        float eps, float weight_decay, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense fp32 GEMM on the fp32 MFMA with the elementwise neighbours fused in.  Replaces the nn.Linear / MLP calls around
+ * the recurrence and their autograd (torchrl MLP at networks.py:57-64,130-145; cnn's Linear layers; init_proj,
+ * core.py:132-133) and the weight gradients of the scan:
+ *   C[i][j] (+)= act_out( bias[j] + sum_r actA(A'(i, r)) * actB(B'(j, r)) ) * act_z'(zgrad[i][j])
+ *   A'(i, r) = a_rmajor ? A[r * lda + i] : A[i * lda + r];   B'(j, r) = b_rmajor ? B[r * ldb + j] : B[j * ldb + r]
+ *   forward Y = act(X) W^T + b: A = X, B = W;  data gradient dX = (dY W) * act'(X): A = dY, B = W with b_rmajor;
+ *   weight gradient dW += dY^T act(X), db += column sums of dY: A = dY, B = X, both r-major, accumulate, colsum = db.
+ * bias, zgrad, colsum may be NULL.  split_r: 0 = choose (splits only when accumulate is set and no output epilogue), else
+ * the number of reduction slices (> 1 accumulates with fp32 atomics and needs accumulate = 1).  Numerics: each output
+ * element is a k-ordered fp32 fma chain (v_mfma_f32_32x32x2_f32).  Rows may be strided views (lda / ldb / ldc / ldz).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct MtrssmGemm {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;
+  const float* zgrad;
+  float* colsum;
+  int32_t M, N, R, lda, ldb, ldc, ldz;
+  int32_t a_rmajor, b_rmajor, act_a, act_b, act_out, act_z, accumulate, split_r;
+} MtrssmGemm;
+int mtrssm_gemm(const MtrssmGemm* g, void* stream);
 
 #ifdef __cplusplus
 }

@@ -76,6 +76,9 @@ ConvGeom = _struct("MtrssmConvGeom", [(n, _i) for n in (
     "N", "C", "Hs", "Ws", "C2", "Cpad", "KH", "KW", "SS", "TS", "OFFY", "OFFX", "Hq", "Wq", "OS", "QY", "QX", "Ho", "Wo",
     "Cout", "CoutPad", "pre_act", "act", "mfma_split")])
 
+Gemm = _struct("MtrssmGemm", _ptrs("A", "B", "C", "bias", "zgrad", "colsum") + [(n, _i) for n in (
+    "M", "N", "R", "lda", "ldb", "ldc", "ldz", "a_rmajor", "b_rmajor", "act_a", "act_b", "act_out", "act_z", "accumulate", "split_r")])
+
 # every symbol include/mtrssm.h declares (tests/test_capi.py checks the header against this list)
 SYMBOLS: dict[str, tuple[type | None, list[type]]] = {
     "mtrssm_version": (C.c_int, []),
@@ -95,10 +98,11 @@ SYMBOLS: dict[str, tuple[type | None, list[type]]] = {
     "mtrssm_channel_sum": (C.c_int, [_p, _i, _i, _i, _p, _p]),
     "mtrssm_convt_k4s2_thin": (C.c_int, [_i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _p, _p]),
     "mtrssm_episode_gather": (C.c_int, [_p, _p, _p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _f, _p, _p, _p]),
-    "mtrssm_gaussian_nll_fwd": (C.c_int, [_p, _p, C.c_int64, C.c_int64, _p, _p]),
-    "mtrssm_gaussian_nll_bwd": (C.c_int, [_p, _p, _p, C.c_int64, C.c_int64, _p, _p]),
+    "mtrssm_gaussian_nll_fwd": (C.c_int, [_p, _p, C.c_int64, C.c_int64, _i, _p, _p]),
+    "mtrssm_gaussian_nll_bwd": (C.c_int, [_p, _p, _p, C.c_int64, C.c_int64, _i, _p, _p]),
     "mtrssm_sumsq": (C.c_int, [_p, C.c_int64, _p, _p]),
     "mtrssm_adamw_step": (C.c_int, [_p, _p, _p, _p, C.c_int64, _p, _f, _f, _f, _f, _f, _f, _f, _i, _p]),
+    "mtrssm_gemm": (C.c_int, [C.POINTER(Gemm), _p]),
     "mtrssm_adamw_prepare": (C.c_int, [_p, C.c_int64, _p, _p, _f, _f, _p]),
     "mtrssm_adamw_apply": (C.c_int, [_p, _p, _p, _p, _p, C.c_int64, _p, _p, _f, _f, _f, _f, _f, _f, _p]),
 }

@@ -30,6 +30,7 @@ import torch
 from torch import Tensor, nn
 
 from multimodal_mtrssm_amd import _lib
+from multimodal_mtrssm_amd.linear import linear
 from multimodal_mtrssm_amd.conv import (
     conv2d,
     conv2d_pair,
@@ -118,13 +119,14 @@ def encode_pair(enc_a: "Encoder", enc_b: "Encoder", xa: Tensor, xb: Tensor) -> t
     return enc_a.head(xa, lead_a), enc_b.head(xb, lead_b)
 
 
-def decode_pair(dec_a: "Decoder", dec_b: "Decoder", fa: Tensor, fb: Tensor) -> tuple[Tensor, Tensor]:
-    """``(dec_a(fa), dec_b(fb))`` with the layers of the two stacks that have the same shape sharing their launches."""
+def decode_pair(dec_a: "Decoder", dec_b: "Decoder", fa: Tensor, fb: Tensor, *, raw: bool = False) -> tuple[Tensor, Tensor]:
+    """``(dec_a(fa), dec_b(fb))`` with the layers of the two stacks that have the same shape sharing their launches.
+    ``raw``: without the final ``out_activation`` (the fused Gaussian NLL applies it while it reads the prediction)."""
     lead_a, lead_b = fa.shape[:-1], fb.shape[:-1]
     xa, xb = dec_a.stem(fa), dec_b.stem(fb)
     xa, xb = _res_pair(dec_a.res, dec_b.res, xa, xb)
     if len(dec_a.deconvs) != len(dec_b.deconvs) or (len(dec_a.res) > 0) != (len(dec_b.res) > 0):
-        return dec_a.tail(xa, lead_a), dec_b.tail(xb, lead_b)
+        return dec_a.tail(xa, lead_a, raw=raw), dec_b.tail(xb, lead_b, raw=raw)
     for i, (ma, mb) in enumerate(zip(dec_a.deconvs, dec_b.deconvs, strict=True)):
         pre = i > 0 or len(dec_a.res) > 0
         if _same_layer(ma, mb) and dec_a.act_id == dec_b.act_id:
@@ -133,7 +135,7 @@ def decode_pair(dec_a: "Decoder", dec_b: "Decoder", fa: Tensor, fb: Tensor) -> t
                 (xb, mb.weight, mb.bias, mb.stride[0], mb.padding[0], mb.output_padding[0], pre, dec_b.act_id))
         else:
             xa, xb = _deconv(xa, ma, pre_act=pre, act=dec_a.act_id), _deconv(xb, mb, pre_act=pre, act=dec_b.act_id)
-    return dec_a.finish(xa, lead_a), dec_b.finish(xb, lead_b)
+    return dec_a.finish(xa, lead_a, raw=raw), dec_b.finish(xb, lead_b, raw=raw)
 
 
 class Encoder(nn.Module):
@@ -210,11 +212,10 @@ class Encoder(nn.Module):
         return self.stem_convs(*self.prepare(x))
 
     def head(self, x: Tensor, lead: torch.Size) -> Tensor:
-        x = self.act(x).flatten(start_dim=1)
-        for i, lin in enumerate(self.linears):
-            x = lin(x)
-            if i + 1 < len(self.linears):
-                x = self.act(x)
+        # "act -> flatten -> Linear [-> act -> Linear ...]": every activation rides in the following GEMM's operand staging
+        x = x.flatten(start_dim=1)
+        for lin in self.linears:
+            x = linear(x, lin.weight, lin.bias, pre_act=self.act_id)
         return self.out_act(x).reshape(*lead, -1)
 
 
@@ -249,12 +250,18 @@ class Decoder(nn.Module):
             width = out
         self.in_features = in_features
 
-    def forward(self, f: Tensor) -> Tensor:
+    def forward(self, f: Tensor, *, raw: bool = False) -> Tensor:
         lead = f.shape[:-1]
         x = self.stem(f)
         for blk in self.res:
             x = blk(x)
-        return self.tail(x, lead)
+        return self.tail(x, lead, raw=raw)
+
+    @property
+    def out_act_id(self) -> int | None:
+        """Activation id of ``out_activation`` if the fused NLL kernel can apply it (Identity / Tanh), else None."""
+        name = type(self.out_act).__name__
+        return {"Identity": 0, "Tanh": 3}.get(name)
 
     def stem(self, f: Tensor) -> Tensor:
         if len(self.linears) == 0:
@@ -262,17 +269,16 @@ class Decoder(nn.Module):
             self.to(f.device)
         x = f.reshape(-1, f.shape[-1])
         for i, lin in enumerate(self.linears):
-            x = lin(x)
-            if i + 1 < len(self.linears):
-                x = self.act(x)
+            x = linear(x, lin.weight, lin.bias, pre_act=self.act_id if i > 0 else 0)
         return x.reshape(-1, *self.conv_in_shape)
 
-    def tail(self, x: Tensor, lead: torch.Size) -> Tensor:
+    def tail(self, x: Tensor, lead: torch.Size, *, raw: bool = False) -> Tensor:
         for i, dc in enumerate(self.deconvs):
             # "act -> deconv" everywhere except a first deconv fed straight by the Linear (no residual stack)
             x = _deconv(x, dc, pre_act=i > 0 or len(self.res) > 0, act=self.act_id)
-        return self.finish(x, lead)
+        return self.finish(x, lead, raw=raw)
 
-    def finish(self, x: Tensor, lead: torch.Size) -> Tensor:
-        x = self.out_act(x)
+    def finish(self, x: Tensor, lead: torch.Size, *, raw: bool = False) -> Tensor:
+        if not raw:
+            x = self.out_act(x)
         return x.reshape(*lead, *x.shape[-3:])

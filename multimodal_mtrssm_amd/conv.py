@@ -73,6 +73,7 @@ class _PackPlan:
         self.serial = 0
         self.table: Tensor | None = None
         self.table_serials: tuple = ()
+        self.pinned = False  # a captured graph reads the packed buffers: entries are never dropped then
 
     def invalidate(self) -> None:
         self.epoch += 1
@@ -85,7 +86,8 @@ class _PackPlan:
         self.epoch += 1
         self.step_epoch = self.epoch
         # keep what the last step used (weights of modules that went away leave with their strong reference)
-        self.entries = {k: e for k, e in self.entries.items() if e[5] >= self.epoch - 2}
+        if not self.pinned:
+            self.entries = {k: e for k, e in self.entries.items() if e[5] >= self.epoch - 2}
         self.stream = torch.cuda.current_stream(device).cuda_stream
         live = [(k, e) for k, e in self.entries.items() if k[4] == device and k[3] == _MFMA_SPLIT]
         if not live:
@@ -322,6 +324,16 @@ def _zeros(n: int, device: torch.device) -> Tensor:
     out = st[0][st[1] : st[1] + n]
     st[1] += need
     return out
+
+
+def reset_scratch(*, pin: bool = False) -> None:
+    """Forget the partly used zeroed chunks (the next weight gradient opens a fresh one).  ``graph.CapturedTrainStep`` calls
+    this right before and right after a capture: a chunk zeroed BEFORE the capture would come back dirty on the second
+    replay, and one allocated inside the capture belongs to the graph's private pool.  ``pin`` keeps every packed-weight
+    buffer of the step plan alive for good (the captured kernels read those addresses)."""
+    _ZERO_CHUNKS.clear()
+    if pin:
+        _PLAN.pinned = True
 
 
 def _weight_grad(a: Tensor, src: Tensor, coords: Tensor | None, kh: int, kw: int, stride: int, pad: int, pre_act_a: bool,

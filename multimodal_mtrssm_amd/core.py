@@ -132,14 +132,18 @@ class MoPoE_MRSSM(_Base):  # noqa: N801
         return self.audio_encoder(audio_obs), self.vision_encoder(vision_obs)
 
     def _reconstruction_losses(self, feature: Tensor, targets: dict[str, Tensor]) -> dict[str, Tensor]:
-        """``decode_state`` + ``compute_reconstruction_loss`` (``mrssm core.py:262-308``)."""
-        if _pairable(self.audio_decoder, self.vision_decoder, cnn.Decoder):
-            pa, pv = cnn.decode_pair(self.audio_decoder, self.vision_decoder, feature, feature)
-            audio = likelihood(prediction=pa, target=targets["recon/audio"], event_ndims=3)
-            vision = likelihood(prediction=pv, target=targets["recon/vision"], event_ndims=3)
-            return {"recon": audio + vision, "recon/audio": audio, "recon/vision": vision}
-        audio = likelihood(prediction=self.audio_decoder(feature), target=targets["recon/audio"], event_ndims=3)
-        vision = likelihood(prediction=self.vision_decoder(feature), target=targets["recon/vision"], event_ndims=3)
+        """``decode_state`` + ``compute_reconstruction_loss`` (``mrssm core.py:262-308``).  With this package's decoders the
+        out_activation (Tanh) is applied inside the NLL kernels: the activated reconstructions are never written in training."""
+        da, dv = self.audio_decoder, self.vision_decoder
+        fused = isinstance(da, cnn.Decoder) and isinstance(dv, cnn.Decoder) and da.out_act_id is not None and dv.out_act_id is not None
+        if fused and _pairable(da, dv, cnn.Decoder):
+            pa, pv = cnn.decode_pair(da, dv, feature, feature, raw=True)
+        elif fused:
+            pa, pv = da(feature, raw=True), dv(feature, raw=True)
+        else:
+            pa, pv = da(feature), dv(feature)
+        audio = likelihood(prediction=pa, target=targets["recon/audio"], event_ndims=3, out_act=da.out_act_id if fused else 0)
+        vision = likelihood(prediction=pv, target=targets["recon/vision"], event_ndims=3, out_act=dv.out_act_id if fused else 0)
         return {"recon": audio + vision, "recon/audio": audio, "recon/vision": vision}
 
     # -- states ---------------------------------------------------------------------------------

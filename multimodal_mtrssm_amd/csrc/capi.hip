@@ -32,10 +32,11 @@ int conv_gather_pair_merges(const MtrssmConvGeom*, const MtrssmConvGeom*, bool);
 int conv_weight_grad_launch(const MtrssmConvGeom*, const float*, const float*, const float*, int, float*, float*, hipStream_t);
 int channel_sum_launch(const float*, int, int, int, float*, hipStream_t);
 int convt_k4s2_thin_launch(int, int, int, int, int, const float*, const float*, const float*, int, int, float*, hipStream_t);
-int nll_fwd_launch(const float*, const float*, int64_t, int64_t, float*, hipStream_t);
-int nll_bwd_launch(const float*, const float*, const float*, int64_t, int64_t, float*, hipStream_t);
+int nll_fwd_launch(const float*, const float*, int64_t, int64_t, int, float*, hipStream_t);
+int nll_bwd_launch(const float*, const float*, const float*, int64_t, int64_t, int, float*, hipStream_t);
 int sumsq_launch(const float*, int64_t, float*, hipStream_t);
 int adamw_launch(float*, const float*, float*, float*, int64_t, const float*, float, float, float, float, float, float, float, int, hipStream_t);
+int gemm_launch(const MtrssmGemm*, hipStream_t);
 int adamw_prepare_launch(const float*, int64_t, float*, float*, float, float, hipStream_t);
 int adamw_apply_launch(float*, const float*, float*, float*, const unsigned char*, int64_t, const float*, const float*, float, float, float, float,
                        float, float, hipStream_t);
@@ -61,11 +62,12 @@ MTRSSM_API int mtrssm_mmtrssm_rollout_fwd(const MtrssmMmtrssmDims* d, const Mtrs
 MTRSSM_API int mtrssm_mmtrssm_rollout_bwd(const MtrssmMmtrssmDims* d, const MtrssmMmtrssmBwdWeights* w, const MtrssmMmtrssmBwdIO* io, void* stream) {
   return mmtrssm_bwd_launch(d, w, io, static_cast<hipStream_t>(stream));
 }
-MTRSSM_API int mtrssm_gaussian_nll_fwd(const float* pred, const float* target, int64_t frames, int64_t event, float* out, void* stream) {
-  return nll_fwd_launch(pred, target, frames, event, out, static_cast<hipStream_t>(stream));
+MTRSSM_API int mtrssm_gaussian_nll_fwd(const float* pred, const float* target, int64_t frames, int64_t event, int32_t act, float* out, void* stream) {
+  return nll_fwd_launch(pred, target, frames, event, act, out, static_cast<hipStream_t>(stream));
 }
-MTRSSM_API int mtrssm_gaussian_nll_bwd(const float* pred, const float* target, const float* g_out, int64_t frames, int64_t event, float* g_pred, void* stream) {
-  return nll_bwd_launch(pred, target, g_out, frames, event, g_pred, static_cast<hipStream_t>(stream));
+MTRSSM_API int mtrssm_gaussian_nll_bwd(const float* pred, const float* target, const float* g_out, int64_t frames, int64_t event, int32_t act,
+                                       float* g_pred, void* stream) {
+  return nll_bwd_launch(pred, target, g_out, frames, event, act, g_pred, static_cast<hipStream_t>(stream));
 }
 MTRSSM_API int mtrssm_sumsq(const float* x, int64_t n, float* out, void* stream) {
   return sumsq_launch(x, n, out, static_cast<hipStream_t>(stream));
@@ -76,6 +78,7 @@ MTRSSM_API int mtrssm_adamw_step(float* param, const float* grad, float* exp_avg
   return adamw_launch(param, grad, exp_avg, exp_avg_sq, n, sumsq, clip_norm, grad_scale, lr, beta1, beta2, eps, weight_decay, step,
                       static_cast<hipStream_t>(stream));
 }
+MTRSSM_API int mtrssm_gemm(const MtrssmGemm* g, void* stream) { return gemm_launch(g, static_cast<hipStream_t>(stream)); }
 MTRSSM_API int mtrssm_adamw_prepare(const float* grad, int64_t n, float* sumsq, float* state, float beta1, float beta2, void* stream) {
   return adamw_prepare_launch(grad, n, sumsq, state, beta1, beta2, static_cast<hipStream_t>(stream));
 }

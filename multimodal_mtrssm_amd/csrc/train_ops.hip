@@ -25,6 +25,7 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 }
 
 // out += scale * sum 0.5 (t - p)^2   (+ the constant on block 0)
+template <bool TANH>
 __global__ void nll_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ target, int64_t n,
                                float scale, float constant, float* __restrict__ out) {
   __shared__ float red[kThreads / kWave];
@@ -33,13 +34,15 @@ __global__ void nll_fwd_kernel(const float* __restrict__ pred, const float* __re
   const float4* t4 = reinterpret_cast<const float4*>(target);
   float acc = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-    const float4 p = p4[i], t = t4[i];
+    float4 p = p4[i];
+    const float4 t = t4[i];
+    if (TANH) { p.x = tanhf(p.x); p.y = tanhf(p.y); p.z = tanhf(p.z); p.w = tanhf(p.w); }
     const float a = t.x - p.x, b = t.y - p.y, c = t.z - p.z, d = t.w - p.w;
     acc += 0.5f * (a * a) + 0.5f * (b * b) + 0.5f * (c * c) + 0.5f * (d * d);
   }
   if (blockIdx.x == 0) {
     for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) {
-      const float a = target[i] - pred[i];
+      const float a = target[i] - (TANH ? tanhf(pred[i]) : pred[i]);
       acc += 0.5f * a * a;
     }
   }
@@ -47,6 +50,8 @@ __global__ void nll_fwd_kernel(const float* __restrict__ pred, const float* __re
   if (threadIdx.x == 0) atomicAdd(out, tot * scale + (blockIdx.x == 0 ? constant : 0.f));
 }
 
+// d/dz of 0.5 (t - act(z))^2 = (act(z) - t) act'(z); Tanh: act' = 1 - act^2
+template <bool TANH>
 __global__ void nll_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ target,
                                const float* __restrict__ g_out, int64_t n, float inv_frames, float* __restrict__ g_pred) {
   const float g = g_out[0] * inv_frames;
@@ -55,11 +60,20 @@ __global__ void nll_bwd_kernel(const float* __restrict__ pred, const float* __re
   const float4* t4 = reinterpret_cast<const float4*>(target);
   float4* o4 = reinterpret_cast<float4*>(g_pred);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-    const float4 p = p4[i], t = t4[i];
-    o4[i] = make_float4(g * (p.x - t.x), g * (p.y - t.y), g * (p.z - t.z), g * (p.w - t.w));
+    float4 p = p4[i];
+    const float4 t = t4[i];
+    float4 d = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (TANH) {
+      p.x = tanhf(p.x); p.y = tanhf(p.y); p.z = tanhf(p.z); p.w = tanhf(p.w);
+      d = make_float4(1.f - p.x * p.x, 1.f - p.y * p.y, 1.f - p.z * p.z, 1.f - p.w * p.w);
+    }
+    o4[i] = make_float4(g * (p.x - t.x) * d.x, g * (p.y - t.y) * d.y, g * (p.z - t.z) * d.z, g * (p.w - t.w) * d.w);
   }
   if (blockIdx.x == 0)
-    for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) g_pred[i] = g * (pred[i] - target[i]);
+    for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) {
+      const float p = TANH ? tanhf(pred[i]) : pred[i];
+      g_pred[i] = g * (p - target[i]) * (TANH ? 1.f - p * p : 1.f);
+    }
 }
 
 __global__ void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
@@ -167,24 +181,32 @@ static int check_launch(const char* what) {
   return MTRSSM_OK;
 }
 
-int nll_fwd_launch(const float* pred, const float* target, int64_t frames, int64_t event, float* out, hipStream_t s) {
+int nll_fwd_launch(const float* pred, const float* target, int64_t frames, int64_t event, int act, float* out, hipStream_t s) {
   if (!pred || !target || !out || frames <= 0 || event <= 0) { set_error("gaussian_nll_fwd: bad argument"); return MTRSSM_EINVAL; }
+  if (act != MTRSSM_ACT_IDENTITY && act != MTRSSM_ACT_TANH) { set_error("gaussian_nll: the fused output activation is Identity or Tanh (got %d)", act); return MTRSSM_EINVAL; }
   if (((uintptr_t)pred | (uintptr_t)target) & 15) { set_error("gaussian_nll_fwd: pred/target must be 16-byte aligned"); return MTRSSM_EINVAL; }
   hipError_t e = hipMemsetAsync(out, 0, sizeof(float), s);
   if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return MTRSSM_ELAUNCH; }
   const int64_t n = frames * event;
   const float constant = 0.5f * 1.8378770664093453f * (float)event;  // 0.5 log(2 pi) per element
   set_last_kernel("mtrssm::nll_fwd_kernel");
-  hipLaunchKernelGGL(nll_fwd_kernel, dim3(grid_for(n / 4)), dim3(kThreads), 0, s, pred, target, n, 1.f / (float)frames, constant, out);
+  if (act == MTRSSM_ACT_TANH)
+    hipLaunchKernelGGL(nll_fwd_kernel<true>, dim3(grid_for(n / 4)), dim3(kThreads), 0, s, pred, target, n, 1.f / (float)frames, constant, out);
+  else
+    hipLaunchKernelGGL(nll_fwd_kernel<false>, dim3(grid_for(n / 4)), dim3(kThreads), 0, s, pred, target, n, 1.f / (float)frames, constant, out);
   return check_launch("gaussian_nll_fwd");
 }
 
-int nll_bwd_launch(const float* pred, const float* target, const float* g_out, int64_t frames, int64_t event, float* g_pred, hipStream_t s) {
+int nll_bwd_launch(const float* pred, const float* target, const float* g_out, int64_t frames, int64_t event, int act, float* g_pred, hipStream_t s) {
   if (!pred || !target || !g_out || !g_pred || frames <= 0 || event <= 0) { set_error("gaussian_nll_bwd: bad argument"); return MTRSSM_EINVAL; }
+  if (act != MTRSSM_ACT_IDENTITY && act != MTRSSM_ACT_TANH) { set_error("gaussian_nll: the fused output activation is Identity or Tanh (got %d)", act); return MTRSSM_EINVAL; }
   if (((uintptr_t)pred | (uintptr_t)target | (uintptr_t)g_pred) & 15) { set_error("gaussian_nll_bwd: buffers must be 16-byte aligned"); return MTRSSM_EINVAL; }
   const int64_t n = frames * event;
   set_last_kernel("mtrssm::nll_bwd_kernel");
-  hipLaunchKernelGGL(nll_bwd_kernel, dim3(grid_for(n / 4)), dim3(kThreads), 0, s, pred, target, g_out, n, 1.f / (float)frames, g_pred);
+  if (act == MTRSSM_ACT_TANH)
+    hipLaunchKernelGGL(nll_bwd_kernel<true>, dim3(grid_for(n / 4)), dim3(kThreads), 0, s, pred, target, g_out, n, 1.f / (float)frames, g_pred);
+  else
+    hipLaunchKernelGGL(nll_bwd_kernel<false>, dim3(grid_for(n / 4)), dim3(kThreads), 0, s, pred, target, g_out, n, 1.f / (float)frames, g_pred);
   return check_launch("gaussian_nll_bwd");
 }
 

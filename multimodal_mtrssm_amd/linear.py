@@ -1,0 +1,160 @@
+"""Linear layers of the rollout path on the hand-written fp32-MFMA GEMM (``mtrssm_gemm``, ``csrc/gemm.hip``).
+
+Replaces the ``nn.Linear`` / ``torchrl.modules.MLP`` calls around the recurrence (``networks.py:57-64,130-145``,
+``core.py:132-133``, the Linear layers of ``cnn.Encoder`` / ``cnn.Decoder``) and their autograd:
+
+* ``linear(x, weight, bias, pre_act)``  =  ``F.linear(act(x), weight, bias)`` -- the stacks are "Linear -> act -> Linear", so
+  the activation is applied to the operand while it is staged (never materialised) and the backward multiplies the data
+  gradient by ``act'(x)`` in the GEMM's epilogue;
+* weight gradients are ``dY^T act(X)`` accumulated by the GEMM **straight into the flat gradient buffer** when the weight is
+  a view of an ``optim.FlatParameters`` buffer (``grad_target``), the bias gradient being the column sums of the same
+  staged operand: no temporary, no AccumulateGrad add, no separate reduction.  The autograd node then returns ``None`` for
+  that input (the gradient has already been accumulated where the optimizer reads it) -- the arrangement Megatron calls
+  gradient-accumulation fusion.  Outside a ``FlatParameters`` module the gradients are returned as usual.
+
+Numerics: each output element is a k-ordered fp32 fma chain (``v_mfma_f32_32x32x2_f32``), the reference's fp32 nn.Linear.
+"""
+
+from __future__ import annotations
+
+import bisect
+import ctypes as C
+import weakref
+
+import torch
+from torch import Tensor
+
+from multimodal_mtrssm_amd import _lib
+
+# ------------------------------------------------------------------------------------------------
+# gradient sinks: flat gradient buffers registered by optim.FlatParameters
+# ------------------------------------------------------------------------------------------------
+_SINKS: list = []  # weak references to FlatParameters
+SINK_ENABLED = True
+
+
+def register_sink(flat) -> None:  # noqa: ANN001
+    _SINKS.append(weakref.ref(flat))
+
+
+def grad_target(t: Tensor) -> Tensor | None:
+    """The view of a flat gradient buffer that mirrors ``t`` (a parameter held by a ``FlatParameters``, or a strided view into
+    one), or None.  Marks the parameter as touched: the caller is about to accumulate its gradient there."""
+    if not SINK_ENABLED or not t.is_cuda or torch.is_grad_enabled():
+        return None  # (backward runs with grad mode off unless create_graph: then the usual path is taken)
+    addr = t.data_ptr()
+    for ref in _SINKS:
+        flat = ref()
+        if flat is None or flat.param.device != t.device:
+            continue
+        base = flat.param.data_ptr()
+        off = (addr - base) // 4
+        if addr < base or off >= flat.numel:
+            continue
+        i = bisect.bisect_right(flat.offsets, off) - 1
+        p = flat.params[i]
+        extent = sum((n - 1) * s for n, s in zip(t.shape, t.stride(), strict=True)) + 1 if t.numel() else 0
+        if off + extent > flat.offsets[i] + p.numel():
+            return None  # not contained in one parameter
+        flat.mark_touched(i)
+        return flat.grad_full.as_strided(t.shape, t.stride(), off)
+    return None
+
+
+# ------------------------------------------------------------------------------------------------
+# the kernel call
+# ------------------------------------------------------------------------------------------------
+def _ld(t: Tensor) -> int:
+    if t.dim() != 2 or t.stride(1) != 1 or t.dtype != torch.float32 or not t.is_cuda:  # noqa: PLR2004
+        msg = f"mtrssm_gemm operands are fp32 GPU matrices with unit column stride, got shape {tuple(t.shape)} stride {t.stride()} {t.dtype} {t.device}"
+        raise _lib.MtrssmLibraryError(msg)
+    return int(t.stride(0)) if t.shape[0] > 1 else max(int(t.stride(0)), int(t.shape[1]))
+
+
+def gemm(a: Tensor, b: Tensor, c: Tensor, *, a_rmajor: bool, b_rmajor: bool, bias: Tensor | None = None, zgrad: Tensor | None = None,  # noqa: PLR0913
+         colsum: Tensor | None = None, act_a: int = 0, act_b: int = 0, act_z: int = 0, accumulate: bool = False, split_r: int = 0) -> None:
+    """``c[i][j] (+)= (bias[j] + sum_r actA(a'(i,r)) actB(b'(j,r))) * act_z'(zgrad[i][j])`` (``include/mtrssm.h: MtrssmGemm``).
+    ``a`` is ``[M, R]`` (or ``[R, M]`` when ``a_rmajor``), ``b`` is ``[N, R]`` (or ``[R, N]`` when ``b_rmajor``), ``c`` is ``[M, N]``."""
+    m, r = (a.shape[1], a.shape[0]) if a_rmajor else (a.shape[0], a.shape[1])
+    n, r2 = (b.shape[1], b.shape[0]) if b_rmajor else (b.shape[0], b.shape[1])
+    if r != r2 or tuple(c.shape) != (m, n):
+        msg = f"gemm shapes do not agree: a' [{m}, {r}], b' [{n}, {r2}], c {tuple(c.shape)}"
+        raise ValueError(msg)
+    if bias is not None and bias.numel() != n or colsum is not None and colsum.numel() != m or zgrad is not None and tuple(zgrad.shape) != (m, n):
+        msg = "gemm: bias must have N entries, colsum M entries, zgrad the shape of c"
+        raise ValueError(msg)
+    g = _lib.Gemm()
+    g.A, g.B, g.C = _lib.raw_ptr(a), _lib.raw_ptr(b), _lib.raw_ptr(c)
+    g.bias, g.zgrad, g.colsum = _lib.raw_ptr(bias), _lib.raw_ptr(zgrad), _lib.raw_ptr(colsum)
+    g.M, g.N, g.R = m, n, r
+    g.lda, g.ldb, g.ldc = _ld(a), _ld(b), _ld(c)
+    g.ldz = _ld(zgrad) if zgrad is not None else 0
+    g.a_rmajor, g.b_rmajor = int(a_rmajor), int(b_rmajor)
+    g.act_a, g.act_b, g.act_out, g.act_z = int(act_a), int(act_b), 0, int(act_z)
+    g.accumulate, g.split_r = int(accumulate), int(split_r)
+    for t in (bias, colsum):
+        if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
+            msg = "gemm: bias / colsum must be contiguous fp32 vectors"
+            raise _lib.MtrssmLibraryError(msg)
+    lib = _lib.load()
+    _lib.check(_lib.TIMERS.call("mtrssm_gemm", lib.mtrssm_gemm, C.byref(g), _lib.stream_ptr(a.device), flops=2.0 * m * n * r,
+                                nbytes=4.0 * (m * r + n * r + m * n)), "mtrssm_gemm")
+
+
+def weight_grad(gy: Tensor, x: Tensor, weight: Tensor, bias: Tensor | None, *, act_x: int = 0, want_weight: bool = True,
+                want_bias: bool = True) -> tuple[Tensor | None, Tensor | None]:
+    """``dW = gy^T act(x)`` (``[N, K]``), ``db = column sums of gy`` for ``y = act(x) W^T + b`` with ``gy [M, N]``, ``x [M, K]``.
+    Accumulated into the flat gradient buffer when ``weight`` / ``bias`` live in one (then None is returned for that
+    tensor), else returned.  One launch for both."""
+    gw_ret = gb_ret = None
+    if want_weight:
+        gw = grad_target(weight)
+        if gw is None:
+            gw = gw_ret = torch.zeros(weight.shape, device=gy.device, dtype=torch.float32)
+    gb = None
+    if bias is not None and want_bias:
+        gb = grad_target(bias)
+        if gb is None:
+            gb = gb_ret = torch.zeros(bias.shape, device=gy.device, dtype=torch.float32)
+    if want_weight:
+        gemm(gy, x, gw, a_rmajor=True, b_rmajor=True, act_b=act_x, colsum=gb, accumulate=True)
+    elif gb is not None:
+        gb.add_(gy.sum(0))
+    return gw_ret, gb_ret
+
+
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, weight: Tensor, bias: Tensor | None, pre_act: int) -> Tensor:  # noqa: ANN001
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, x.shape[-1])
+        if x2.stride(1) != 1:
+            x2 = x2.contiguous()
+        w = weight if weight.stride(1) == 1 else weight.contiguous()
+        y = torch.empty(x2.shape[0], w.shape[0], device=x.device, dtype=torch.float32)
+        gemm(x2, w, y, a_rmajor=False, b_rmajor=False, bias=None if bias is None else bias.contiguous(), act_a=pre_act)
+        ctx.save_for_backward(x2, weight, bias if bias is not None else x2.new_zeros(0))
+        ctx.pre_act, ctx.has_bias, ctx.lead = pre_act, bias is not None, lead
+        return y.reshape(*lead, w.shape[0])
+
+    @staticmethod
+    def backward(ctx, gy: Tensor):  # noqa: ANN001, ANN205
+        x2, weight, bias = ctx.saved_tensors
+        bias = bias if ctx.has_bias else None
+        gy2 = gy.reshape(-1, gy.shape[-1])
+        if gy2.stride(1) != 1:
+            gy2 = gy2.contiguous()
+        gx = None
+        if ctx.needs_input_grad[0]:
+            w = weight if weight.stride(1) == 1 else weight.contiguous()
+            gx = torch.empty_like(x2)
+            gemm(gy2, w, gx, a_rmajor=False, b_rmajor=True, zgrad=x2 if ctx.pre_act else None, act_z=ctx.pre_act)
+            gx = gx.reshape(*ctx.lead, x2.shape[1])
+        gw, gb = weight_grad(gy2, x2, weight, bias, act_x=ctx.pre_act, want_weight=ctx.needs_input_grad[1],
+                             want_bias=ctx.has_bias and ctx.needs_input_grad[2])
+        return gx, gw, gb, None
+
+
+def linear(x: Tensor, weight: Tensor, bias: Tensor | None = None, *, pre_act: int = 0) -> Tensor:
+    """``F.linear(act(x), weight, bias)`` over any leading dims, on the fp32-MFMA GEMM; GPU tensors only (no fallback)."""
+    return _Linear.apply(x, weight, bias, int(pre_act))

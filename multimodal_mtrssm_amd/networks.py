@@ -61,6 +61,22 @@ class MLP(nn.Sequential):
         super().__init__(*layers)
         self.in_features, self.out_features, self.num_cells, self.depth = in_features, out_features, num_cells, depth
         self.activation_name = activation_name(act)
+        self.activate_last_layer = bool(activate_last_layer)
+
+    def forward(self, x: Tensor) -> Tensor:  # noqa: A003
+        """On the GPU: the fp32-MFMA GEMMs of ``linear.py`` with each activation fused into the NEXT layer's operand staging
+        (and its derivative into the data gradient's epilogue).  CPU tensors (host-side API use) take nn.Sequential's path."""
+        from multimodal_mtrssm_amd import _lib  # noqa: PLC0415
+        from multimodal_mtrssm_amd.linear import linear  # noqa: PLC0415
+
+        act = _lib.ACT_IDS.get(self.activation_name)
+        if not x.is_cuda or act is None or x.dtype != torch.float32:
+            return super().forward(x)
+        layers = [m for m in self if isinstance(m, nn.Linear)]
+        h = linear(x, layers[0].weight, layers[0].bias)
+        for lin in layers[1:]:
+            h = linear(h, lin.weight, lin.bias, pre_act=act)
+        return self[-1](h) if self.activate_last_layer else h
 
     def two_layer(self) -> tuple[nn.Linear, nn.Linear]:
         """The (first, last) Linear of a depth-1 MLP -- the only shape the scan kernels implement."""

@@ -22,7 +22,7 @@ from __future__ import annotations
 import torch
 from torch import Tensor, nn
 
-from multimodal_mtrssm_amd import _lib, conv
+from multimodal_mtrssm_amd import _lib, conv, linear
 
 
 class FlatParameters:
@@ -65,6 +65,7 @@ class FlatParameters:
                 p.grad = self.grad[off : off + p.numel()].view_as(p)
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._touch_hook(i)))
         self._grad_ptrs = [p.grad.data_ptr() for p in params]
+        linear.register_sink(self)  # kernels that own a weight gradient accumulate it straight into self.grad
 
     def _touch_hook(self, i: int):  # noqa: ANN202
         def hook(_p: Tensor) -> None:

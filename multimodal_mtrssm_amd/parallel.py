@@ -82,14 +82,25 @@ class FlatDataParallel:
         return 1.0 / self.world
 
     @torch.no_grad()
-    def sync(self, scalars: dict[str, Tensor] | None = None) -> dict[str, Tensor]:
-        """All-reduce gradients (SUM, left un-normalised) and average ``scalars`` in the same call."""
+    def stage_scalars(self, scalars: dict[str, Tensor] | None = None) -> list[str]:
+        """Copy the loss scalars into the gradient buffer's tail slots (they ride in the same all-reduce)."""
         keys = list(scalars or {})
         if len(keys) > self.flat.extra:
             msg = f"at most {self.flat.extra} scalars fit in the gradient buffer's tail"
             raise ValueError(msg)
         for i, k in enumerate(keys):
             self.flat.tail[i].copy_(scalars[k].detach().reshape(()))  # type: ignore[index]
+        return keys
+
+    @torch.no_grad()
+    def reduce(self) -> None:
+        """THE exchange of the step: one all-reduce (SUM, left un-normalised) over gradients + tail."""
         if self.active:  # also with one rank: same code path, the collective is then a no-op copy
             dist.all_reduce(self.flat.grad_full, op=dist.ReduceOp.SUM, group=self.group)
+
+    @torch.no_grad()
+    def sync(self, scalars: dict[str, Tensor] | None = None) -> dict[str, Tensor]:
+        """All-reduce gradients (SUM, left un-normalised) and average ``scalars`` in the same call."""
+        keys = self.stage_scalars(scalars)
+        self.reduce()
         return {k: self.flat.tail[i] / self.world for i, k in enumerate(keys)}

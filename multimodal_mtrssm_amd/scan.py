@@ -5,9 +5,11 @@ Division of labour:
 * the serial T-step recurrence runs in ONE persistent HIP launch forward and ONE backward
   (``mtrssm_*_rollout_fwd`` / ``_bwd``);
 * contractions that do not depend on the recurrence -- the action / observation-embedding halves of the
-  first layers -- are hoisted out of the loop as ``[B*T, in] x [in, out]`` library GEMMs (``F.linear``);
-* every weight gradient is formed AFTER the backward scan as one ``[out, B*T] x [B*T, in]`` library GEMM
-  from the per-step pre-activation gradients the kernel emits.
+  first layers -- are hoisted out of the loop as ``[B*T, in] x [in, out]`` GEMMs (``linear.linear``: the hand-written
+  fp32-MFMA kernel of ``csrc/gemm.hip``);
+* every weight gradient is formed AFTER the backward scan as one ``[out, B*T] x [B*T, in]`` GEMM of the same kernel
+  from the per-step pre-activation gradients the scan emits, accumulated straight into the flat gradient buffer when the
+  parameters live in one (``linear.grad_target``), bias gradients as column sums inside the same launch.
 
 Replaces the loop bodies of ``mrssm/mopoe_mrssm/core.py:221-256`` and
 ``mmtrssm/mopoe_mmtrssm/core.py:405-490`` and their autograd graphs (~870 eager ops per step).
@@ -19,11 +21,11 @@ import ctypes as C
 from dataclasses import dataclass
 
 import torch
-import torch.nn.functional as F  # noqa: N812
 from torch import Tensor
 
 from multimodal_mtrssm_amd import _lib
 from multimodal_mtrssm_amd.distributions import KL_BALANCE_ALPHA
+from multimodal_mtrssm_amd.linear import gemm, grad_target, linear
 
 
 @dataclass(frozen=True)
@@ -57,6 +59,41 @@ def _new(like: Tensor, *shape: int) -> Tensor:
 
 def _opt(t: Tensor | None) -> Tensor | None:
     return None if t is None else _c(t)
+
+
+class _WeightGrads:
+    """Collects ``dW[:, cols] += gy^T x`` / ``db += colsum(gy)`` launches of one backward; ``result(w)`` is what autograd gets
+    for ``w``: None when the gradient went straight into a flat gradient buffer, else the tensor it was accumulated in."""
+
+    def __init__(self) -> None:
+        self.own: dict[int, Tensor] = {}
+
+    def _target(self, w: Tensor, rows: slice | None, cols: slice | None) -> Tensor:
+        view = w
+        if rows is not None:
+            view = view[rows]
+        if cols is not None:
+            view = view[:, cols]
+        tgt = grad_target(view)
+        if tgt is not None:
+            return tgt
+        full = self.own.get(id(w))
+        if full is None:
+            full = self.own[id(w)] = torch.zeros_like(w)
+        out = full
+        if rows is not None:
+            out = out[rows]
+        if cols is not None:
+            out = out[:, cols]
+        return out
+
+    def add(self, gy: Tensor, x: Tensor, w: Tensor, *, cols: slice | None = None, bias: Tensor | None = None) -> None:
+        """``w.grad[:, cols] += gy^T x`` with ``gy [B*T, out]``, ``x [B*T, in]`` (strided column views welcome)."""
+        gemm(gy, x, self._target(w, None, cols), a_rmajor=True, b_rmajor=True, colsum=None if bias is None else self._target(bias, None, None),
+             accumulate=True)
+
+    def result(self, w: Tensor) -> Tensor | None:
+        return self.own.get(id(w))
 
 
 def _expect(**named: tuple[Tensor | None, tuple[int, ...]]) -> None:
@@ -126,6 +163,7 @@ class _MrssmScan(torch.autograd.Function):
                    "mtrssm_mrssm_rollout_fwd")
         if need_grad:
             ctx.cfg, ctx.A = cfg, A
+            ctx.biases, ctx.w3 = (b2, bih, bhh, b3, b4, ba2, bv2), w3
             ctx.save_for_backward(deter0, stoch0, deter, prior_logits, post_logits, post_stoch, sv["sv_h1"], sv["sv_h2"],
                                   sv["sv_gates"], sv["sv_heads"], sv["sv_la"], sv["sv_lv"], w1s_t, wh1,
                                   w1, w2, wih, whh, w4, wa1, wa2, wv1, wv2)
@@ -169,29 +207,30 @@ class _MrssmScan(torch.autograd.Function):
                                      _lib.stream_ptr(deter.device), flops=2.0 * B * T * macs, nbytes=4.0 * B * T * per_bt),
                    "mtrssm_mrssm_rollout_bwd")
 
-        # ---- weight gradients: one [out, B*T] x [B*T, in] library GEMM each (rocBLAS) -------------
+        # ---- weight gradients: one [out, B*T] x [B*T, in] GEMM each (csrc/gemm.hip), bias gradients in the same launches -----
         prev_stoch = _flat2(torch.cat([stoch0.unsqueeze(1), post_stoch[:, :-1]], dim=1))
         prev_deter = _flat2(torch.cat([deter0.unsqueeze(1), deter[:, :-1]], dim=1))
         fz1, fh2, fgi, fgh, fzh = map(_flat2, (d_z1, d_h2, d_gi, d_gh, d_zh))
         flp, fla, flv = map(_flat2, (d_lp, d_la, d_lv))
         fdet, fh1, fsh2, fheads = map(_flat2, (deter, sv_h1, sv_h2, sv_heads))
-        g_w1 = torch.zeros_like(w1)
-        g_w1[:, A:] = fz1.t() @ prev_stoch
-        g_w2, g_b2 = fh2.t() @ fh1, fh2.sum(0)
-        g_wih, g_bih = fgi.t() @ fsh2, fgi.sum(0)
-        g_whh, g_bhh = fgh.t() @ prev_deter, fgh.sum(0)
-        g_wh1 = fzh.t() @ fdet  # [3H, D]: prior.0 | audio.0[:, :D] | vision.0[:, :D]
-        g_w3, g_b3 = g_wh1[:H], fzh[:, :H].sum(0)
-        g_wa1 = torch.zeros_like(wa1)
-        g_wa1[:, :D] = g_wh1[H : 2 * H]
-        g_wv1 = torch.zeros_like(wv1)
-        g_wv1[:, :D] = g_wh1[2 * H :]
-        g_w4, g_b4 = flp.t() @ fheads[:, :H], flp.sum(0)
-        g_wa2, g_ba2 = fla.t() @ fheads[:, H : 2 * H], fla.sum(0)
-        g_wv2, g_bv2 = flv.t() @ fheads[:, 2 * H :], flv.sum(0)
+        (b2, bih, bhh, b3, b4, ba2, bv2) = ctx.biases
+        wg = _WeightGrads()
+        wg.add(fz1, prev_stoch, w1, cols=slice(A, None))
+        wg.add(fh2, fh1, w2, bias=b2)
+        wg.add(fgi, fsh2, wih, bias=bih)
+        wg.add(fgh, prev_deter, whh, bias=bhh)
+        w3 = ctx.w3
+        wg.add(fzh[:, :H], fdet, w3, bias=b3)  # prior.0 | audio.0[:, :D] | vision.0[:, :D]
+        wg.add(fzh[:, H : 2 * H], fdet, wa1, cols=slice(0, D))
+        wg.add(fzh[:, 2 * H :], fdet, wv1, cols=slice(0, D))
+        wg.add(flp, fheads[:, :H], w4, bias=b4)
+        wg.add(fla, fheads[:, H : 2 * H], wa2, bias=ba2)
+        wg.add(flv, fheads[:, 2 * H :], wv2, bias=bv2)
         g_pa, g_pv = d_zh[..., H : 2 * H], d_zh[..., 2 * H :]
+        r = wg.result
         return (None, d_z1, g_pa, g_pv, g_deter0, g_stoch0, None, None,
-                g_w1, g_w2, g_b2, g_wih, g_bih, g_whh, g_bhh, g_w3, g_b3, g_w4, g_b4, g_wa1, g_wa2, g_ba2, g_wv1, g_wv2, g_bv2)
+                r(w1), r(w2), r(b2), r(wih), r(bih), r(whh), r(bhh), r(w3), r(b3), r(w4), r(b4), r(wa1), r(wa2), r(ba2), r(wv1), r(wv2),
+                r(bv2))
 
 
 def mrssm_posterior_rollout(  # noqa: PLR0913
@@ -215,9 +254,9 @@ def mrssm_posterior_rollout(  # noqa: PLR0913
         raise NotImplementedError(msg)
     cfg = ScanConfig(K, Cc, _lib.ACT_IDS[act_names.pop()], balancing, rows_per_block, threads)
     # hoisted, recurrence-independent halves of the first layers: plain library GEMMs
-    xa = F.linear(actions, l1.weight[:, :A], l1.bias)
-    pa = F.linear(audio_embed, a1.weight[:, D:], a1.bias)
-    pv = F.linear(vision_embed, v1.weight[:, D:], v1.bias)
+    xa = linear(actions, l1.weight[:, :A], l1.bias)
+    pa = linear(audio_embed, a1.weight[:, D:], a1.bias)
+    pv = linear(vision_embed, v1.weight[:, D:], v1.bias)
     cell = transition.rnn_cell
     deter, prior_logits, post_logits, post_stoch, prior_stoch, kl = _MrssmScan.apply(
         cfg, xa, pa, pv, deter0, stoch0, u_post, u_prior,
@@ -246,7 +285,7 @@ def mrssm_prior_rollout(transition, actions: Tensor, deter0: Tensor, stoch0: Ten
         cell = transition.rnn_cell
         if u_prior is None:
             u_prior = torch.rand(B, T, K, device=actions.device)
-        xa = _c(F.linear(actions, l1.weight[:, :A], l1.bias))
+        xa = _c(linear(actions, l1.weight[:, :A], l1.bias))
         tensors = dict(w1s_t=_c(l1.weight[:, A:].t()), w2_t=_c(l2.weight.t()), b2=_c(l2.bias), wih_t=_c(cell.weight_ih.t()),
                        bih=_c(cell.bias_ih), whh_t=_c(cell.weight_hh.t()), bhh=_c(cell.bias_hh), wh1_t=_c(p1.weight.t()),
                        b3=_c(p1.bias), w4=_c(p2.weight), b4=_c(p2.bias))
@@ -353,6 +392,7 @@ class _MmtrssmScan(torch.autograd.Function):
         del tensors
         if need_grad:
             ctx.cfg, ctx.A = cfg, A
+            ctx.biases, ctx.first_layers = (bh, blp1, blp2, ba2, bv2, bhp1, bhp2, bhq1, bhq2), (wlp1, whp1)
             ctx.save_for_backward(
                 deter_l0, deter_h0, stoch_l0, stoch_h0, o["deter_l"], o["deter_h"], o["prior_logits_l"], o["prior_logits_h"],
                 o["post_logits_l"], o["post_logits_h"], o["post_stoch_l"], o["post_stoch_h"], sv["sv_l1"], sv["sv_h1"],
@@ -407,32 +447,32 @@ class _MmtrssmScan(torch.autograd.Function):
         ful, fuh, fzl, fzh = map(_flat2, (d["d_ul"], d["d_uh"], d["d_zl1"], d["d_zh1"]))
         flpl, fla, flv, flph, flqh = map(_flat2, (d["d_lpl"], d["d_la"], d["d_lv"], d["d_lph"], d["d_lqh"]))
         fdl, fdh, fl1, fh1 = map(_flat2, (deter_l, deter_h, sv_l1, sv_h1))
-        g_wxl = torch.zeros_like(wxl)
-        g_wxl[:, A:] = ful.t() @ prev_slh
-        g_wdl = ful.t() @ prev_dl
-        g_wxh = fuh.t() @ _flat2(prev_sh)
-        g_wdh = fuh.t() @ prev_dh
-        g_bh = fuh.sum(0)
-        g_wl1 = fzl.t() @ fdl  # [4H, LD]
-        g_wlp1, g_blp1 = g_wl1[:H], fzl[:, :H].sum(0)
-        g_wa1 = torch.zeros_like(wa1)
-        g_wa1[:, :LD] = g_wl1[H : 2 * H]
-        g_wv1 = torch.zeros_like(wv1)
-        g_wv1[:, :LD] = g_wl1[2 * H : 3 * H]
+        (bh, blp1, blp2, ba2, bv2, bhp1, bhp2, bhq1, bhq2) = ctx.biases
+        wlp1, whp1 = ctx.first_layers
+        # one [out, B*T] x [B*T, in] GEMM per weight block (csrc/gemm.hip), bias gradients as column sums in the same launch
+        wg = _WeightGrads()
+        wg.add(ful, prev_slh, wxl, cols=slice(A, None))
+        wg.add(ful, prev_dl, wdl)
+        wg.add(fuh, prev_slh[:, LS:], wxh, bias=bh)
+        wg.add(fuh, prev_dh, wdh)
+        wg.add(fzl[:, :H], fdl, wlp1, bias=blp1)
+        wg.add(fzl[:, H : 2 * H], fdl, wa1, cols=slice(0, LD))
+        wg.add(fzl[:, 2 * H : 3 * H], fdl, wv1, cols=slice(0, LD))
         fzq = fzl[:, 3 * H :]
-        g_whq1 = torch.cat([g_wl1[3 * H :], fzq.t() @ fdh], dim=1)
-        g_bhq1 = fzq.sum(0)
-        g_whp1, g_bhp1 = fzh.t() @ fdh, fzh.sum(0)
-        g_wlp2, g_blp2 = flpl.t() @ fl1[:, :H], flpl.sum(0)
-        g_wa2, g_ba2 = fla.t() @ fl1[:, H : 2 * H], fla.sum(0)
-        g_wv2, g_bv2 = flv.t() @ fl1[:, 2 * H : 3 * H], flv.sum(0)
-        g_whq2, g_bhq2 = flqh.t() @ fl1[:, 3 * H :], flqh.sum(0)
-        g_whp2, g_bhp2 = flph.t() @ fh1, flph.sum(0)
+        wg.add(fzq, fdl, whq1, cols=slice(0, LD), bias=bhq1)
+        wg.add(fzq, fdh, whq1, cols=slice(LD, None))
+        wg.add(fzh, fdh, whp1, bias=bhp1)
+        wg.add(flpl, fl1[:, :H], wlp2, bias=blp2)
+        wg.add(fla, fl1[:, H : 2 * H], wa2, bias=ba2)
+        wg.add(flv, fl1[:, 2 * H : 3 * H], wv2, bias=bv2)
+        wg.add(flqh, fl1[:, 3 * H :], whq2, bias=bhq2)
+        wg.add(flph, fh1, whp2, bias=bhp2)
         zl = d["d_zl1"]
+        r = wg.result
         return (None, d["d_ul"], zl[..., H : 2 * H], zl[..., 2 * H : 3 * H], g0["g_deter_l0"], g0["g_deter_h0"], g0["g_hidden_l0"],
                 g0["g_hidden_h0"], g0["g_stoch_l0"], g0["g_stoch_h0"], None, None, None, None,
-                g_wxl, g_wdl, g_wxh, g_wdh, g_bh, g_wlp1, g_blp1, g_wlp2, g_blp2, g_wa1, g_wa2, g_ba2, g_wv1, g_wv2, g_bv2,
-                g_whp1, g_bhp1, g_whp2, g_bhp2, g_whq1, g_bhq1, g_whq2, g_bhq2)
+                r(wxl), r(wdl), r(wxh), r(wdh), r(bh), r(wlp1), r(blp1), r(wlp2), r(blp2), r(wa1), r(wa2), r(ba2), r(wv1), r(wv2), r(bv2),
+                r(whp1), r(bhp1), r(whp2), r(bhp2), r(whq1), r(bhq1), r(whq2), r(bhq2))
 
 
 def _mt_act(model) -> int:  # noqa: ANN001
@@ -459,9 +499,9 @@ def mmtrssm_posterior_rollout(model, actions: Tensor, audio_embed: Tensor, visio
     a1, a2 = model.audio_representation.rnn_to_post_projector.two_layer()
     v1, v2 = model.vision_representation.rnn_to_post_projector.two_layer()
     lr, hr = model.l_rnn, model.h_rnn
-    xl = F.linear(actions, lr._input2h.weight[:, :A], lr._input2h.bias + lr._d2h.bias)  # noqa: SLF001
-    pa = F.linear(audio_embed, a1.weight[:, LD:], a1.bias)
-    pv = F.linear(vision_embed, v1.weight[:, LD:], v1.bias)
+    xl = linear(actions, lr._input2h.weight[:, :A], lr._input2h.bias + lr._d2h.bias)  # noqa: SLF001
+    pa = linear(audio_embed, a1.weight[:, LD:], a1.bias)
+    pv = linear(vision_embed, v1.weight[:, LD:], v1.bias)
     bh = hr._input2h.bias + hr._d2h.bias  # noqa: SLF001
     out = _MmtrssmScan.apply(
         cfg, xl, pa, pv, state0["deter_l"], state0["deter_h"], state0["hidden_l"], state0["hidden_h"], state0["stoch_l"],
@@ -495,7 +535,7 @@ def mmtrssm_prior_rollout(model, actions: Tensor, state0: dict[str, Tensor], noi
         hp1, hp2 = model.h_prior.two_layer()
         H = lp1.out_features
         lr, hr = model.l_rnn, model.h_rnn
-        xl = _c(F.linear(actions, lr._input2h.weight[:, :A], lr._input2h.bias + lr._d2h.bias))  # noqa: SLF001
+        xl = _c(linear(actions, lr._input2h.weight[:, :A], lr._input2h.bias + lr._d2h.bias))  # noqa: SLF001
         tensors = dict(
             wxl_s_t=_c(lr._input2h.weight[:, A:].t()), wdl_t=_c(lr._d2h.weight.t()), wxh_t=_c(hr._input2h.weight.t()),  # noqa: SLF001
             wdh_t=_c(hr._d2h.weight.t()), bh=_c(hr._input2h.bias + hr._d2h.bias), wl1_t=_c(lp1.weight.t()), bl1=_c(lp1.bias),  # noqa: SLF001

@@ -694,6 +694,123 @@ def test_bf16_mode_stays_within_its_stated_tolerance(lib_loaded: None) -> None:
 
 
 # ---------------------------------------------------------------------------------------------
+# fp32-MFMA GEMM (csrc/gemm.hip) and the Linear layers built on it
+# ---------------------------------------------------------------------------------------------
+GEMM_CASES = [
+    # M, N, R, a_rmajor, b_rmajor, extras
+    (3200, 256, 4096, False, False, "bias+act_a"),   # encoder head forward: act(X) W^T + b
+    (3200, 200, 4, False, False, "bias"),            # action projection: 4-wide reduction, unaligned rows (lda = 4 ok, K tail)
+    (64, 200, 256, False, False, "bias"),            # init_proj on B rows
+    (130, 70, 33, False, False, "views"),            # ragged everything, operands are column slices of wider matrices
+    (3200, 4096, 256, False, True, "zgrad"),         # encoder head data gradient: (dY W) * act'(X)
+    (100, 230, 64, False, True, ""),                 # decoder stem data gradient
+    (200, 230, 3200, True, True, "colsum+acc"),      # scan weight gradient + bias gradient, split reduction (atomics)
+    (30, 200, 3200, True, True, "colsum+acc"),       # narrow head weight gradient
+    (256, 4096, 3200, True, True, "acc+act_b"),      # encoder head weight gradient with the fused activation on X
+    (70, 50, 129, True, True, "views+acc"),          # ragged, strided views, accumulate into a running target
+    (65, 33, 70, True, False, ""),                   # the fourth layout (unused by the model, same kernel)
+]
+
+
+@pytest.mark.parametrize(("m", "n", "r", "a_rm", "b_rm", "extras"), GEMM_CASES)
+def test_gemm_kernel(m: int, n: int, r: int, a_rm: bool, b_rm: bool, extras: str, lib_loaded: None) -> None:  # noqa: PLR0913
+    """mtrssm_gemm against float64 matmul: every layout, ragged tiles, strided views, fused activations / bias / act' / column sums /
+    accumulation.  Tolerance 2e-6 of the result's scale (an fp32 fma chain over <= 4096 terms; the reference's fp32 nn.Linear
+    has the same)."""
+    import torch.nn.functional as F  # noqa: N812
+
+    from multimodal_mtrssm_amd.linear import gemm
+
+    g = torch.Generator().manual_seed(m * 7 + n * 3 + r)
+    pad = 5 if "views" in extras else 0
+    a_full = torch.randn((r, m + pad) if a_rm else (m, r + pad), generator=g)
+    b_full = torch.randn((r, n + pad) if b_rm else (n, r + pad), generator=g)
+    a = a_full[:, pad:] if pad else a_full
+    b = b_full[:, pad:] if pad else b_full
+    a_ir = a.t() if a_rm else a   # [M, R]
+    b_jr = b.t() if b_rm else b   # [N, R]
+    if "act_a" in extras:
+        a_ir = F.elu(a_ir)
+    if "act_b" in extras:
+        b_jr = F.elu(b_jr)
+    want = a_ir.double() @ b_jr.double().t()
+    bias = torch.randn(n, generator=g) if "bias" in extras else None
+    if bias is not None:
+        want = want + bias.double()
+    z = torch.randn(m, n, generator=g) if "zgrad" in extras else None
+    if z is not None:
+        want = want * torch.where(z > 0, torch.ones_like(z), z.exp()).double()
+    c0 = torch.randn(m, n + pad, generator=g) if "acc" in extras else torch.full((m, n + pad), float("nan"))
+    if "acc" in extras:
+        want = want + c0[:, pad:].double()
+    c = c0.to(DEV)
+    colsum0 = torch.randn(m, generator=g) if "colsum" in extras else None
+    colsum = None if colsum0 is None else colsum0.to(DEV)
+    ag, bg = a_full.to(DEV), b_full.to(DEV)
+    gemm(ag[:, pad:] if pad else ag, bg[:, pad:] if pad else bg, c[:, pad:] if pad else c, a_rmajor=a_rm, b_rmajor=b_rm,
+         bias=None if bias is None else bias.to(DEV), zgrad=None if z is None else z.to(DEV), colsum=colsum,
+         act_a=2 if "act_a" in extras else 0, act_b=2 if "act_b" in extras else 0, act_z=2 if z is not None else 0,
+         accumulate="acc" in extras)
+    got = c[:, pad:] if pad else c
+    scale = float(want.abs().max())
+    np.testing.assert_allclose(_np(got), want.float().numpy(), rtol=1e-5, atol=2e-6 * scale)
+    if pad and "acc" not in extras:
+        assert torch.isnan(c[:, :pad]).all()  # nothing outside the view was written
+    if colsum is not None:
+        want_cs = colsum0.double() + (a.t() if a_rm else a).double().sum(1)
+        np.testing.assert_allclose(_np(colsum), want_cs.float().numpy(), rtol=1e-5, atol=2e-6 * float(want_cs.abs().max()))
+
+
+def test_linear_function_and_gradient_sink(lib_loaded: None) -> None:
+    """linear.linear (= F.linear(act(x), W, b)) forward / backward against torch on the CPU, once with plain parameters (gradients
+    returned to autograd) and once inside a FlatParameters module (weight / bias gradients accumulated by the GEMM straight into
+    the flat buffer: .grad views filled, the autograd node hands back None, the parameters are marked touched)."""
+    import torch.nn.functional as F  # noqa: N812
+
+    import multimodal_mtrssm_amd as mt
+    from multimodal_mtrssm_amd.linear import linear
+    from multimodal_mtrssm_amd.optim import FlatParameters
+
+    torch.manual_seed(3)
+    ref = mt.MLP(37, 11, 50, 1, torch.nn.ELU)
+    x = torch.randn(6, 9, 37, requires_grad=True)
+    y = ref(x)  # CPU: nn.Sequential's path
+    gy = torch.randn(y.shape)
+    y.backward(gy)
+    for flat_mode in (False, True):
+        net = mt.MLP(37, 11, 50, 1, torch.nn.ELU)
+        net.load_state_dict(ref.state_dict())
+        net = net.to(DEV)
+        flat = FlatParameters(net) if flat_mode else None
+        xg = x.detach().to(DEV).requires_grad_()
+        yg = net(xg)
+        yg.backward(gy.to(DEV))
+        np.testing.assert_allclose(_np(yg), y.detach().numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(_np(xg.grad), x.grad.numpy(), rtol=1e-5, atol=1e-6)
+        for (k, p), q in zip(net.named_parameters(), ref.parameters(), strict=True):
+            np.testing.assert_allclose(_np(p.grad), q.grad.numpy(), rtol=1e-5, atol=2e-6 * float(q.grad.abs().max()), err_msg=k)
+        if flat is not None:
+            flat.check_views()
+            assert all(flat.touched)
+            # a second backward accumulates (as AccumulateGrad would)
+            net(xg).backward(gy.to(DEV))
+            for p, q in zip(net.parameters(), ref.parameters(), strict=True):
+                np.testing.assert_allclose(_np(p.grad), 2 * q.grad.numpy(), rtol=1e-5, atol=4e-6 * float(q.grad.abs().max()))
+    # a slice of a weight (the hoisted halves of the scan's first layers) and an activation on the input
+    w = torch.randn(20, 30, requires_grad=True)
+    b = torch.randn(20, requires_grad=True)
+    xx = torch.randn(17, 12, requires_grad=True)
+    want = F.linear(F.elu(xx), w[:, 18:], b)
+    want.square().sum().backward()
+    wg, bg, xg = (t.detach().to(DEV).requires_grad_() for t in (w, b, xx))
+    got = linear(xg, wg[:, 18:], bg, pre_act=2)
+    got.square().sum().backward()
+    np.testing.assert_allclose(_np(got), want.detach().numpy(), rtol=1e-5, atol=1e-5)
+    for a_, b_ in ((wg, w), (bg, b), (xg, xx)):
+        np.testing.assert_allclose(_np(a_.grad), b_.grad.numpy(), rtol=1e-5, atol=2e-6 * float(b_.grad.abs().max()))
+
+
+# ---------------------------------------------------------------------------------------------
 # the small streaming kernels
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("shape", [(3, 5, 1, 8, 8), (2, 7, 1, 5, 3), (4, 1, 3, 16, 16)])
@@ -713,6 +830,15 @@ def test_gaussian_nll_kernel(shape: tuple[int, ...], lib_loaded: None) -> None:
     np.testing.assert_allclose(_np(p.grad), pred.grad.numpy(), rtol=1e-6, atol=1e-8)
     with pytest.raises(ValueError, match="same shape"):
         mt.likelihood(prediction=p, target=tgt.to(DEV)[1:], event_ndims=3)
+    # the decoder's Tanh folded into the kernel: likelihood(raw, out_act=Tanh) == likelihood(tanh(raw))
+    raw = torch.randn(shape, generator=g).requires_grad_()
+    want_t = gaussian_nll(torch.tanh(raw), tgt, 3)
+    want_t.backward()
+    r = raw.detach().to(DEV).requires_grad_()
+    got_t = mt.likelihood(prediction=r, target=tgt.to(DEV), event_ndims=3, out_act=3)
+    (got_t * 1.0).backward()
+    np.testing.assert_allclose(float(got_t), float(want_t), rtol=2e-6)
+    np.testing.assert_allclose(_np(r.grad), raw.grad.numpy(), rtol=2e-5, atol=1e-7)
 
 
 class _WithDeadLayer(torch.nn.Module):
