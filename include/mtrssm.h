@@ -393,6 +393,10 @@ int mtrssm_pack_conv_weight(const float* w, int32_t O, int32_t I, int32_t KH, in
 int mtrssm_pack_conv_weights(const int64_t* table, int32_t count, int32_t blocks_per_weight, void* stream);
 int mtrssm_conv_weight_grad(const MtrssmConvGeom* g, const float* a, const float* src, const float* src2,
                             int32_t pre_act_a, float* dwp, float* dbias, void* stream);
+/* End of backward: add every packed conv weight gradient [OPad][taps][IPad] of the step into its parameter-layout target
+ * [O][I][KH][KW] (a view of the flat gradient buffer) and clear the packed buffers, in ONE launch.  table (device memory):
+ * `count` rows of 8 int64 = { packed pointer, target pointer, O, I, taps = KH*KW, IPad, 0, 0 }. */
+int mtrssm_unpack_conv_grads(const int64_t* table, int32_t count, int32_t blocks_per_entry, void* stream);
 /* Last decoder layer (default.yaml:70-74, channels [.., 1]): out[N, Cout<=2, 2Hs, 2Ws] = bias + ConvTranspose2d_{k=4,s=2,p=1}(pre(src[N,C,Hs,Ws]))
  * with w in the ConvTranspose2d layout [C][Cout][4][4].  All four output parity classes in one pass, one activation per
  * source element. */

@@ -20,6 +20,7 @@ import torch
 from torch import Tensor
 
 from multimodal_mtrssm_amd import _lib
+from multimodal_mtrssm_amd.linear import grad_target
 
 
 def _pad_to(n: int, m: int) -> int:
@@ -326,6 +327,51 @@ def _zeros(n: int, device: torch.device) -> Tensor:
     return out
 
 
+class _ConvGradSink:
+    """Conv weight gradients of parameters that live in an ``optim.FlatParameters`` buffer: each weight owns a persistent
+    packed accumulation buffer ``[OPad][taps][IPad]`` (what the weight-gradient kernels' coalesced atomics want), and ONE
+    ``mtrssm_unpack_conv_grads`` launch at the end of the backward pass (autograd's ``queue_callback``) adds them all into the
+    flat gradient buffer in the parameter layout and clears them.  Replaces, per conv weight, a zero fill + a strided
+    AccumulateGrad add (~80 of each per train step); the autograd nodes return None for these weights."""
+
+    def __init__(self) -> None:
+        self.entries: dict[tuple, tuple] = {}
+        self.table: Tensor | None = None
+        self.pending = False
+
+    def target(self, weight: Tensor | None, o: int, i: int, taps: int, opad: int, ipad: int) -> Tensor | None:
+        """The packed accumulation buffer for ``weight`` ([o][i][kh][kw]-shaped parameter), or None when it has no flat home."""
+        if weight is None or not weight.is_contiguous():
+            return None
+        dst = grad_target(weight)
+        if dst is None:
+            return None
+        key = (weight.data_ptr(), o, i, taps, opad, ipad)
+        e = self.entries.get(key)
+        if e is None:
+            packed = torch.zeros(opad, taps, ipad, device=weight.device, dtype=torch.float32)
+            e = self.entries[key] = (packed, dst)
+            self.table = None
+        if not self.pending:
+            self.pending = True
+            torch.autograd.Variable._execution_engine.queue_callback(self.flush)  # noqa: SLF001
+        return e[0]
+
+    def flush(self) -> None:
+        self.pending = False
+        if not self.entries:
+            return
+        dev = next(iter(self.entries.values()))[0].device
+        if self.table is None:
+            rows = [[packed.data_ptr(), dst.data_ptr(), k[1], k[2], k[3], k[5], 0, 0] for k, (packed, dst) in self.entries.items()]
+            self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
+        _lib.check(_lib.TIMERS.call("mtrssm_unpack_conv_grads", _lib.load().mtrssm_unpack_conv_grads, _lib.raw_ptr(self.table),
+                                    len(self.entries), 8, _lib.stream_ptr(dev)), "mtrssm_unpack_conv_grads")
+
+
+_GRAD_SINK = _ConvGradSink()
+
+
 def reset_scratch(*, pin: bool = False) -> None:
     """Forget the partly used zeroed chunks (the next weight gradient opens a fresh one).  ``graph.CapturedTrainStep`` calls
     this right before and right after a capture: a chunk zeroed BEFORE the capture would come back dirty on the second
@@ -336,18 +382,25 @@ def reset_scratch(*, pin: bool = False) -> None:
         _PLAN.pinned = True
 
 
-def _weight_grad(a: Tensor, src: Tensor, coords: Tensor | None, kh: int, kw: int, stride: int, pad: int, pre_act_a: bool,
-                 pre_act_src: bool, act: int, *, want_bias: bool = False) -> tuple[Tensor, Tensor | None]:  # noqa: FBT001
+def _weight_grad(a: Tensor, src: Tensor, coords: Tensor | None, kh: int, kw: int, stride: int, pad: int, pre_act_a: bool,  # noqa: PLR0913
+                 pre_act_src: bool, act: int, *, want_bias: bool = False, weight: Tensor | None = None,
+                 bias: Tensor | None = None) -> tuple[Tensor | None, Tensor | None]:  # noqa: FBT001
     """``dw[o][i][ky][kx] = sum preA(a)[n,o,y,x] * pre(src ++ coords)[n,i,y*s-p+ky,x*s-p+kx]`` -> ``[O][I][kh][kw]``.
 
-    With ``want_bias`` (only when ``a`` is the raw output gradient) the same pass also returns ``sum_{n,y,x} a``."""
+    With ``want_bias`` (only when ``a`` is the raw output gradient) the same pass also returns ``sum_{n,y,x} a``.
+    ``weight`` / ``bias``: the parameters themselves; when they live in a flat gradient buffer the gradients are accumulated
+    there (``_ConvGradSink``; the bias directly by the kernel's atomics) and None is returned in their place."""
     lib = _lib.load()
     n, o, hq, wq = a.shape
     _, c, hs, ws = src.shape
     c2 = 0 if coords is None else coords.shape[0]
     opad, ipad = _pads(o, c + c2)
-    dwp = _zeros(opad * kh * kw * ipad, a.device).view(opad, kh * kw, ipad)
-    dbias = _zeros(o, a.device) if want_bias else None
+    sunk = _GRAD_SINK.target(weight, o, c + c2, kh * kw, opad, ipad)
+    dwp = sunk if sunk is not None else _zeros(opad * kh * kw * ipad, a.device).view(opad, kh * kw, ipad)
+    dbias = bias_sunk = None
+    if want_bias:
+        bias_sunk = grad_target(bias) if bias is not None and bias.is_contiguous() else None
+        dbias = bias_sunk if bias_sunk is not None else _zeros(o, a.device)
     geom = _geom(N=n, C=c, Hs=hs, Ws=ws, C2=c2, Cpad=ipad, KH=kh, KW=kw, SS=stride, TS=1, OFFY=-pad, OFFX=-pad, Hq=hq, Wq=wq,
                  OS=1, QY=0, QX=0, Ho=hq, Wo=wq, Cout=o, CoutPad=opad, pre_act=int(pre_act_src), act=act)
     flops = 2.0 * n * hq * wq * o * kh * kw * (c + c2)
@@ -356,16 +409,19 @@ def _weight_grad(a: Tensor, src: Tensor, coords: Tensor | None, kh: int, kw: int
         "mtrssm_conv_weight_grad", lib.mtrssm_conv_weight_grad, C.byref(geom), _lib.ptr(a), _lib.ptr(src), _lib.ptr(coords),
         int(pre_act_a), _lib.ptr(dwp), _lib.ptr(dbias), _lib.stream_ptr(a.device), flops=flops, nbytes=nbytes),
         "mtrssm_conv_weight_grad")
-    return dwp[:o, :, : c + c2].reshape(o, kh, kw, c + c2).permute(0, 3, 1, 2), dbias
+    g_w = None if sunk is not None else dwp[:o, :, : c + c2].reshape(o, kh, kw, c + c2).permute(0, 3, 1, 2)
+    return g_w, (None if bias_sunk is not None else dbias)
 
 
-def _channel_sum(x: Tensor) -> Tensor:
+def _channel_sum(x: Tensor, bias: Tensor | None = None) -> Tensor | None:
+    """``sum_{n,y,x} x[n, c, y, x]``; straight into ``bias``'s flat gradient view when it has one (None is returned then)."""
     lib = _lib.load()
     n, c, h, w = x.shape
-    out = _zeros(c, x.device)
+    sunk = grad_target(bias) if bias is not None and bias.is_contiguous() else None
+    out = sunk if sunk is not None else _zeros(c, x.device)
     _lib.check(_lib.TIMERS.call("mtrssm_channel_sum", lib.mtrssm_channel_sum, _lib.ptr(x), n, c, h * w, _lib.ptr(out),
                                 _lib.stream_ptr(x.device)), "mtrssm_channel_sum")
-    return out
+    return None if sunk is not None else out
 
 
 class _Conv2d(torch.autograd.Function):
@@ -377,6 +433,7 @@ class _Conv2d(torch.autograd.Function):
         out = _conv_forward_gather(x, coords, weight, bias, stride, pad, pre_act, act)
         ctx.save_for_backward(x, weight, coords if coords is not None else x.new_zeros(0))
         ctx.cfg = (stride, pad, pre_act, act, coords is not None, bias is not None)
+        ctx.bias = bias  # the parameter (for its gradient's destination), not needed as a value
         return out
 
     @staticmethod
@@ -394,9 +451,10 @@ class _Conv2d(torch.autograd.Function):
         g_w = g_b = None
         want_b = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            g_w, g_b = _weight_grad(g_out, x, coords, kh, kw, stride, pad, False, pre_act, act, want_bias=want_b)
+            g_w, g_b = _weight_grad(g_out, x, coords, kh, kw, stride, pad, False, pre_act, act, want_bias=want_b, weight=weight,
+                                    bias=ctx.bias)
         elif want_b:
-            g_b = _channel_sum(g_out)
+            g_b = _channel_sum(g_out, ctx.bias)
         return g_x, g_w, g_b, None, None, None, None, None
 
 
@@ -411,6 +469,7 @@ class _ConvTranspose2d(torch.autograd.Function):
         out = _conv_transposed_gather(x, weight, bias, stride, pad, (ho, wo), pre_act, act)
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, pad, pre_act, act, bias is not None)
+        ctx.bias = bias
         return out
 
     @staticmethod
@@ -426,8 +485,8 @@ class _ConvTranspose2d(torch.autograd.Function):
         g_w = None
         if ctx.needs_input_grad[1]:
             # dW[ci][co][ky][kx] = sum pre(x)[n,ci,y,x] dOut[n,co,y*s-p+ky,x*s-p+kx]
-            g_w, _ = _weight_grad(x, g_out, None, kh, kw, stride, pad, pre_act, False, act)
-        g_b = _channel_sum(g_out) if has_bias and ctx.needs_input_grad[2] else None
+            g_w, _ = _weight_grad(x, g_out, None, kh, kw, stride, pad, pre_act, False, act, weight=weight)
+        g_b = _channel_sum(g_out, ctx.bias) if has_bias and ctx.needs_input_grad[2] else None
         return g_x, g_w, g_b, None, None, None, None, None
 
 
@@ -442,7 +501,7 @@ class _ResidualBlock(torch.autograd.Function):
         h = _conv_forward_gather(x, None, w3, b3, 1, p3, True, act)
         y = _conv_forward_gather(h, None, w1, b1, 1, p1, True, act, add_in=x)
         ctx.save_for_backward(x, h, w3, w1)
-        ctx.act = act
+        ctx.act, ctx.biases = act, (b3, b1)
         return y
 
     @staticmethod
@@ -452,11 +511,12 @@ class _ResidualBlock(torch.autograd.Function):
         g_y = g_y.contiguous()
         p3, p1 = w3.shape[2] // 2, w1.shape[2] // 2
         g_h = _conv_transposed_gather(g_y, w1, None, 1, p1, (h.shape[2], h.shape[3]), False, act, actgrad_in=h)
-        g_w1, g_b1 = _weight_grad(g_y, h, None, w1.shape[2], w1.shape[3], 1, p1, False, True, act, want_bias=True)
+        b3, b1 = ctx.biases
+        g_w1, g_b1 = _weight_grad(g_y, h, None, w1.shape[2], w1.shape[3], 1, p1, False, True, act, want_bias=True, weight=w1, bias=b1)
         g_x = None
         if ctx.needs_input_grad[0]:
             g_x = _conv_transposed_gather(g_h, w3, None, 1, p3, (x.shape[2], x.shape[3]), False, act, actgrad_in=x, add_in=g_y)
-        g_w3, g_b3 = _weight_grad(g_h, x, None, w3.shape[2], w3.shape[3], 1, p3, False, True, act, want_bias=True)
+        g_w3, g_b3 = _weight_grad(g_h, x, None, w3.shape[2], w3.shape[3], 1, p3, False, True, act, want_bias=True, weight=w3, bias=b3)
         return g_x, g_w3, g_b3, g_w1, g_b1, None
 
 
@@ -473,7 +533,7 @@ class _PairResidualBlock(torch.autograd.Function):
         ya, yv = paired(lambda: _conv_forward_gather(ha, None, w1a, b1a, 1, p1, True, act, add_in=xa),
                         lambda: _conv_forward_gather(hv, None, w1v, b1v, 1, p1, True, act, add_in=xv))
         ctx.save_for_backward(xa, ha, w3a, w1a, xv, hv, w3v, w1v)
-        ctx.act = act
+        ctx.act, ctx.biases = act, (b3a, b1a, b3v, b1v)
         return ya, yv
 
     @staticmethod
@@ -484,13 +544,14 @@ class _PairResidualBlock(torch.autograd.Function):
         p3, p1 = w3a.shape[2] // 2, w1a.shape[2] // 2
         g_ha, g_hv = paired(lambda: _conv_transposed_gather(g_ya, w1a, None, 1, p1, (ha.shape[2], ha.shape[3]), False, act, actgrad_in=ha),
                             lambda: _conv_transposed_gather(g_yv, w1v, None, 1, p1, (hv.shape[2], hv.shape[3]), False, act, actgrad_in=hv))
-        g_w1a, g_b1a = _weight_grad(g_ya, ha, None, w1a.shape[2], w1a.shape[3], 1, p1, False, True, act, want_bias=True)
-        g_w1v, g_b1v = _weight_grad(g_yv, hv, None, w1v.shape[2], w1v.shape[3], 1, p1, False, True, act, want_bias=True)
+        b3a, b1a, b3v, b1v = ctx.biases
+        g_w1a, g_b1a = _weight_grad(g_ya, ha, None, w1a.shape[2], w1a.shape[3], 1, p1, False, True, act, want_bias=True, weight=w1a, bias=b1a)
+        g_w1v, g_b1v = _weight_grad(g_yv, hv, None, w1v.shape[2], w1v.shape[3], 1, p1, False, True, act, want_bias=True, weight=w1v, bias=b1v)
         g_xa, g_xv = paired(
             lambda: _conv_transposed_gather(g_ha, w3a, None, 1, p3, (xa.shape[2], xa.shape[3]), False, act, actgrad_in=xa, add_in=g_ya),
             lambda: _conv_transposed_gather(g_hv, w3v, None, 1, p3, (xv.shape[2], xv.shape[3]), False, act, actgrad_in=xv, add_in=g_yv))
-        g_w3a, g_b3a = _weight_grad(g_ha, xa, None, w3a.shape[2], w3a.shape[3], 1, p3, False, True, act, want_bias=True)
-        g_w3v, g_b3v = _weight_grad(g_hv, xv, None, w3v.shape[2], w3v.shape[3], 1, p3, False, True, act, want_bias=True)
+        g_w3a, g_b3a = _weight_grad(g_ha, xa, None, w3a.shape[2], w3a.shape[3], 1, p3, False, True, act, want_bias=True, weight=w3a, bias=b3a)
+        g_w3v, g_b3v = _weight_grad(g_hv, xv, None, w3v.shape[2], w3v.shape[3], 1, p3, False, True, act, want_bias=True, weight=w3v, bias=b3v)
         return g_xa, g_w3a, g_b3a, g_w1a, g_b1a, g_xv, g_w3v, g_b3v, g_w1v, g_b1v, None
 
 
@@ -527,6 +588,7 @@ def _pair_function(base: type) -> type:
             ca, cb = _BranchCtx(), _BranchCtx()
             ya, yb = paired(lambda: base.forward(ca, *args[:n]), lambda: base.forward(cb, *args[n:]))
             ctx.n, ctx.na, ctx.cfgs = n, len(ca.saved_tensors), (ca.cfg, cb.cfg)
+            ctx.biases = (getattr(ca, "bias", None), getattr(cb, "bias", None))
             ctx.save_for_backward(*ca.saved_tensors, *cb.saved_tensors)
             return ya, yb
 
@@ -536,6 +598,7 @@ def _pair_function(base: type) -> type:
             ca, cb = _BranchCtx(needs[: ctx.n]), _BranchCtx(needs[ctx.n :])
             ca.saved_tensors, cb.saved_tensors = saved[: ctx.na], saved[ctx.na :]
             ca.cfg, cb.cfg = ctx.cfgs
+            ca.bias, cb.bias = ctx.biases
             ra, rb = paired(lambda: base.backward(ca, ga), lambda: base.backward(cb, gb))
             return (None, *ra, *rb)
 

@@ -37,6 +37,7 @@ int nll_bwd_launch(const float*, const float*, const float*, int64_t, int64_t, i
 int sumsq_launch(const float*, int64_t, float*, hipStream_t);
 int adamw_launch(float*, const float*, float*, float*, int64_t, const float*, float, float, float, float, float, float, float, int, hipStream_t);
 int gemm_launch(const MtrssmGemm*, hipStream_t);
+int unpack_conv_grads_launch(const int64_t*, int, int, hipStream_t);
 int adamw_prepare_launch(const float*, int64_t, float*, float*, float, float, hipStream_t);
 int adamw_apply_launch(float*, const float*, float*, float*, const unsigned char*, int64_t, const float*, const float*, float, float, float, float,
                        float, float, hipStream_t);
@@ -77,6 +78,9 @@ MTRSSM_API int mtrssm_adamw_step(float* param, const float* grad, float* exp_avg
                                  int32_t step, void* stream) {
   return adamw_launch(param, grad, exp_avg, exp_avg_sq, n, sumsq, clip_norm, grad_scale, lr, beta1, beta2, eps, weight_decay, step,
                       static_cast<hipStream_t>(stream));
+}
+MTRSSM_API int mtrssm_unpack_conv_grads(const int64_t* table, int32_t count, int32_t blocks_per_entry, void* stream) {
+  return unpack_conv_grads_launch(table, count, blocks_per_entry, static_cast<hipStream_t>(stream));
 }
 MTRSSM_API int mtrssm_gemm(const MtrssmGemm* g, void* stream) { return gemm_launch(g, static_cast<hipStream_t>(stream)); }
 MTRSSM_API int mtrssm_adamw_prepare(const float* grad, int64_t n, float* sumsq, float* state, float beta1, float beta2, void* stream) {

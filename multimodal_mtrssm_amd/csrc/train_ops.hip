@@ -250,6 +250,35 @@ int adamw_apply_launch(float* p, const float* g, float* m, float* v, const unsig
 }
 
 // ------------------------------------------------------------------------------------------------
+// Conv weight gradients, end of backward: every conv weight gradient of the step was accumulated (fp32 atomics, 128-byte
+// coalesced) in the kernels' packed layout [OPad][taps][IPad]; ONE launch adds them all into the flat gradient buffer in
+// the parameter layout [O][I][KH][KW] and clears the packed buffers for the next step.  Replaces one strided torch add
+// (AccumulateGrad) and one zero fill per conv weight (~80 of each per MoPoE-MRSSM train step).
+// table: `count` rows of 8 int64 = { packed*, grad*, O, I, taps, IPad, 0, 0 }.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void unpack_conv_grads_kernel(const long* __restrict__ table) {
+  const long* row = table + (long)blockIdx.y * 8;
+  float* packed = reinterpret_cast<float*>(row[0]);
+  float* grad = reinterpret_cast<float*>(row[1]);
+  const long O = row[2], I = row[3], taps = row[4], ipad = row[5];
+  const long total = O * taps * ipad;  // rows o >= O of the padded buffer are never written by the kernels
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long i = e % ipad, ot = e / ipad, tap = ot % taps, o = ot / taps;
+    const float v = packed[e];
+    if (v != 0.f) packed[e] = 0.f;
+    if (i < I) grad[(o * I + i) * taps + tap] += v;
+  }
+}
+
+int unpack_conv_grads_launch(const int64_t* table, int count, int blocks_per_entry, hipStream_t s) {
+  if (!table || count <= 0 || blocks_per_entry <= 0) { set_error("unpack_conv_grads: bad argument"); return MTRSSM_EINVAL; }
+  static_assert(sizeof(long) == sizeof(int64_t), "descriptor words are 64-bit");
+  set_last_kernel("mtrssm::unpack_conv_grads_kernel");
+  hipLaunchKernelGGL(unpack_conv_grads_kernel, dim3(blocks_per_entry, count), dim3(kThreads), 0, s, reinterpret_cast<const long*>(table));
+  return check_launch("unpack_conv_grads");
+}
+
+// ------------------------------------------------------------------------------------------------
 // Episode feed: one [B, T, E] input / target pair from the HBM-resident episode store.
 //   target[b, t, :] = store[idx[b], t, :]            (TakeFirstN: t < T <= Tfull, transform.py:31-52)
 //   input [b, t, :] = target + noise[b, t, :] * std  (GaussianNoise, transform.py:55-72: two roundings, mul then add)
