@@ -137,19 +137,22 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
-  Stage sa, sb;
-  load_tile<AR>(sa, g.A, g.lda, g.M, g.R, i0, s_lo * kStep, r_end, vec_a);
-  load_tile<BR>(sb, g.B, g.ldb, g.N, g.R, j0, s_lo * kStep, r_end, vec_b);
-  store_tile<AR>(sa, lds[0][0], g.act_a);
-  store_tile<BR>(sb, lds[0][1], g.act_b);
-  __syncthreads();
-  for (int s = s_lo; s < s_hi; ++s) {
-    const int cur = (s - s_lo) & 1;
-    const bool more = s + 1 < s_hi;
-    if (more) {
-      load_tile<AR>(sa, g.A, g.lda, g.M, g.R, i0, (s + 1) * kStep, r_end, vec_a);
-      load_tile<BR>(sb, g.B, g.ldb, g.N, g.R, j0, (s + 1) * kStep, r_end, vec_b);
+  // Software pipeline: the operand tiles of steps s+1 and s+2 are in flight in registers (two stages) while step s is
+  // multiplied out of LDS, so a global load has two whole steps to land; with one stage the ~1.5 us load latency, not the
+  // 0.43 us of MFMAs, set the step time on grids of < 1 workgroup per SIMD (measured: 13-16 TFLOP/s).
+  Stage sa[2], sb[2];
+  auto issue = [&](int which, int s) {
+    if (s < s_hi) {
+      load_tile<AR>(sa[which], g.A, g.lda, g.M, g.R, i0, s * kStep, r_end, vec_a);
+      load_tile<BR>(sb[which], g.B, g.ldb, g.N, g.R, j0, s * kStep, r_end, vec_b);
     }
+  };
+  auto step = [&](int which, int s, int cur) {  // `which`: the register stage that holds step s + 1
+    if (s + 1 < s_hi) {
+      store_tile<AR>(sa[which], lds[cur ^ 1][0], g.act_a);
+      store_tile<BR>(sb[which], lds[cur ^ 1][1], g.act_b);
+    }
+    issue(which, s + 3);
     const float* ia = lds[cur][0];
     const float* ib = lds[cur][1];
     const int ar = wr * 32 + (lane & 31), bc = wc * 32 + (lane & 31), kh = lane >> 5;
@@ -163,11 +166,17 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
 #pragma unroll 8
       for (int k = 0; k < kStep; ++k) csum += image_at<AR>(ia, tid, k);
     }
-    if (more) {
-      store_tile<AR>(sa, lds[cur ^ 1][0], g.act_a);
-      store_tile<BR>(sb, lds[cur ^ 1][1], g.act_b);
-    }
     __syncthreads();
+  };
+  issue(0, s_lo);
+  store_tile<AR>(sa[0], lds[0][0], g.act_a);
+  store_tile<BR>(sb[0], lds[0][1], g.act_b);
+  issue(0, s_lo + 1);
+  issue(1, s_lo + 2);
+  __syncthreads();
+  for (int s = s_lo; s < s_hi; s += 2) {
+    step(0, s, 0);
+    if (s + 1 < s_hi) step(1, s + 1, 1);
   }
 
   // epilogue: C/D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
@@ -207,10 +216,6 @@ int gemm_launch(const MtrssmGemm* p, hipStream_t stream) {
       set_error("gemm: unknown activation id %d", a);
       return MTRSSM_EINVAL;
     }
-  if ((p->act_out || p->zgrad) && p->split_r > 1) {
-    set_error("gemm: an output activation / act' epilogue cannot be combined with a split reduction");
-    return MTRSSM_EINVAL;
-  }
   GemmArgs g;
   g.A = p->A; g.B = p->B; g.C = p->C; g.bias = p->bias; g.zgrad = p->zgrad; g.colsum = p->colsum;
   g.M = p->M; g.N = p->N; g.R = p->R; g.lda = p->lda; g.ldb = p->ldb; g.ldc = p->ldc; g.ldz = p->ldz;
@@ -218,16 +223,28 @@ int gemm_launch(const MtrssmGemm* p, hipStream_t stream) {
   g.act_z = p->act_z; g.accumulate = p->accumulate;
   const int ti = (p->M + kTile - 1) / kTile, tj = (p->N + kTile - 1) / kTile;
   int splits = p->split_r;
-  if (splits <= 0) {  // automatic: enough workgroups for 256 CUs, at least 8 reduction steps each; only where the
-    splits = 1;       // target may be accumulated atomically (accumulate into a zeroed / running buffer)
-    if (p->accumulate && !p->act_out && !p->zgrad) {
-      const int steps = (p->R + kStep - 1) / kStep;
-      while (ti * tj * splits < 512 && steps / (splits * 2) >= 8) splits *= 2;
-    }
+  const int steps = (p->R + kStep - 1) / kStep;
+  const bool plain_epilogue = !p->act_out && !p->zgrad;
+  const bool dense_c = p->ldc == p->N;
+  if (splits <= 0) {
+    // Automatic: a workgroup's time is (its reduction steps) x (a load round trip), so a grid that does not fill the 256 CUs
+    // three deep is cut along the reduction, down to 4 steps per slice.  Slices meet by fp32 atomics: into the running
+    // target when accumulating; otherwise into C zeroed here first (dense C only).
+    splits = 1;
+    if (plain_epilogue && (p->accumulate || dense_c))
+      while (ti * tj * splits < 768 && steps / (splits * 2) >= 4) splits *= 2;
+  }
+  if (splits > 1 && !plain_epilogue) {
+    set_error("gemm: an output activation / act' epilogue cannot be combined with a split reduction");
+    return MTRSSM_EINVAL;
   }
   if (splits > 1 && !p->accumulate) {
-    set_error("gemm: a split reduction accumulates atomically: set accumulate and hand in a zeroed (or running) C");
-    return MTRSSM_EINVAL;
+    if (!dense_c) {
+      set_error("gemm: a split reduction into a strided C needs accumulate (C is zeroed by the caller)");
+      return MTRSSM_EINVAL;
+    }
+    hipError_t e = hipMemsetAsync(p->C, 0, (size_t)p->M * p->N * sizeof(float), stream);
+    if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return MTRSSM_ELAUNCH; }
   }
   g.splits = splits;
   const dim3 grid(tj, ti, splits);

@@ -363,7 +363,8 @@ def test_bench_model_full_batch_properties(name: str, lib_loaded: None) -> None:
         full = model.shared_step(batch, noise)
         halves = [model.shared_step(tuple(x[h] for x in batch), {k: v[h] for k, v in noise.items()}) for h in (slice(0, 32), slice(32, 64))]
     for k in full:
-        np.testing.assert_allclose(float(full[k]), 0.5 * (float(halves[0][k]) + float(halves[1][k])), rtol=2e-6, err_msg=k)
+        # equal up to the fp32 summation order of 13 M squared errors (atomics over workgroup partials): a few 1e-6
+        np.testing.assert_allclose(float(full[k]), 0.5 * (float(halves[0][k]) + float(halves[1][k])), rtol=1e-5, err_msg=k)
 
 
 # ---------------------------------------------------------------------------------------------
