@@ -268,6 +268,8 @@ def main() -> None:  # noqa: PLR0914, PLR0915
         raise SystemExit(msg)
     if args.share_device and args.backend != "gloo":
         raise SystemExit("--share-device needs --backend gloo")
+    if args.share_device:  # two processes on one GPU: the cluster scan's workgroups could not all be resident
+        os.environ["MTRSSM_SCAN_CLUSTER"] = "0"
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dev_index = 0 if args.share_device else local_rank
     torch.cuda.set_device(dev_index)
@@ -348,6 +350,7 @@ def main() -> None:  # noqa: PLR0914, PLR0915
     marks[args.steps].record()
     barrier()
     elapsed = time.perf_counter() - t0
+    scan.check_cluster_status()  # a cluster-scan exchange that timed out would have left invalid results
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     median_ms = step_ms[len(step_ms) // 2]
     # Kernel durations, right AFTER the timed region (HIP events around every launch cost the step ~3 %): 3 more steps

@@ -122,6 +122,36 @@ typedef struct MtrssmMrssmFwdIO {
 int mtrssm_mrssm_rollout_fwd(const MtrssmMrssmDims* dims, const MtrssmMrssmFwdWeights* w,
                              const MtrssmMrssmFwdIO* io, void* stream);
 
+/* The same forward scan with one batch row on a CLUSTER of four compute units (csrc/mrssm_cluster.hip): every workgroup
+ * keeps its quarter of the weights resident in registers / LDS for all T steps and the four exchange D/4 deter values and
+ * 3S logit partial sums per step through 8-byte {epoch, value} granules (no weight is re-streamed; 31 -> ~5 us per step at
+ * D = H = 200).  Posterior rollout only (post = 1).  The GRU input path is fused by the caller:
+ *   wf_t = w2_t . wih_t  ([H][3D] = (W_ih W2)^T),   bf = W_ih b2 + b_ih,
+ * so sv_h2 is NOT written (recompute h2 = W2 h1 + b2 as one batched GEMM where dW_ih needs it).
+ * workspace: caller-owned device memory of mtrssm_mrssm_cluster_workspace_bytes() bytes, 16-byte aligned; the call zeroes
+ * it.  Its first int32 is a status word: 0 after a good launch, else the code of a spin that gave up (results invalid).
+ * The grid is 4 x min(B, 64) workgroups that must be co-resident (one per CU): launch it on a GPU this process has to
+ * itself.  mtrssm_mrssm_cluster_supported() says whether the dims fit this regime (else use mtrssm_mrssm_rollout_fwd). */
+typedef struct MtrssmMrssmClusterWeights {
+  const float* w1s_t;  /* [S][H] */
+  const float* wf_t;   /* [H][3D]  (W_ih W2)^T */
+  const float* bf;     /* [3D]     W_ih b2 + b_ih */
+  const float* whh_t;  /* [D][3D] */
+  const float* bhh;    /* [3D] */
+  const float* wh1_t;  /* [D][3H] */
+  const float* b3;     /* [H] */
+  const float* w4;     /* [S][H] */
+  const float* b4;     /* [S] */
+  const float* wa2;    /* [S][H] */
+  const float* ba2;    /* [S] */
+  const float* wv2;    /* [S][H] */
+  const float* bv2;    /* [S] */
+} MtrssmMrssmClusterWeights;
+int mtrssm_mrssm_cluster_supported(const MtrssmMrssmDims* dims);
+int64_t mtrssm_mrssm_cluster_workspace_bytes(const MtrssmMrssmDims* dims);
+int mtrssm_mrssm_rollout_fwd_cluster(const MtrssmMrssmDims* dims, const MtrssmMrssmClusterWeights* weights, const MtrssmMrssmFwdIO* io,
+                                     void* workspace, int64_t workspace_bytes, void* stream);
+
 typedef struct MtrssmMrssmBwdWeights {
   const float* w1s_t; /* [S][H]  action_state_projector.0.weight[:, A:]^T (same buffer as the forward's) */
   const float* w2;   /* [H][H] */
@@ -461,8 +491,8 @@ int mtrssm_adamw_apply(float* param, const float* grad, float* exp_avg, float* e
  *   forward Y = act(X) W^T + b: A = X, B = W;  data gradient dX = (dY W) * act'(X): A = dY, B = W with b_rmajor;
  *   weight gradient dW += dY^T act(X), db += column sums of dY: A = dY, B = X, both r-major, accumulate, colsum = db.
  * bias, zgrad, colsum may be NULL.  split_r: 0 = choose (splits only when accumulate is set and no output epilogue), else
- * the number of reduction slices (> 1 accumulates with fp32 atomics and needs accumulate = 1).  Numerics: each output
- * element is a k-ordered fp32 fma chain (v_mfma_f32_32x32x2_f32).  Rows may be strided views (lda / ldb / ldc / ldz).
+ * the number of reduction slices (> 1 meets in C by fp32 atomics: accumulate = 1, or a dense C that the call zeroes
+ * first).  Numerics: each output element is a k-ordered fp32 fma chain per slice (v_mfma_f32_32x32x2_f32).  Rows may be strided views (lda / ldb / ldc / ldz).
  * ------------------------------------------------------------------------------------------ */
 typedef struct MtrssmGemm {
   const float* A;
@@ -473,6 +503,8 @@ typedef struct MtrssmGemm {
   float* colsum;
   int32_t M, N, R, lda, ldb, ldc, ldz;
   int32_t a_rmajor, b_rmajor, act_a, act_b, act_out, act_z, accumulate, split_r;
+  int32_t* tickets;   /* optional: >= n_tickets device ints (zeroed by the call).  Lets a reduction be split although the output */
+  int32_t n_tickets;  /* has an epilogue (act' of a data gradient): the last slice to arrive at a 64 x 64 tile finishes it */
 } MtrssmGemm;
 int mtrssm_gemm(const MtrssmGemm* g, void* stream);
 

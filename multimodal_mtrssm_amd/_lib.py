@@ -42,6 +42,8 @@ MrssmFwdIO = _struct("MtrssmMrssmFwdIO", _ptrs(
     "xa", "pa", "pv", "deter0", "stoch0", "u_post", "u_prior",
     "deter", "prior_logits", "prior_stoch", "post_logits", "post_stoch", "kl",
     "sv_h1", "sv_h2", "sv_gates", "sv_heads", "sv_la", "sv_lv"))
+MrssmClusterWeights = _struct("MtrssmMrssmClusterWeights", _ptrs(
+    "w1s_t", "wf_t", "bf", "whh_t", "bhh", "wh1_t", "b3", "w4", "b4", "wa2", "ba2", "wv2", "bv2"))
 MrssmBwdWeights = _struct("MtrssmMrssmBwdWeights", _ptrs("w1s_t", "w2", "wih", "whh", "wh1", "w4", "wa2", "wv2"))
 MrssmBwdIO = _struct("MtrssmMrssmBwdIO", _ptrs(
     "deter0", "deter", "prior_logits", "post_logits", "sv_h1", "sv_h2", "sv_gates", "sv_heads", "sv_la", "sv_lv",
@@ -77,7 +79,8 @@ ConvGeom = _struct("MtrssmConvGeom", [(n, _i) for n in (
     "Cout", "CoutPad", "pre_act", "act", "mfma_split")])
 
 Gemm = _struct("MtrssmGemm", _ptrs("A", "B", "C", "bias", "zgrad", "colsum") + [(n, _i) for n in (
-    "M", "N", "R", "lda", "ldb", "ldc", "ldz", "a_rmajor", "b_rmajor", "act_a", "act_b", "act_out", "act_z", "accumulate", "split_r")])
+    "M", "N", "R", "lda", "ldb", "ldc", "ldz", "a_rmajor", "b_rmajor", "act_a", "act_b", "act_out", "act_z", "accumulate", "split_r")]
+    + [("tickets", _p), ("n_tickets", _i)])
 
 # every symbol include/mtrssm.h declares (tests/test_capi.py checks the header against this list)
 SYMBOLS: dict[str, tuple[type | None, list[type]]] = {
@@ -85,6 +88,9 @@ SYMBOLS: dict[str, tuple[type | None, list[type]]] = {
     "mtrssm_last_error": (C.c_char_p, []),
     "mtrssm_last_kernel": (C.c_char_p, []),
     "mtrssm_mrssm_rollout_fwd": (C.c_int, [C.POINTER(MrssmDims), C.POINTER(MrssmFwdWeights), C.POINTER(MrssmFwdIO), _p]),
+    "mtrssm_mrssm_cluster_supported": (C.c_int, [C.POINTER(MrssmDims)]),
+    "mtrssm_mrssm_cluster_workspace_bytes": (C.c_int64, [C.POINTER(MrssmDims)]),
+    "mtrssm_mrssm_rollout_fwd_cluster": (C.c_int, [C.POINTER(MrssmDims), C.POINTER(MrssmClusterWeights), C.POINTER(MrssmFwdIO), _p, C.c_int64, _p]),
     "mtrssm_mrssm_rollout_bwd": (C.c_int, [C.POINTER(MrssmDims), C.POINTER(MrssmBwdWeights), C.POINTER(MrssmBwdIO), _p]),
     "mtrssm_mmtrssm_rollout_fwd": (C.c_int, [C.POINTER(MmtrssmDims), C.POINTER(MmtrssmFwdWeights), C.POINTER(MmtrssmFwdIO), _p]),
     "mtrssm_mmtrssm_rollout_bwd": (C.c_int, [C.POINTER(MmtrssmDims), C.POINTER(MmtrssmBwdWeights), C.POINTER(MmtrssmBwdIO), _p]),

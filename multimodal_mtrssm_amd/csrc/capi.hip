@@ -37,6 +37,9 @@ int nll_bwd_launch(const float*, const float*, const float*, int64_t, int64_t, i
 int sumsq_launch(const float*, int64_t, float*, hipStream_t);
 int adamw_launch(float*, const float*, float*, float*, int64_t, const float*, float, float, float, float, float, float, float, int, hipStream_t);
 int gemm_launch(const MtrssmGemm*, hipStream_t);
+int mrssm_cluster_supported(const MtrssmMrssmDims*);
+size_t mrssm_cluster_workspace_bytes(const MtrssmMrssmDims*);
+int mrssm_fwd_cluster_launch(const MtrssmMrssmDims*, const MtrssmMrssmClusterWeights*, const MtrssmMrssmFwdIO*, void*, size_t, hipStream_t);
 int unpack_conv_grads_launch(const int64_t*, int, int, hipStream_t);
 int adamw_prepare_launch(const float*, int64_t, float*, float*, float, float, hipStream_t);
 int adamw_apply_launch(float*, const float*, float*, float*, const unsigned char*, int64_t, const float*, const float*, float, float, float, float,
@@ -81,6 +84,12 @@ MTRSSM_API int mtrssm_adamw_step(float* param, const float* grad, float* exp_avg
 }
 MTRSSM_API int mtrssm_unpack_conv_grads(const int64_t* table, int32_t count, int32_t blocks_per_entry, void* stream) {
   return unpack_conv_grads_launch(table, count, blocks_per_entry, static_cast<hipStream_t>(stream));
+}
+MTRSSM_API int mtrssm_mrssm_cluster_supported(const MtrssmMrssmDims* d) { return mrssm_cluster_supported(d); }
+MTRSSM_API int64_t mtrssm_mrssm_cluster_workspace_bytes(const MtrssmMrssmDims* d) { return (int64_t)mrssm_cluster_workspace_bytes(d); }
+MTRSSM_API int mtrssm_mrssm_rollout_fwd_cluster(const MtrssmMrssmDims* d, const MtrssmMrssmClusterWeights* w, const MtrssmMrssmFwdIO* io,
+                                                void* workspace, int64_t workspace_bytes, void* stream) {
+  return mrssm_fwd_cluster_launch(d, w, io, workspace, workspace_bytes < 0 ? 0 : (size_t)workspace_bytes, static_cast<hipStream_t>(stream));
 }
 MTRSSM_API int mtrssm_gemm(const MtrssmGemm* g, void* stream) { return gemm_launch(g, static_cast<hipStream_t>(stream)); }
 MTRSSM_API int mtrssm_adamw_prepare(const float* grad, int64_t n, float* sumsq, float* state, float beta1, float beta2, void* stream) {

@@ -42,66 +42,84 @@ struct GemmArgs {
   int act_z;              // activation whose derivative multiplies the output (with zgrad)
   int accumulate;         // C += instead of C =
   int splits;             // reduction split over gridDim.z (atomic accumulation when > 1)
+  int* tickets;           // per output tile: arrivals of the reduction slices (only for a split reduction WITH an epilogue)
 };
 
-__device__ __forceinline__ float act_grad_from_in(float z, int act) {
-  switch (act) {
-    case MTRSSM_ACT_RELU: return z > 0.f ? 1.f : 0.f;
-    case MTRSSM_ACT_ELU: return z > 0.f ? 1.f : expf(z);
-    case MTRSSM_ACT_TANH: { const float t = tanhf(z); return 1.f - t * t; }
-    default: return 1.f;
+// Branch-free activations for the staging path (uniform scalar branch on `act`, no libm call per element: an inlined
+// expm1f / tanhf per staged element cost more VALU time than the MFMAs it feeds).  ELU: v_exp_f32 - 1 on the negative side
+// (absolute error < 1.2e-7, as in the conv kernels); Tanh: 1 - 2 / (exp(2x) + 1) (absolute error ~1e-7, saturates cleanly).
+__device__ __forceinline__ float4 act4(float4 q, int act) {
+  if (act == MTRSSM_ACT_ELU) {
+    q.x = q.x > 0.f ? q.x : __expf(q.x) - 1.f; q.y = q.y > 0.f ? q.y : __expf(q.y) - 1.f;
+    q.z = q.z > 0.f ? q.z : __expf(q.z) - 1.f; q.w = q.w > 0.f ? q.w : __expf(q.w) - 1.f;
+  } else if (act == MTRSSM_ACT_RELU) {
+    q.x = fmaxf(q.x, 0.f); q.y = fmaxf(q.y, 0.f); q.z = fmaxf(q.z, 0.f); q.w = fmaxf(q.w, 0.f);
+  } else if (act == MTRSSM_ACT_TANH) {
+    q.x = 1.f - 2.f / (__expf(2.f * q.x) + 1.f); q.y = 1.f - 2.f / (__expf(2.f * q.y) + 1.f);
+    q.z = 1.f - 2.f / (__expf(2.f * q.z) + 1.f); q.w = 1.f - 2.f / (__expf(2.f * q.w) + 1.f);
   }
+  return q;
+}
+__device__ __forceinline__ float act_grad_from_in(float z, int act) {
+  if (act == MTRSSM_ACT_ELU) return z > 0.f ? 1.f : __expf(z);
+  if (act == MTRSSM_ACT_RELU) return z > 0.f ? 1.f : 0.f;
+  if (act == MTRSSM_ACT_TANH) { const float t = 1.f - 2.f / (__expf(2.f * z) + 1.f); return 1.f - t * t; }
+  return 1.f;
 }
 
-// one operand tile (64 rows x 32 r) from global memory into registers: 2 x float4 per thread
+// one operand tile (64 rows x 32 r) from global memory into registers: 2 x float4 per thread.  Loads are branch-free per
+// lane -- clamped addresses, masked afterwards: a load inside a divergent branch is waited for at the join, which serialises
+// the prefetch (the first version of this kernel ran at 13-20 TFLOP/s for that reason).
 struct Stage { float4 v[2]; };
 
-template <bool RMAJOR>
-__device__ __forceinline__ void load_tile(Stage& st, const float* __restrict__ P, int ld, int rows, int R, int row0, int r0,
-                                          int r_end, bool vec) {
-  const int tid = threadIdx.x;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int f = tid + 256 * j;
-    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (RMAJOR) {  // memory [r][row]: 16 float4 per r line of 64 rows
-      const int r = r0 + (f >> 4), row = row0 + 4 * (f & 15);
-      if (r < r_end) {
-        const float* p = P + (size_t)r * ld + row;
-        if (vec && row + 3 < rows) q = *reinterpret_cast<const float4*>(p);
-        else {
-          if (row < rows) q.x = p[0];
-          if (row + 1 < rows) q.y = p[1];
-          if (row + 2 < rows) q.z = p[2];
-          if (row + 3 < rows) q.w = p[3];
-        }
-      }
-    } else {  // memory [row][r]: 8 float4 per row of 32 r
-      const int row = row0 + (f >> 3), r = r0 + 4 * (f & 7);
-      if (row < rows) {
-        const float* p = P + (size_t)row * ld + r;
-        if (vec && r + 3 < r_end) q = *reinterpret_cast<const float4*>(p);
-        else {
-          if (r < r_end) q.x = p[0];
-          if (r + 1 < r_end) q.y = p[1];
-          if (r + 2 < r_end) q.z = p[2];
-          if (r + 3 < r_end) q.w = p[3];
-        }
-      }
-    }
-    st.v[j] = q;
+// y: index along the strided axis (limit ylim), x: first of 4 consecutive indices along the contiguous axis (limit xlim).
+// Returns the RAW quad from clamped addresses; mask_quad() zeroes the out-of-range lanes later, when the tile goes to LDS
+// (a select right behind the load would make the compiler wait for the load on the spot).
+__device__ __forceinline__ float4 load_quad(const float* __restrict__ P, int ld, int y, int ylim, int x, int xlim, bool vec) {
+  const int yc = y < ylim ? y : ylim - 1;
+  const float* row = P + (size_t)yc * ld;
+  float4 q;
+  if (vec) {  // uniform: rows are 16-byte aligned and ld % 4 == 0, so any quad that starts below ld lies inside the row
+    const int xc = x <= ld - 4 ? x : ld - 4;  // xc != x only for x >= ld >= xlim: fully masked
+    q = *reinterpret_cast<const float4*>(row + xc);
+  } else {
+    const int last = xlim - 1;
+    q.x = row[x < last ? x : last];
+    q.y = row[x + 1 < last ? x + 1 : last];
+    q.z = row[x + 2 < last ? x + 2 : last];
+    q.w = row[x + 3 < last ? x + 3 : last];
   }
-  (void)R;
+  return q;
+}
+__device__ __forceinline__ float4 mask_quad(float4 q, int y, int ylim, int x, int xlim) {
+  const bool oky = y < ylim;
+  q.x = (oky && x < xlim) ? q.x : 0.f;
+  q.y = (oky && x + 1 < xlim) ? q.y : 0.f;
+  q.z = (oky && x + 2 < xlim) ? q.z : 0.f;
+  q.w = (oky && x + 3 < xlim) ? q.w : 0.f;
+  return q;
 }
 
 template <bool RMAJOR>
-__device__ __forceinline__ void store_tile(const Stage& st, float* img, int act) {
+__device__ __forceinline__ void load_tile(Stage& st, const float* __restrict__ P, int ld, int rows, int row0, int r0, int r_end, bool vec) {
   const int tid = threadIdx.x;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int f = tid + 256 * j;
-    float4 q = st.v[j];
-    if (act) { q.x = act_fwd(q.x, act); q.y = act_fwd(q.y, act); q.z = act_fwd(q.z, act); q.w = act_fwd(q.w, act); }
+    if (RMAJOR) st.v[j] = load_quad(P, ld, r0 + (f >> 4), r_end, row0 + 4 * (f & 15), rows, vec);  // memory [r][row]
+    else st.v[j] = load_quad(P, ld, row0 + (f >> 3), rows, r0 + 4 * (f & 7), r_end, vec);          // memory [row][r]
+  }
+}
+
+template <bool RMAJOR>
+__device__ __forceinline__ void store_tile(const Stage& st, float* img, int act, int rows, int row0, int r0, int r_end) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int f = tid + 256 * j;
+    float4 q = RMAJOR ? mask_quad(st.v[j], r0 + (f >> 4), r_end, row0 + 4 * (f & 15), rows)
+                      : mask_quad(st.v[j], row0 + (f >> 3), rows, r0 + 4 * (f & 7), r_end);
+    q = act4(q, act);  // act(0) = 0 for every supported activation
     if (RMAJOR) {
       *reinterpret_cast<float4*>(img + (f >> 4) * kLdT + 4 * (f & 15)) = q;
     } else {
@@ -143,25 +161,29 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
   Stage sa[2], sb[2];
   auto issue = [&](int which, int s) {
     if (s < s_hi) {
-      load_tile<AR>(sa[which], g.A, g.lda, g.M, g.R, i0, s * kStep, r_end, vec_a);
-      load_tile<BR>(sb[which], g.B, g.ldb, g.N, g.R, j0, s * kStep, r_end, vec_b);
+      load_tile<AR>(sa[which], g.A, g.lda, g.M, i0, s * kStep, r_end, vec_a);
+      load_tile<BR>(sb[which], g.B, g.ldb, g.N, j0, s * kStep, r_end, vec_b);
     }
   };
+  auto to_lds = [&](int which, int s, int buf) {
+    store_tile<AR>(sa[which], lds[buf][0], g.act_a, g.M, i0, s * kStep, r_end);
+    store_tile<BR>(sb[which], lds[buf][1], g.act_b, g.N, j0, s * kStep, r_end);
+  };
+  const int ar = wr * 32 + (lane & 31), bc = wc * 32 + (lane & 31), kh = lane >> 5;
   auto step = [&](int which, int s, int cur) {  // `which`: the register stage that holds step s + 1
-    if (s + 1 < s_hi) {
-      store_tile<AR>(sa[which], lds[cur ^ 1][0], g.act_a);
-      store_tile<BR>(sb[which], lds[cur ^ 1][1], g.act_b);
-    }
+    if (s + 1 < s_hi) to_lds(which, s + 1, cur ^ 1);
     issue(which, s + 3);
     const float* ia = lds[cur][0];
     const float* ib = lds[cur][1];
-    const int ar = wr * 32 + (lane & 31), bc = wc * 32 + (lane & 31), kh = lane >> 5;
+    float av[kStep / 2], bv[kStep / 2];  // all operand values of the step first: the LDS reads pipeline under the MFMAs
 #pragma unroll
-    for (int k = 0; k < kStep; k += 2) {
-      const float a = image_at<AR>(ia, ar, k + kh);
-      const float b = image_at<BR>(ib, bc, k + kh);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    for (int k = 0; k < kStep / 2; ++k) {
+      av[k] = image_at<AR>(ia, ar, 2 * k + kh);
+      bv[k] = image_at<BR>(ib, bc, 2 * k + kh);
     }
+    __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the MFMA chain (the scheduler re-sinks them pair by pair otherwise)
+#pragma unroll
+    for (int k = 0; k < kStep / 2; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[k], bv[k], acc, 0, 0, 0);
     if (want_colsum && tid < kTile) {
 #pragma unroll 8
       for (int k = 0; k < kStep; ++k) csum += image_at<AR>(ia, tid, k);
@@ -169,8 +191,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
     __syncthreads();
   };
   issue(0, s_lo);
-  store_tile<AR>(sa[0], lds[0][0], g.act_a);
-  store_tile<BR>(sb[0], lds[0][1], g.act_b);
+  to_lds(0, s_lo, 0);
   issue(0, s_lo + 1);
   issue(1, s_lo + 2);
   __syncthreads();
@@ -179,23 +200,70 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
     if (s + 1 < s_hi) step(1, s + 1, 1);
   }
 
-  // epilogue: C/D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+  // epilogue: C/D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+  // All loads first (clamped, branch-free), then the arithmetic, then the stores.
   const int j = j0 + wc * 32 + (lane & 31);
-  const float bias = (g.bias && j < g.N) ? g.bias[j] : 0.f;
+  const bool okj = j < g.N;
+  const int jc = okj ? j : g.N - 1;
   const bool atomic = g.splits > 1;
+  const int ibase = i0 + wr * 32 + 4 * (lane >> 5);
+  // A split reduction whose output needs an epilogue (bias / act' of the data gradient): the slices add their raw sums
+  // atomically into the zeroed C, take a ticket per tile, and the LAST slice to arrive reads the finished sums back
+  // (sc1 loads: the atomics were performed memory-side), applies the epilogue and stores.  Without an epilogue the atomics
+  // are the result (bias by slice 0).
+  const bool finalize = atomic && g.tickets != nullptr;
+  if (atomic) {
+    const float bias0 = (g.bias && !finalize && blockIdx.z == 0) ? g.bias[jc] : 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int i = ibase + (reg & 3) + 8 * (reg >> 2);
+      if (i < g.M && okj) atomicAdd(g.C + (size_t)i * g.ldc + j, acc[reg] + bias0);
+    }
+    if (!finalize) {
+      if (want_colsum && tid < kTile && i0 + tid < g.M) atomicAdd(g.colsum + i0 + tid, csum);
+      return;
+    }
+    __shared__ int last_flag;
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) last_flag = atomicAdd(g.tickets + blockIdx.y * gridDim.x + blockIdx.x, 1) == g.splits - 1;
+    __syncthreads();
+    if (!last_flag) {
+      if (want_colsum && tid < kTile && i0 + tid < g.M) atomicAdd(g.colsum + i0 + tid, csum);
+      return;
+    }
+    __threadfence();
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int i = ibase + (reg & 3) + 8 * (reg >> 2);
+      acc[reg] = __hip_atomic_load(g.C + (size_t)(i < g.M ? i : g.M - 1) * g.ldc + jc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  const float bias = g.bias ? g.bias[jc] : 0.f;
+  float zv[16];
+  if (g.zgrad) {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int i = ibase + (reg & 3) + 8 * (reg >> 2);
+      zv[reg] = g.zgrad[(size_t)(i < g.M ? i : g.M - 1) * g.ldz + jc];
+    }
+  }
+  float cv[16];
+  if (g.accumulate && !atomic) {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int i = ibase + (reg & 3) + 8 * (reg >> 2);
+      cv[reg] = g.C[(size_t)(i < g.M ? i : g.M - 1) * g.ldc + jc];
+    }
+  }
 #pragma unroll
   for (int reg = 0; reg < 16; ++reg) {
-    const int i = i0 + wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-    if (i < g.M && j < g.N) {
-      float v = acc[reg];
-      if (!atomic || blockIdx.z == 0) v += bias;
-      if (g.act_out) v = act_fwd(v, g.act_out);
-      if (g.zgrad) v *= act_grad_from_in(g.zgrad[(size_t)i * g.ldz + j], g.act_z);
-      float* c = g.C + (size_t)i * g.ldc + j;
-      if (atomic) atomicAdd(c, v);
-      else if (g.accumulate) *c += v;
-      else *c = v;
-    }
+    const int i = ibase + (reg & 3) + 8 * (reg >> 2);
+    float v = acc[reg] + bias;
+    if (g.act_out) v = act_fwd(v, g.act_out);
+    if (g.zgrad) v *= act_grad_from_in(zv[reg], g.act_z);
+    if (g.accumulate && !atomic) v += cv[reg];
+    if (i < g.M && okj) g.C[(size_t)i * g.ldc + j] = v;
   }
   if (want_colsum && tid < kTile && i0 + tid < g.M) atomicAdd(g.colsum + i0 + tid, csum);
 }
@@ -226,17 +294,23 @@ int gemm_launch(const MtrssmGemm* p, hipStream_t stream) {
   const int steps = (p->R + kStep - 1) / kStep;
   const bool plain_epilogue = !p->act_out && !p->zgrad;
   const bool dense_c = p->ldc == p->N;
+  const bool can_finalize = p->tickets && p->n_tickets >= ti * tj && !p->accumulate && dense_c;
   if (splits <= 0) {
     // Automatic: a workgroup's time is (its reduction steps) x (a load round trip), so a grid that does not fill the 256 CUs
     // three deep is cut along the reduction, down to 4 steps per slice.  Slices meet by fp32 atomics: into the running
-    // target when accumulating; otherwise into C zeroed here first (dense C only).
+    // target when accumulating; otherwise into C zeroed here first (dense C only); an output epilogue (act' of a data
+    // gradient) then needs the ticket words for its last-arriver pass.
     splits = 1;
-    if (plain_epilogue && (p->accumulate || dense_c))
+    if ((plain_epilogue && (p->accumulate || dense_c)) || (!plain_epilogue && can_finalize))
       while (ti * tj * splits < 768 && steps / (splits * 2) >= 4) splits *= 2;
   }
+  bool finalize = false;
   if (splits > 1 && !plain_epilogue) {
-    set_error("gemm: an output activation / act' epilogue cannot be combined with a split reduction");
-    return MTRSSM_EINVAL;
+    if (!can_finalize) {
+      set_error("gemm: a split reduction with an output epilogue needs ticket words (>= one per 64x64 tile), a dense C and no accumulate");
+      return MTRSSM_EINVAL;
+    }
+    finalize = true;
   }
   if (splits > 1 && !p->accumulate) {
     if (!dense_c) {
@@ -245,7 +319,12 @@ int gemm_launch(const MtrssmGemm* p, hipStream_t stream) {
     }
     hipError_t e = hipMemsetAsync(p->C, 0, (size_t)p->M * p->N * sizeof(float), stream);
     if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return MTRSSM_ELAUNCH; }
+    if (finalize) {
+      e = hipMemsetAsync(p->tickets, 0, (size_t)ti * tj * sizeof(int), stream);
+      if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return MTRSSM_ELAUNCH; }
+    }
   }
+  g.tickets = finalize ? p->tickets : nullptr;
   g.splits = splits;
   const dim3 grid(tj, ti, splits);
   if (p->a_rmajor && p->b_rmajor) {

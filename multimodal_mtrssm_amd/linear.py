@@ -64,6 +64,10 @@ def grad_target(t: Tensor) -> Tensor | None:
 # ------------------------------------------------------------------------------------------------
 # the kernel call
 # ------------------------------------------------------------------------------------------------
+_TICKETS: dict = {}
+_N_TICKETS = 8192
+
+
 def _ld(t: Tensor) -> int:
     if t.dim() != 2 or t.stride(1) != 1 or t.dtype != torch.float32 or not t.is_cuda:  # noqa: PLR2004
         msg = f"mtrssm_gemm operands are fp32 GPU matrices with unit column stride, got shape {tuple(t.shape)} stride {t.stride()} {t.dtype} {t.device}"
@@ -92,6 +96,11 @@ def gemm(a: Tensor, b: Tensor, c: Tensor, *, a_rmajor: bool, b_rmajor: bool, bia
     g.a_rmajor, g.b_rmajor = int(a_rmajor), int(b_rmajor)
     g.act_a, g.act_b, g.act_out, g.act_z = int(act_a), int(act_b), 0, int(act_z)
     g.accumulate, g.split_r = int(accumulate), int(split_r)
+    if zgrad is not None and not accumulate:  # a skinny data gradient may split its long reduction: last-arriver epilogue
+        tk = _TICKETS.get(a.device)
+        if tk is None:
+            tk = _TICKETS[a.device] = torch.zeros(_N_TICKETS, device=a.device, dtype=torch.int32)
+        g.tickets, g.n_tickets = tk.data_ptr(), _N_TICKETS
     for t in (bias, colsum):
         if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
             msg = "gemm: bias / colsum must be contiguous fp32 vectors"

@@ -44,6 +44,24 @@ class ScanConfig:
 
 KERNEL_TIMERS = _lib.TIMERS
 
+# The posterior rollout of square, mid-sized models (D = H in {32, 64, 128, 200}: BASELINE configs[1]) runs one batch row on a
+# CLUSTER of four CUs with all weights resident (csrc/mrssm_cluster.hip) instead of one CU streaming them from L2 every
+# step.  Its workgroups wait for each other, so they must be co-resident: a GPU shared with another process must switch it
+# off (MTRSSM_SCAN_CLUSTER=0).  Each launch leaves a status word (0 = fine) in its workspace: `check_cluster_status()`.
+import os as _os  # noqa: E402
+
+CLUSTER_SCAN = _os.environ.get("MTRSSM_SCAN_CLUSTER", "1") != "0"
+_CLUSTER_WS: dict[tuple, Tensor] = {}
+
+
+def check_cluster_status() -> None:
+    """Synchronises and raises if a cluster-scan launch gave up on an exchange (its outputs are then invalid)."""
+    for key, ws in _CLUSTER_WS.items():
+        code = int(ws[:1].view(torch.int32)[0].item()) if ws.dtype == torch.int64 else 0
+        if code:
+            msg = f"cluster scan {key}: an exchange timed out (status {code}); the GPU was probably shared -- set MTRSSM_SCAN_CLUSTER=0"
+            raise _lib.MtrssmLibraryError(msg)
+
 
 def _c(t: Tensor) -> Tensor:
     return t.contiguous()
@@ -158,9 +176,29 @@ class _MrssmScan(torch.autograd.Function):
         # S-wide rows, kl and (training) the saved activations; FLOPs = 2 x every weight element touched per row-step
         per_bt = 3 * H + 2 * K + D + 3 * S + 1 + (2 * H + 4 * D + 3 * H + 2 * S if need_grad else 0)
         macs = S * H + H * H + 3 * D * H + 3 * D * D + 3 * H * D + 3 * S * H
-        _lib.check(_lib.TIMERS.call("mtrssm_mrssm_rollout_fwd", lib.mtrssm_mrssm_rollout_fwd, C.byref(dims), C.byref(fw), C.byref(io),
-                                     _lib.stream_ptr(xa.device), flops=2.0 * B * T * macs, nbytes=4.0 * B * T * per_bt),
-                   "mtrssm_mrssm_rollout_fwd")
+        cluster = (CLUSTER_SCAN and cfg.rows_per_block == 0 and cfg.threads == 0 and bool(lib.mtrssm_mrssm_cluster_supported(C.byref(dims))))
+        if cluster:
+            # fused GRU input path: gi = (W_ih W2) h1 + (W_ih b2 + b_ih); two small GEMMs per launch (weights change every step)
+            wf_t = _new(xa, H, 3 * D)
+            gemm(w2, wih, wf_t, a_rmajor=True, b_rmajor=False)            # wf_t[k][j] = sum_h W2[h][k] W_ih[j][h]
+            bf = _new(xa, 1, 3 * D)
+            gemm(b2.reshape(1, H), wih, bf, a_rmajor=False, b_rmajor=False, bias=_c(bih))
+            cw = _lib.fill(_lib.MrssmClusterWeights(), w1s_t=w1s_t, wf_t=wf_t, bf=bf.reshape(-1), whh_t=fw._refs["whh_t"], bhh=_c(bhh),  # noqa: SLF001
+                           wh1_t=fw._refs["wh1_t"], b3=_c(b3), w4=_c(w4), b4=_c(b4), wa2=_c(wa2), ba2=_c(ba2), wv2=_c(wv2), bv2=_c(bv2))  # noqa: SLF001
+            nbytes_ws = int(lib.mtrssm_mrssm_cluster_workspace_bytes(C.byref(dims)))
+            key = (xa.device, _lib.stream_ptr(xa.device), B, D, S)
+            ws = _CLUSTER_WS.get(key)
+            if ws is None or ws.numel() * 8 < nbytes_ws:
+                ws = _CLUSTER_WS[key] = torch.zeros((nbytes_ws + 7) // 8, device=xa.device, dtype=torch.int64)
+            io.sv_h2 = None  # not produced on this path: recomputed in the backward where dW_ih needs it
+            _lib.check(_lib.TIMERS.call("mtrssm_mrssm_rollout_fwd_cluster", lib.mtrssm_mrssm_rollout_fwd_cluster, C.byref(dims), C.byref(cw),
+                                        C.byref(io), _lib.raw_ptr(ws), ws.numel() * 8, _lib.stream_ptr(xa.device),
+                                        flops=2.0 * B * T * macs, nbytes=4.0 * B * T * per_bt), "mtrssm_mrssm_rollout_fwd_cluster")
+            sv["sv_h2"] = None
+        else:
+            _lib.check(_lib.TIMERS.call("mtrssm_mrssm_rollout_fwd", lib.mtrssm_mrssm_rollout_fwd, C.byref(dims), C.byref(fw), C.byref(io),
+                                        _lib.stream_ptr(xa.device), flops=2.0 * B * T * macs, nbytes=4.0 * B * T * per_bt),
+                       "mtrssm_mrssm_rollout_fwd")
         if need_grad:
             ctx.cfg, ctx.A = cfg, A
             ctx.biases, ctx.w3 = (b2, bih, bhh, b3, b4, ba2, bv2), w3
@@ -212,8 +250,11 @@ class _MrssmScan(torch.autograd.Function):
         prev_deter = _flat2(torch.cat([deter0.unsqueeze(1), deter[:, :-1]], dim=1))
         fz1, fh2, fgi, fgh, fzh = map(_flat2, (d_z1, d_h2, d_gi, d_gh, d_zh))
         flp, fla, flv = map(_flat2, (d_lp, d_la, d_lv))
-        fdet, fh1, fsh2, fheads = map(_flat2, (deter, sv_h1, sv_h2, sv_heads))
         (b2, bih, bhh, b3, b4, ba2, bv2) = ctx.biases
+        if sv_h2 is None:  # cluster forward (fused GRU input path): h2 = W2 h1 + b2 for all (b, t) at once
+            sv_h2 = _new(deter, B, T, H)
+            gemm(_flat2(sv_h1), w2, _flat2(sv_h2), a_rmajor=False, b_rmajor=False, bias=_c(b2))
+        fdet, fh1, fsh2, fheads = map(_flat2, (deter, sv_h1, sv_h2, sv_heads))
         wg = _WeightGrads()
         wg.add(fz1, prev_stoch, w1, cols=slice(A, None))
         wg.add(fh2, fh1, w2, bias=b2)

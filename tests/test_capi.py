@@ -18,7 +18,7 @@ HEADER = (ROOT / "include" / "mtrssm.h").read_text()
 
 
 def declared_functions() -> list[str]:
-    names = re.findall(r"^\s*(?:int|const char\*)\s+(mtrssm_\w+)\s*\(", HEADER, flags=re.MULTILINE)
+    names = re.findall(r"^\s*(?:int|int64_t|const char\*)\s+(mtrssm_\w+)\s*\(", HEADER, flags=re.MULTILINE)
     assert len(names) >= 10
     return names
 
@@ -49,7 +49,7 @@ def _struct_fields(name: str) -> list[str]:
 
 
 @pytest.mark.parametrize("cls", [
-    _lib.MrssmDims, _lib.MrssmFwdWeights, _lib.MrssmFwdIO, _lib.MrssmBwdWeights, _lib.MrssmBwdIO,
+    _lib.MrssmDims, _lib.MrssmFwdWeights, _lib.MrssmClusterWeights, _lib.MrssmFwdIO, _lib.MrssmBwdWeights, _lib.MrssmBwdIO,
     _lib.MmtrssmDims, _lib.MmtrssmFwdWeights, _lib.MmtrssmFwdIO, _lib.MmtrssmBwdWeights, _lib.MmtrssmBwdIO,
 ])
 def test_ctypes_structs_mirror_the_header(cls: type) -> None:

@@ -202,6 +202,48 @@ def test_large_dims_match_oracle(name: str, lib_loaded: None) -> None:
 
 
 # ---------------------------------------------------------------------------------------------
+# cluster scan (one row on four CUs, weights resident) against the single-CU scan
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize(("name", "batch", "steps"), [("mrssm_default", 5, 9), ("mrssm_cfg2dims", 70, 6), ("mrssm_bench", 3, 50)])
+def test_cluster_scan_matches_single_cu_scan(name: str, batch: int, steps: int, lib_loaded: None) -> None:
+    """csrc/mrssm_cluster.hip (default for D = H in {32, 64, 128, 200}) vs csrc/mrssm_scan.hip on the same inputs: same samples,
+    deter / logits to 2e-6 (the fused W_ih W2 product rounds differently), same losses to 1e-6, gradients to 1e-5 of the
+    tensor's max; more rows than clusters (70 > 64: a cluster walks two rows) and ragged cluster groups (5, 3 rows)."""
+    from multimodal_mtrssm_amd import scan
+
+    case = with_sizes(CASES[name], batch, steps)
+    oracle = build_model(case)
+    batch_t = tuple(b.to(DEV) for b in build_batch(case))
+    noise = _to(build_noise(case), DEV)
+    runs = {}
+    for cluster in (False, True):
+        scan.CLUSTER_SCAN = cluster
+        try:
+            model = product_from_case(case, oracle, DEV)
+            with torch.no_grad():
+                state0 = model.initial_state((batch_t[1][:, 0], batch_t[2][:, 0]), noise)
+                post, prior = model.rollout_representation(actions=batch_t[0], observations=(batch_t[1], batch_t[2]), prev_state=state0,
+                                                           noise=noise)
+            out = model.shared_step(batch_t, noise)
+            out["loss"].backward()
+            scan.check_cluster_status()
+            runs[cluster] = (post, prior, {k: float(v) for k, v in out.items()},
+                             {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+        finally:
+            scan.CLUSTER_SCAN = True
+    (p0, q0, l0, g0), (p1, q1, l1, g1) = runs[False], runs[True]
+    assert torch.equal(p0.stoch, p1.stoch) and torch.equal(q0.stoch, q1.stoch)
+    np.testing.assert_allclose(_np(p1.deter), _np(p0.deter), atol=2e-6)
+    np.testing.assert_allclose(_np(p1.distribution.probs), _np(p0.distribution.probs), atol=2e-6)
+    np.testing.assert_allclose(_np(q1.distribution.probs), _np(q0.distribution.probs), atol=2e-6)
+    np.testing.assert_allclose(_np(p1.kl_per_step), _np(p0.kl_per_step), rtol=1e-4, atol=1e-6)
+    for k in l0:
+        np.testing.assert_allclose(l1[k], l0[k], rtol=2e-6, err_msg=k)
+    for k, g in g0.items():
+        np.testing.assert_allclose(_np(g1[k]), _np(g), rtol=1e-4, atol=1e-5 * (float(g.abs().max()) + 1e-9), err_msg=k)
+
+
+# ---------------------------------------------------------------------------------------------
 # row-tile variants and ragged batches: every tiling gives the same answer
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name", ["mrssm_nonsquare", "mmtrssm_default"])
