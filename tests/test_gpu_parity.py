@@ -626,7 +626,7 @@ def test_paired_launches_change_nothing(lib_loaded: None) -> None:
         if i < 4:
             assert torch.equal(a, b), i
         else:
-            np.testing.assert_allclose(_np(a), _np(b), rtol=1e-5, atol=2e-6 * float(b.abs().max()), err_msg=str(i))
+            np.testing.assert_allclose(_np(a), _np(b), rtol=1e-4, atol=1e-5 * float(b.abs().max()), err_msg=str(i))
     # and against the unpaired single-block node
     ya1 = conv.residual_block(xa.detach(), *(t.detach() for t in pa), act=1)
     assert torch.equal(ya1, res[True][0])
@@ -651,7 +651,7 @@ def test_paired_launches_change_nothing(lib_loaded: None) -> None:
         np.testing.assert_allclose(runs[True][0][k], v, rtol=2e-6, err_msg=k)
     for k, g in runs[False][1].items():
         scale = float(g.abs().max()) + 1e-12
-        np.testing.assert_allclose(_np(runs[True][1][k]), _np(g), rtol=1e-5, atol=2e-6 * scale, err_msg=k)
+        np.testing.assert_allclose(_np(runs[True][1][k]), _np(g), rtol=1e-4, atol=1e-5 * scale, err_msg=k)
 
 
 def test_step_pack_plan_changes_nothing(lib_loaded: None) -> None:
