@@ -37,6 +37,7 @@ int nll_bwd_launch(const float*, const float*, const float*, int64_t, int64_t, i
 int sumsq_launch(const float*, int64_t, float*, hipStream_t);
 int adamw_launch(float*, const float*, float*, float*, int64_t, const float*, float, float, float, float, float, float, float, int, hipStream_t);
 int gemm_launch(const MtrssmGemm*, hipStream_t);
+int debug_set_cluster_profile(void*);
 int mrssm_cluster_supported(const MtrssmMrssmDims*);
 size_t mrssm_cluster_workspace_bytes(const MtrssmMrssmDims*);
 int mrssm_fwd_cluster_launch(const MtrssmMrssmDims*, const MtrssmMrssmClusterWeights*, const MtrssmMrssmFwdIO*, void*, size_t, hipStream_t);
@@ -91,6 +92,8 @@ MTRSSM_API int mtrssm_mrssm_rollout_fwd_cluster(const MtrssmMrssmDims* d, const 
                                                 void* workspace, int64_t workspace_bytes, void* stream) {
   return mrssm_fwd_cluster_launch(d, w, io, workspace, workspace_bytes < 0 ? 0 : (size_t)workspace_bytes, static_cast<hipStream_t>(stream));
 }
+/* development aid, not part of the documented ABI (tools/cluster_probe.py) */
+extern "C" __attribute__((visibility("default"))) int mtrssm_debug_set_cluster_profile(void* buf) { return debug_set_cluster_profile(buf); }
 MTRSSM_API int mtrssm_gemm(const MtrssmGemm* g, void* stream) { return gemm_launch(g, static_cast<hipStream_t>(stream)); }
 MTRSSM_API int mtrssm_adamw_prepare(const float* grad, int64_t n, float* sumsq, float* state, float beta1, float beta2, void* stream) {
   return adamw_prepare_launch(grad, n, sumsq, state, beta1, beta2, static_cast<hipStream_t>(stream));

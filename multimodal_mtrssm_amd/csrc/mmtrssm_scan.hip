@@ -52,7 +52,7 @@ __global__ __launch_bounds__(1024) void mmtrssm_fwd_kernel(const MtrssmMmtrssmDi
     for (int i = tid; i < LS; i += blockDim.x) r[L.slh + i] = io.stoch_l0[b * LS + i];
     for (int i = tid; i < HS; i += blockDim.x) r[L.slh + LS + i] = io.stoch_h0[b * HS + i];
   }
-  __syncthreads();
+  lds_barrier();
 
   for (int t = 0; t < T; ++t) {
     size_t bt[RB];
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(1024) void mmtrssm_fwd_kernel(const MtrssmMmtrssmDi
           if (io.sv_l1 && valid[rb]) io.sv_l1[bt[rb] * 4 * H + 3 * H + o] = h;
         }
       }
-      __syncthreads();
+      lds_barrier();
     }
     // (3) layer 1 of every head (narrow outputs): lpl | la | lv | lph | lqh
     {
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(1024) void mmtrssm_fwd_kernel(const MtrssmMmtrssmDi
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     // (4) MoPoE on the lower level, categorical blocks on both levels
     for (int rb = wave; rb < RB; rb += nwave) {
       float* r = lds + rb * L.stride;
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(1024) void mmtrssm_fwd_kernel(const MtrssmMmtrssmDi
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     int tswap = lcur; lcur = lnxt; lnxt = tswap;
     tswap = hcur; hcur = hnxt; hnxt = tswap;
   }
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(1024) void mmtrssm_bwd_kernel(const MtrssmMmtrssmDi
     for (int i = tid; i < HD; i += blockDim.x) { r[L.c_dh + i] = 0.f; r[L.c_hh + i] = 0.f; }
     for (int i = tid; i < LS + HS; i += blockDim.x) r[L.c_s + i] = 0.f;
   }
-  __syncthreads();
+  lds_barrier();
 
   for (int t = T - 1; t >= 0; --t) {
     size_t bt[RB];
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(1024) void mmtrssm_bwd_kernel(const MtrssmMmtrssmDi
       for (int i = tid; i < LD; i += blockDim.x) { r[L.dl + i] = io.deter_l[q * LD + i]; r[L.dlp + i] = dlsrc[i]; }
       for (int i = tid; i < HD; i += blockDim.x) { r[L.dh + i] = io.deter_h[q * HD + i]; r[L.dhp + i] = dhsrc[i]; }
     }
-    __syncthreads();
+    lds_barrier();
 
     // (b) categorical blocks (lower: mixed posterior; higher: plain posterior) + MoPoE backward
     for (int rb = wave; rb < RB; rb += nwave) {
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(1024) void mmtrssm_bwd_kernel(const MtrssmMmtrssmDi
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
 
     // (c) layer 1 transposed -> pre-activation grads of layer 0
     auto head_bwd = [&](const float* W, int R, int vin_off, int act_off, int dst_off, int g_off, bool to_l, int dup_off) {
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(1024) void mmtrssm_bwd_kernel(const MtrssmMmtrssmDi
     head_bwd(w.wv2, LS, L.dlv, L.l1 + 2 * H, L.dzl + 2 * H, 2 * H, true, -1);
     head_bwd(w.whq2, HS, L.dlqh, L.l1 + 3 * H, L.dzl + 3 * H, 3 * H, true, L.dzh + H);
     head_bwd(w.whp2, HS, L.dlph, L.h1, L.dzh, 0, false, -1);
-    __syncthreads();
+    lds_barrier();
 
     // (d) grads at d_l / d_h, through tanh into the leaky integrators
     gemv_sk<RB, VEC>(w.wl1, LD, 4 * H, LD, lds + L.dzl, L.stride, red,
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(1024) void mmtrssm_bwd_kernel(const MtrssmMmtrssmDi
         for (int rb = 0; rb < RB; ++rb) lds[rb * L.stride + L.c_s + s] = acc[rb];
       }
     }
-    __syncthreads();
+    lds_barrier();
   }
 
   for (int rb = 0; rb < RB; ++rb) {

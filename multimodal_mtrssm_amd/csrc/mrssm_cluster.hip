@@ -3,26 +3,23 @@
 // The single-CU scan (mrssm_scan.hip) streams the step's 1.5 MB of fp32 weights from L2 through one CU's 64 B/clk load
 // path every timestep: 31 us per step against 0.4 us of arithmetic.  Here a row's step is split over kClu = 4 workgroups
 // (= 4 CUs: each workgroup takes a whole CU's LDS), each of which keeps ITS QUARTER of the weights resident for all T
-// steps -- one column of the fused GRU input matrix or of W_hh per thread in registers (up to 200 floats), the head matrix
-// and W1s in LDS (144 KB) -- so nothing is streamed and the step costs its arithmetic plus two exchanges:
+// steps -- its columns of the fused GRU input matrix and of W_hh in registers, cut into pieces spread evenly over all 256
+// threads (240 floats per thread at D = H = 200: a 256-thread workgroup is one wave per SIMD, so each thread may use all
+// 512 registers), the head matrix and W1s in LDS (144 KB) -- so nothing is streamed and the step costs its arithmetic plus
+// two exchanges:
 //
 //   every member   h1 = act(xa + W1s s)                                    (redundant: H x S, W1s in LDS)
-//   member m       gi | gh for its D/4 deter units (threads own whole columns: no reduction), gates, d_new[own]
-//                                                                           -> publish D/4 values, gather 3 D/4   (exchange 1)
+//   member m       gi | gh for its D/4 deter units, gates, d_new[own]      -> publish D/4 values, gather D      (exchange 1)
 //   member m       head layer 0 for its H/4 units of the prior / audio / vision heads, then its share of the 3 S logit
-//                  dot products (partial sums over its units)              -> publish 3 S partials, gather 9 S   (exchange 2)
+//                  dot products (partial sums over its units)              -> publish 3 S partials, gather 12 S (exchange 2)
 //   every member   logits = bias + the four partials in member order, MoPoE mix, KL, sample   (redundant, identical bits)
-//
-// Thread roles (512 threads, 8 waves, <= 256 VGPRs): waves 0-2 one column of (W_ih W2)^T each (gi), waves 3-5 one column of
-// W_hh^T each (gh), both groups split head layer 0's reduction between them; threads 384.. hold one row of the second-layer
-// slices (logit partials); wave 7 gathers the exchanges and runs the categorical block.
 //
 // Exchanges are 8-byte {epoch, value} granules written by ONE sc1 (write-through) store and polled by ONE wave with sc1 loads:
 // the data is the flag, no fence, no ordering requirement (cdna_hip_programming.md Guideline 16, form R2); granule words are
 // zeroed by a memset node in the launch function, epochs count from 1 inside the launch.  Every spin is bounded: a wave that
 // gives up writes a code to the launch's status word and the whole workgroup leaves (the host reads the word after the
-// launch; results are then invalid).  The grid is 4 x min(B, 64) workgroups of 512 threads with ~150 KB of LDS each: one per
-// CU, all resident on the 256 CUs (a cluster loops over rows c, c + clusters, ...), which the spins rely on.
+// launch; results are then invalid).  The grid is 4 x min(B, 64) workgroups with ~150 KB of LDS each: one per CU, all
+// resident on the 256 CUs (a cluster loops over rows c, c + clusters, ...), which the spins rely on.
 //
 // The GRU's input path is fused: gi = W_ih (W2 h1 + b2) + b_ih = (W_ih W2) h1 + (W_ih b2 + b_ih); the caller hands in the
 // product (one small GEMM per launch).  Rounding differs from the two-step form by ~1e-7 relative; h2 itself (needed by
@@ -35,10 +32,16 @@ void set_error(const char* fmt, ...);
 void set_last_kernel(const char* name);
 
 constexpr int kClu = 4;            // workgroups (CUs) per row
-constexpr int kCluThreads = 512;
-constexpr int kCluGroup = 192;     // threads per column group (3 waves): own gate outputs / own head units <= 192
-constexpr int kCluLogit0 = 384;    // first thread of the logit-partial rows
+constexpr int kCluThreads = 256;   // one wave per SIMD: 512 registers per thread
 constexpr unsigned kSpinLimit = 1u << 22;
+
+// Development aid (tools/cluster_probe.py): when set, workgroup 0 stamps s_memtime at the phase boundaries of timesteps
+// 8..11 of its first row into this buffer (16 stamps per step).  Null in normal operation.
+__device__ unsigned long long* g_cluster_prof = nullptr;
+#define MTRSSM_CLU_STAMP(i)                                                                                  \
+  do {                                                                                                       \
+    if (prof && t >= 8 && t < 12) prof[(t - 8) * 16 + (i)] = __builtin_readcyclecounter();                   \
+  } while (0)
 
 __device__ __forceinline__ void granule_store(unsigned long long* p, unsigned epoch, float v) {
   __hip_atomic_store(p, ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
@@ -72,14 +75,20 @@ __device__ __forceinline__ bool wave_gather(const unsigned long long* g, float* 
   }
 }
 
-template <int DH>  // D = H = DH at compile time: the resident columns are DH registers, every stride an immediate
+// DH: D = H (compile time: every stride an immediate).  The 2 * 3 * DH / 4 gate columns are cut into NP pieces of KP = DH / NP
+// reduction terms; thread t holds pieces t * PPT .. t * PPT + PPT - 1 (column = piece / NP, part = piece % NP).
+template <int DH, int NP, int PPT>
 __global__ __launch_bounds__(kCluThreads) void mrssm_fwd_cluster_kernel(const MtrssmMrssmDims dm, const MtrssmMrssmClusterWeights w,
                                                                         const MtrssmMrssmFwdIO io, unsigned long long* __restrict__ gran,
                                                                         int* __restrict__ status, int nclusters) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int D = DH, H = DH, KW = DH;
+  constexpr int D = DH, H = DH;
   constexpr int UD = D / kClu, UH = H / kClu;
   constexpr int NG = 3 * UD, NH = 3 * UH;  // own gate outputs / own head units
+  constexpr int KP = DH / NP;              // reduction terms per piece
+  constexpr int NPIECE = 2 * NG * NP;      // gi columns first, then gh columns
+  static_assert(KP % 4 == 0 && DH % NP == 0, "pieces are whole float4 runs");
+  static_assert(PPT * kCluThreads >= NPIECE, "every piece has a thread");
   const int K = dm.K, C = dm.C, S = K * C, T = dm.T, act = dm.act;
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
   // blocks b, b + 8, b + 16, b + 24 share an XCD under round-robin placement (speed only)
@@ -88,45 +97,43 @@ __global__ __launch_bounds__(kCluThreads) void mrssm_fwd_cluster_kernel(const Mt
   const int cluster = (blk & 7) + 8 * (blk >> 5);
   if (cluster >= nclusters) return;  // whole clusters drop out together
 
-  // ---- LDS carve-up (floats).  The vectors the register-resident columns are multiplied with are KW long, zero padded.
+  // ---- LDS carve-up (floats)
   int o = 0;
   auto take = [&](int n) { const int r = o; o += (n + 3) & ~3; return r; };
-  const int Ls = take(S), Lh1 = take(KW), Ld0 = take(KW), Ld1 = take(KW), Lhd = take(3 * 64);  // head units [which][64], zero padded
+  const int Ls = take(S), Lh1 = take(DH), Ld0 = take(DH), Ld1 = take(DH), Lhd = take(3 * 64);  // head units [which][64], zero padded
   const int Llp = take(S), Lla = take(S), Llv = take(S), Lmx = take(S);
   const int Lpart = take(kClu * 3 * S);   // logit partial sums of the four members
-  const int Lgi = take(NG), Lgh = take(NG), Lred = take(2 * NH);
+  const int Lred = take(NPIECE > NH * NP ? NPIECE : NH * NP);   // per-piece partial sums
   const int Lw1 = take(S * H);            // W1s^T [S][H]
   const int Lwh = take(D * NH);           // [k][o]: this member's columns of the head layer 0
   const int Lflag = take(4);
   (void)o;
   int* abort_flag = reinterpret_cast<int*>(lds + Lflag);
 
-  // ---- roles and resident weights
-  const bool roleG = tid < kCluGroup && tid < NG;                                  // a column of (W_ih W2)^T: gi
-  const bool roleH = tid >= kCluGroup && tid < 2 * kCluGroup && tid - kCluGroup < NG;   // a column of W_hh^T: gh
-  const int og = tid < kCluGroup ? tid : tid - kCluGroup;                          // own output inside the group
-  const bool roleL = tid >= kCluLogit0 && tid - kCluLogit0 < 3 * S;                // a row of the second-layer slices
-  const int lrow = tid - kCluLogit0;
-  // own gate output og = g * UD + u  <->  column g * D + member * UD + u of the [.][3D] matrices
-  const int gcol = (og / UD) * D + member * UD + (og % UD);
-  // one resident vector per thread (no selects, immediate strides: 200 masked loads spilled the register file):
-  //   group G / H: column gcol of wf_t / whh_t, DH elements, stride 3 DH;  logit rows: UH consecutive elements, then zeros
-  float wreg[KW];
+  // ---- resident weights: PPT pieces of KP floats per thread
+  float wreg[PPT][KP];
+  int xsel[PPT];   // per piece: 0 = multiplies h1 (gi column), 1 = multiplies d_prev (gh column); part offset in the high bits
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int pc = tid * PPT + i;
+    const int pcc = pc < NPIECE ? pc : NPIECE - 1;          // threads past the last piece hold a copy (their sums are unused)
+    const int col = pcc / NP, part = pcc - col * NP;
+    const bool is_h = col >= NG;
+    const int og = is_h ? col - NG : col;                   // own gate output og = g * UD + u
+    const int gcol = (og / UD) * D + member * UD + (og % UD);   // <-> column g * D + member * UD + u of the [.][3D] matrices
+    const float* src = (is_h ? w.whh_t : w.wf_t) + (size_t)(part * KP) * 3 * D + gcol;
+    xsel[i] = (is_h ? 1 : 0) | (part * KP) << 1;
+#pragma unroll
+    for (int k = 0; k < KP; ++k) wreg[i][k] = src[(size_t)k * 3 * D];
+  }
+  // the logit rows (second-layer slices, UH <= 64 terms): thread r < 3 S holds row r
+  float wrow[64];
   {
-    // Column roles (waves 0-5): wave-uniform matrix base + compile-time k stride + one 32-bit lane offset, so the 200 loads
-    // need no per-load address registers.  Row roles (waves 6-7): one per-lane base, immediate offsets (UH <= 64 elements).
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    if (wave_u < 6) {
-      const float* ub = wave_u < 3 ? w.wf_t : w.whh_t;
-      const int gc = (roleG || roleH) ? gcol : 0;
+    const bool roleL = tid < 3 * S;
+    const int which = roleL ? tid / S : 0, srow = roleL ? tid - which * S : 0;
+    const float* rowsrc = (which == 0 ? w.w4 : (which == 1 ? w.wa2 : w.wv2)) + (size_t)srow * H + member * UH;
 #pragma unroll
-      for (int k = 0; k < KW; ++k) wreg[k] = ub[(size_t)k * 3 * D + gc];
-    } else {
-      const int which = roleL ? lrow / S : 0, srow = roleL ? lrow - which * S : 0;
-      const float* rowsrc = (which == 0 ? w.w4 : (which == 1 ? w.wa2 : w.wv2)) + (size_t)srow * H + member * UH;
-#pragma unroll
-      for (int k = 0; k < KW; ++k) wreg[k] = k < UH ? rowsrc[k] : 0.f;
-    }
+    for (int k = 0; k < 64; ++k) wrow[k] = k < UH ? rowsrc[k] : 0.f;
   }
   for (int idx = tid; idx < S * H; idx += kCluThreads) lds[Lw1 + idx] = w.w1s_t[idx];
   // head layer 0: own head unit oh = which * UH + u  <->  column which * H + member * UH + u of wh1_t [D][3H]
@@ -134,7 +141,6 @@ __global__ __launch_bounds__(kCluThreads) void mrssm_fwd_cluster_kernel(const Mt
     const int k = idx / NH, oh = idx - k * NH;
     lds[Lwh + idx] = w.wh1_t[(size_t)k * 3 * H + (oh / UH) * H + member * UH + (oh % UH)];
   }
-  for (int i = tid; i < KW; i += kCluThreads) { lds[Lh1 + i] = 0.f; lds[Ld0 + i] = 0.f; lds[Ld1 + i] = 0.f; }
   for (int i = tid; i < 3 * 64; i += kCluThreads) lds[Lhd + i] = 0.f;
   // per-thread constants of the finishing threads
   float bias_g[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // thread u < UD: bf / bhh of its three gates
@@ -146,11 +152,6 @@ __global__ __launch_bounds__(kCluThreads) void mrssm_fwd_cluster_kernel(const Mt
     }
   }
   const float bias_h = (tid < UH) ? w.b3[member * UH + tid] : 0.f;  // prior head units only (audio / vision take pa / pv)
-  float bias_l = 0.f;                                                // thread i < 3S: bias of logit i
-  if (tid < 3 * S) {
-    const int which = tid / S, s = tid - which * S;
-    bias_l = (which == 0 ? w.b4 : (which == 1 ? w.ba2 : w.bv2))[s];
-  }
   if (tid == 0) *abort_flag = 0;
 
   // granule slots of this cluster: [parity][ D-exchange: member x UD | logit exchange: member x 3S ]
@@ -158,14 +159,14 @@ __global__ __launch_bounds__(kCluThreads) void mrssm_fwd_cluster_kernel(const Mt
   const int per_parity = kClu * (slotsD + slotsL);
   unsigned long long* gbase = gran + (size_t)cluster * 2 * per_parity;
   unsigned epoch = 0;
-  const int khalf = ((D / 2) + 3) & ~3;  // head layer 0: group G reduces k < khalf, group H the rest
+  unsigned long long* prof = (blockIdx.x == 0 && tid == 0) ? g_cluster_prof : nullptr;
 
   for (int row = cluster; row < dm.B; row += nclusters) {
     int cur = Ld0, nxt = Ld1;
-    __syncthreads();
+    lds_barrier();
     for (int i = tid; i < D; i += kCluThreads) lds[cur + i] = io.deter0[(size_t)row * D + i];
     for (int i = tid; i < S; i += kCluThreads) lds[Ls + i] = io.stoch0[(size_t)row * S + i];
-    __syncthreads();
+    lds_barrier();
 
     for (int t = 0; t < T; ++t) {
       const size_t bt = (size_t)row * T + t;
@@ -178,44 +179,63 @@ __global__ __launch_bounds__(kCluThreads) void mrssm_fwd_cluster_kernel(const Mt
         pav = (which == 1 ? io.pa : io.pv)[bt * H + member * UH + u];
       }
 
+      MTRSSM_CLU_STAMP(0);
       // (1) h1 = act(xa + W1s s): every member, all H outputs                    networks.py:165-166
       if (tid < H) {
-        float a = xa_v;
+        // S <= 42 terms in four independent chains, reads batched eight deep: a rolled, one-chain loop pays the LDS latency
+        // (~100 cycles) per term on the step's critical path
         const float* wc = lds + Lw1 + tid;
-        for (int k = 0; k < S; ++k) a = fmaf(wc[(size_t)k * H], lds[Ls + k], a);
-        const float h = act_fwd(a, act);
+        float a0 = xa_v, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int k = 0;
+        for (; k + 8 <= S; k += 8) {
+          float wv[8], sv[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { wv[i] = wc[(size_t)(k + i) * H]; sv[i] = lds[Ls + k + i]; }
+          a0 = fmaf(wv[0], sv[0], a0); a1 = fmaf(wv[1], sv[1], a1); a2 = fmaf(wv[2], sv[2], a2); a3 = fmaf(wv[3], sv[3], a3);
+          a0 = fmaf(wv[4], sv[4], a0); a1 = fmaf(wv[5], sv[5], a1); a2 = fmaf(wv[6], sv[6], a2); a3 = fmaf(wv[7], sv[7], a3);
+        }
+        for (; k < S; ++k) a0 = fmaf(wc[(size_t)k * H], lds[Ls + k], a0);
+        const float h = act_fwd((a0 + a1) + (a2 + a3), act);
         lds[Lh1 + tid] = h;
         if (member == 0 && io.sv_h1) io.sv_h1[bt * H + tid] = h;
       }
-      __syncthreads();
+      lds_barrier();
 
-      // (2) gi (fused W_ih W2) by group G, gh (W_hh) by group H: one whole column per thread, no reduction
-      if (roleG || roleH) {
-        const float* xv = lds + (roleG ? Lh1 : cur);
+      MTRSSM_CLU_STAMP(1);
+      // (2) partial dot products of this thread's pieces of gi (fused W_ih W2, times h1) and gh (W_hh, times d_prev)
+#pragma unroll
+      for (int i = 0; i < PPT; ++i) {
+        const float* xv = lds + ((xsel[i] & 1) ? cur : Lh1) + (xsel[i] >> 1);
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
-        for (int k = 0; k < KW; k += 4) {
+        for (int k = 0; k < KP; k += 4) {
           const float4 x = *reinterpret_cast<const float4*>(xv + k);
-          a0 = fmaf(wreg[k], x.x, a0);
-          a1 = fmaf(wreg[k + 1], x.y, a1);
-          a2 = fmaf(wreg[k + 2], x.z, a2);
-          a3 = fmaf(wreg[k + 3], x.w, a3);
-          // registers are the scarce resource here (the column itself holds up to 200): an empty asm that "uses" the
-          // accumulators and clobbers memory keeps the operand reads of the unrolled loop from being hoisted to its top
-          asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) :: "memory");
+          a0 = fmaf(wreg[i][k], x.x, a0);
+          a1 = fmaf(wreg[i][k + 1], x.y, a1);
+          a2 = fmaf(wreg[i][k + 2], x.z, a2);
+          a3 = fmaf(wreg[i][k + 3], x.w, a3);
         }
-        lds[(roleG ? Lgi : Lgh) + og] = (a0 + a1) + (a2 + a3);
+        if (tid * PPT + i < NPIECE) lds[Lred + tid * PPT + i] = (a0 + a1) + (a2 + a3);
       }
-      __syncthreads();
+      lds_barrier();
 
+      MTRSSM_CLU_STAMP(2);
       // (3) gates of the own deter units; publish them                          networks.py:170 (nn.GRUCell)
       ++epoch;
       if (tid < UD) {
-        const float gi0 = lds[Lgi + tid] + bias_g[0], gi1 = lds[Lgi + UD + tid] + bias_g[1], gi2 = lds[Lgi + 2 * UD + tid] + bias_g[2];
-        const float gh0 = lds[Lgh + tid] + bias_g[3], gh1 = lds[Lgh + UD + tid] + bias_g[4], gh2 = lds[Lgh + 2 * UD + tid] + bias_g[5];
-        const float rg = sigmoidf_(gh0 + gi0);
-        const float zg = sigmoidf_(gh1 + gi1);
-        const float ng = tanhf(gi2 + gh2 * rg);
+        float gs[6];
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {  // g < 3: gi of gate g (column g * UD + tid); else gh (column NG + ...)
+          const float* pr = lds + Lred + ((g < 3 ? g : g - 3) * UD + tid + (g < 3 ? 0 : NG)) * NP;
+          float a = bias_g[g];
+#pragma unroll
+          for (int q = 0; q < NP; ++q) a += pr[q];
+          gs[g] = a;
+        }
+        // hardware exp (v_exp_f32, ~1e-6 relative) on the step's critical path: sigmoid = 1 / (1 + e^-x), tanh = 1 - 2 / (e^2x + 1)
+        const float rg = __fdividef(1.f, 1.f + __expf(-(gs[3] + gs[0])));
+        const float zg = __fdividef(1.f, 1.f + __expf(-(gs[4] + gs[1])));
+        const float ng = 1.f - __fdividef(2.f, __expf(2.f * (gs[2] + gs[5] * rg)) + 1.f);
         const int unit = member * UD + tid;
         const float dnew = (lds[cur + unit] - ng) * zg + ng;
         lds[nxt + unit] = dnew;
@@ -223,82 +243,86 @@ __global__ __launch_bounds__(kCluThreads) void mrssm_fwd_cluster_kernel(const Mt
         io.deter[bt * D + unit] = dnew;
         if (io.sv_gates) {
           float* gsv = io.sv_gates + bt * 4 * D;
-          gsv[unit] = rg; gsv[D + unit] = zg; gsv[2 * D + unit] = ng; gsv[3 * D + unit] = gh2;
+          gsv[unit] = rg; gsv[D + unit] = zg; gsv[2 * D + unit] = ng; gsv[3 * D + unit] = gs[5];
         }
       }
-      if (wave == 7) {  // exchange 1: all D deter units, in unit order (the own ones come back unchanged)
+      if (wave == 3) {  // exchange 1: all D deter units, in unit order (the own ones come back unchanged)
         const bool ok = wave_gather<4>(gpar, lds + nxt, D, epoch, lane);
         if (!ok && lane == 0) { *abort_flag = 1; atomicExch(status, 1 + 2 * t); }
       }
-      __syncthreads();
+      lds_barrier();
       if (*abort_flag) return;
 
-      // (4) head layer 0 for the own units of the three heads (matrix slice resident in LDS): the two column groups split
-      //     the reduction                                                        networks.py:171, 82
-      if ((tid < kCluGroup || (tid >= kCluGroup && tid < 2 * kCluGroup)) && og < NH) {
-        const bool first = tid < kCluGroup;
-        const int k0 = first ? 0 : khalf, k1 = first ? (khalf < D ? khalf : D) : D;
-        const float* wcol = lds + Lwh + og;
-        const float* dv = lds + nxt;
-        float p0 = 0.f, p1 = 0.f;
-        int k = k0;
-        for (; k + 2 <= k1; k += 2) {
-          p0 = fmaf(wcol[(size_t)k * NH], dv[k], p0);
-          p1 = fmaf(wcol[(size_t)(k + 1) * NH], dv[k + 1], p1);
+      MTRSSM_CLU_STAMP(3);
+      // (4) head layer 0 for the own units of the three heads (matrix slice resident in LDS), cut into the same NP parts
+      for (int pc = tid; pc < NH * NP; pc += kCluThreads) {
+        const int oh = pc / NP, part = pc - oh * NP;
+        const float* wcol = lds + Lwh + (size_t)(part * KP) * NH + oh;
+        const float* dv = lds + nxt + part * KP;
+        float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+#pragma unroll
+        for (int k = 0; k < KP; k += 8) {  // eight matrix reads in flight, four chains
+          float wv[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) wv[i] = k + i < KP ? wcol[(size_t)(k + i) * NH] : 0.f;
+          const float4 d0 = *reinterpret_cast<const float4*>(dv + k);
+          const float4 d1 = k + 4 < KP ? *reinterpret_cast<const float4*>(dv + k + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+          p0 = fmaf(wv[0], d0.x, p0); p1 = fmaf(wv[1], d0.y, p1); p2 = fmaf(wv[2], d0.z, p2); p3 = fmaf(wv[3], d0.w, p3);
+          p0 = fmaf(wv[4], d1.x, p0); p1 = fmaf(wv[5], d1.y, p1); p2 = fmaf(wv[6], d1.z, p2); p3 = fmaf(wv[7], d1.w, p3);
         }
-        if (k < k1) p0 = fmaf(wcol[(size_t)k * NH], dv[k], p0);
-        lds[Lred + (first ? 0 : NH) + og] = p0 + p1;
+        lds[Lred + pc] = (p0 + p1) + (p2 + p3);
       }
-      __syncthreads();
+      lds_barrier();
       if (tid < NH) {
-        const float z = (tid < UH ? bias_h : pav) + (lds[Lred + tid] + lds[Lred + NH + tid]);
+        float z = tid < UH ? bias_h : pav;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) z += lds[Lred + tid * NP + q];
         const float h = act_fwd(z, act);
         const int which = tid / UH, u = tid - which * UH;
         lds[Lhd + which * 64 + u] = h;
         if (io.sv_heads) io.sv_heads[bt * 3 * H + which * H + member * UH + u] = h;
       }
-      __syncthreads();
+      lds_barrier();
 
+      MTRSSM_CLU_STAMP(4);
       // (5) this member's share of the 3 S logit dot products (rows resident in registers); publish; gather the others
       ++epoch;
       unsigned long long* gl = gpar + (size_t)kClu * slotsD;
-      if (roleL) {
-        const float* hv = lds + Lhd + (lrow / S) * 64;
+      if (tid < 3 * S) {
+        const float* hv = lds + Lhd + (tid / S) * 64;
         float p0 = 0.f, p1 = 0.f;
 #pragma unroll
         for (int u = 0; u < 64; u += 4) {  // UH <= 64 (mrssm_cluster_supported); hv is zero beyond UH
           const float4 x = *reinterpret_cast<const float4*>(hv + u);
-          p0 = fmaf(wreg[u], x.x, p0);
-          p1 = fmaf(wreg[u + 1], x.y, p1);
-          p0 = fmaf(wreg[u + 2], x.z, p0);
-          p1 = fmaf(wreg[u + 3], x.w, p1);
-          asm volatile("" : "+v"(p0), "+v"(p1) :: "memory");
+          p0 = fmaf(wrow[u], x.x, p0);
+          p1 = fmaf(wrow[u + 1], x.y, p1);
+          p0 = fmaf(wrow[u + 2], x.z, p0);
+          p1 = fmaf(wrow[u + 3], x.w, p1);
         }
         const float p = p0 + p1;
-        lds[Lpart + member * 3 * S + lrow] = p;
-        granule_store(gl + (size_t)member * slotsL + lrow, epoch, p);
+        lds[Lpart + member * 3 * S + tid] = p;
+        granule_store(gl + (size_t)member * slotsL + tid, epoch, p);
       }
-      if (wave == 7) {  // exchange 2: the four members' 3 S partial sums, [member][3S]
+      if (wave == 3) {  // exchange 2: the four members' 3 S partial sums, [member][3S]
         const bool ok = wave_gather<6>(gl, lds + Lpart, kClu * 3 * S, epoch, lane);
         if (!ok && lane == 0) { *abort_flag = 1; atomicExch(status, 2 + 2 * t); }
       }
-      __syncthreads();
+      lds_barrier();
       if (*abort_flag) return;
 
-      // (6) logits = bias + partials in member order (the same bits on every member)
-      if (tid < 3 * S) {
-        float v = bias_l;
-#pragma unroll
-        for (int m2 = 0; m2 < kClu; ++m2) v += lds[Lpart + m2 * 3 * S + tid];
-        const int which = tid / S, s = tid - which * S;
-        lds[(which == 0 ? Llp : (which == 1 ? Lla : Llv)) + s] = v;
-      }
-      __syncthreads();
-
-      // (7) fusion, per-categorical softmax, KL, sampling: one wave (every member; member 0 writes the outputs)
-      if (wave == 7) {
+      MTRSSM_CLU_STAMP(5);
+      // (6) logits = bias + partials in member order (the same bits on every member), then fusion, per-categorical softmax,
+      //     KL, sampling: one wave (every member; member 0 writes the outputs)
+      if (wave == 3) {
         const bool writer = member == 0;
-        wave_mopoe_mix(lds + Lla, lds + Llv, lds + Lmx, S, lane);
+        for (int i = lane; i < 3 * S; i += kWave) {
+          const int which = i / S, s2 = i - which * S;
+          float v = (which == 0 ? w.b4 : (which == 1 ? w.ba2 : w.bv2))[s2];
+#pragma unroll
+          for (int m2 = 0; m2 < kClu; ++m2) v += lds[Lpart + m2 * 3 * S + i];
+          lds[(which == 0 ? Llp : (which == 1 ? Lla : Llv)) + s2] = v;
+        }
+        wave_mopoe_mix<true>(lds + Lla, lds + Llv, lds + Lmx, S, lane);
         for (int s = lane; s < S; s += kWave) {
           if (writer) {
             io.prior_logits[bt * S + s] = lds[Llp + s];
@@ -306,29 +330,37 @@ __global__ __launch_bounds__(kCluThreads) void mrssm_fwd_cluster_kernel(const Mt
             if (io.sv_la) { io.sv_la[bt * S + s] = lds[Lla + s]; io.sv_lv[bt * S + s] = lds[Llv + s]; }
           }
         }
-        float kl = cat_block_fwd<true>(lds + Lmx, lds + Llp, K, C, lane, io.u_post + bt * K, io.u_prior ? io.u_prior + bt * K : nullptr,
-                                       lds + Ls, io.post_stoch + bt * S, io.prior_stoch ? io.prior_stoch + bt * S : nullptr, writer);
+        float kl = cat_block_fwd<true, true>(lds + Lmx, lds + Llp, K, C, lane, io.u_post + bt * K, io.u_prior ? io.u_prior + bt * K : nullptr,
+                                             lds + Ls, io.post_stoch + bt * S, io.prior_stoch ? io.prior_stoch + bt * S : nullptr, writer);
         if (io.kl) {
           kl = wave_sum(kl);
           if (lane == 0 && writer) io.kl[bt] = kl;
         }
       }
-      __syncthreads();
+      lds_barrier();
+      MTRSSM_CLU_STAMP(7);
       const int tmp = cur; cur = nxt; nxt = tmp;
     }
   }
 }
 
+int debug_set_cluster_profile(void* buf) {
+  unsigned long long* p = static_cast<unsigned long long*>(buf);
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_cluster_prof), &p, sizeof(p)) == hipSuccess ? MTRSSM_OK : MTRSSM_ELAUNCH;
+}
+
 static int cluster_kw(int D, int H) { return D > H ? D : H; }
 
+static int cluster_np(int DH) { return DH == 200 ? 5 : (DH == 128 ? 4 : (DH == 64 ? 2 : 1)); }
+
 static size_t cluster_lds_floats(int D, int H, int S) {
-  const int UD = D / kClu, UH = H / kClu, NG = 3 * UD, NH = 3 * UH, KW = cluster_kw(D, H);
+  const int UD = D / kClu, UH = H / kClu, NG = 3 * UD, NH = 3 * UH, KW = cluster_kw(D, H), NP = cluster_np(KW);
   size_t o = 0;
   auto take = [&](size_t n) { o += (n + 3) & ~(size_t)3; };
   take(S); take(KW); take(KW); take(KW); take(3 * 64);
   take(S); take(S); take(S); take(S);
   take((size_t)kClu * 3 * S);
-  take(NG); take(NG); take((size_t)2 * NH);
+  take((size_t)(2 * NG * NP > NH * NP ? 2 * NG * NP : NH * NP));
   take((size_t)S * H);
   take((size_t)D * NH);
   take(4);
@@ -347,8 +379,7 @@ int mrssm_cluster_supported(const MtrssmMrssmDims* d) {
   if (!d || d->B <= 0 || d->T <= 0 || d->D <= 0 || d->H <= 0 || d->K <= 0 || d->C <= 0 || !d->post) return 0;
   const int S = d->K * d->C, D = d->D, H = d->H;
   if (D != H || (D != 32 && D != 64 && D != 128 && D != 200)) return 0;  // the instantiated square sizes
-  if (3 * D / kClu > kCluGroup || 3 * H / kClu > kCluGroup) return 0;
-  if (3 * S > kCluThreads - kCluLogit0 || H / kClu > 64) return 0;  // logit rows sit in threads 384..511, <= 64 units each
+  if (3 * S > kCluThreads || H / kClu > 64 || 3 * H / kClu > kCluThreads) return 0;  // logit rows / head units: one thread each
   if (D > 4 * kWave || kClu * 3 * S > 6 * kWave) return 0;  // granules per gather (wave_gather<4> / <6>)
   if (cluster_lds_floats(D, H, S) * sizeof(float) > 160 * 1024) return 0;
   return 1;
@@ -381,18 +412,20 @@ int mrssm_fwd_cluster_launch(const MtrssmMrssmDims* d, const MtrssmMrssmClusterW
   int* status = reinterpret_cast<int*>(workspace);
   unsigned long long* gran = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(workspace) + 16);
   const int kw = cluster_kw(d->D, d->H);
-#define MTRSSM_CLU_LAUNCH(KWV)                                                                                                     \
+#define MTRSSM_CLU_LAUNCH(DHV, NPV, PPTV)                                                                                          \
   {                                                                                                                               \
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(mrssm_fwd_cluster_kernel<KWV>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                            (int)lds);                                                                                            \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(mrssm_fwd_cluster_kernel<DHV, NPV, PPTV>),                              \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                               \
     if (e != hipSuccess) { set_error("hipFuncSetAttribute(max dynamic LDS=%zu): %s", lds, hipGetErrorString(e)); return MTRSSM_ELAUNCH; } \
-    set_last_kernel("mtrssm::mrssm_fwd_cluster_kernel<" #KWV ">");                                                               \
-    hipLaunchKernelGGL(mrssm_fwd_cluster_kernel<KWV>, dim3(grid), dim3(kCluThreads), lds, stream, *d, *w, *io, gran, status, nclusters); \
+    set_last_kernel("mtrssm::mrssm_fwd_cluster_kernel<" #DHV ", " #NPV ", " #PPTV ">");                                          \
+    hipLaunchKernelGGL((mrssm_fwd_cluster_kernel<DHV, NPV, PPTV>), dim3(grid), dim3(kCluThreads), lds, stream, *d, *w, *io, gran,   \
+                       status, nclusters);                                                                                        \
   }
-  if (kw == 32) MTRSSM_CLU_LAUNCH(32)
-  else if (kw == 64) MTRSSM_CLU_LAUNCH(64)
-  else if (kw == 128) MTRSSM_CLU_LAUNCH(128)
-  else MTRSSM_CLU_LAUNCH(200)
+  // pieces per thread = ceil(2 * (3 DH / 4) * NP / 256)
+  if (kw == 32) MTRSSM_CLU_LAUNCH(32, 1, 1)
+  else if (kw == 64) MTRSSM_CLU_LAUNCH(64, 2, 1)
+  else if (kw == 128) MTRSSM_CLU_LAUNCH(128, 4, 3)
+  else MTRSSM_CLU_LAUNCH(200, 5, 6)
 #undef MTRSSM_CLU_LAUNCH
   e = hipGetLastError();
   if (e != hipSuccess) { set_error("cluster scan launch failed: %s", hipGetErrorString(e)); return MTRSSM_ELAUNCH; }

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(1024) void mrssm_fwd_kernel(const MtrssmMrssmDims d
     for (int i = tid; i < D; i += blockDim.x) r[cur + i] = io.deter0[(size_t)brow[rb] * D + i];
     for (int i = tid; i < S; i += blockDim.x) r[L.s + i] = io.stoch0[(size_t)brow[rb] * S + i];
   }
-  __syncthreads();
+  lds_barrier();
 
   for (int t = 0; t < T; ++t) {
     size_t bt[RB];
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(1024) void mrssm_fwd_kernel(const MtrssmMrssmDims d
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     // (5) head layer 0 on the new deter: prior | audio | vision   networks.py:171, 82 ; core.py:82
     gemv_sk<RB, VEC>(w.wh1_t, NH * H, D, NH * H, lds + nxt, L.stride, red,
                [&](int rb, int o) {
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(1024) void mrssm_fwd_kernel(const MtrssmMrssmDims d
         for (int rb = 0; rb < RB; ++rb) lds[rb * L.stride + dst + s] = acc[rb] + b;
       }
     }
-    __syncthreads();
+    lds_barrier();
     // (7) fusion, per-categorical softmax, KL, sampling: wave rb handles row rb
     for (int rb = wave; rb < RB; rb += nwave) {
       float* r_ = lds + rb * L.stride;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(1024) void mrssm_fwd_kernel(const MtrssmMrssmDims d
         if (lane == 0 && ok) io.kl[q] = kl;
       }
     }
-    __syncthreads();
+    lds_barrier();
     const int tmp = cur; cur = nxt; nxt = tmp;
   }
 }
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(1024) void mrssm_bwd_kernel(const MtrssmMrssmDims d
     for (int i = tid; i < D; i += blockDim.x) r[L.cd + i] = 0.f;
     for (int i = tid; i < S; i += blockDim.x) r[L.cs + i] = 0.f;
   }
-  __syncthreads();
+  lds_barrier();
 
   for (int t = T - 1; t >= 0; --t) {
     size_t bt[RB];
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(1024) void mrssm_bwd_kernel(const MtrssmMrssmDims d
       const float* dsrc = t > 0 ? io.deter + (q - 1) * D : io.deter0 + (size_t)brow[rb] * D;
       for (int i = tid; i < D; i += blockDim.x) r[L.dprev + i] = dsrc[i];
     }
-    __syncthreads();
+    lds_barrier();
 
     // (b) categorical block: straight-through sample, KL, per-categorical softmax, MoE/PoE, flat log-softmax
     for (int rb = wave; rb < RB; rb += nwave) {
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(1024) void mrssm_bwd_kernel(const MtrssmMrssmDims d
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
 
     // (c) head layer 1 transposed: dzh[which][j] = act'(hd) * sum_s W[s][j] dl[s]
     gemv_sk<RB, VEC>(w.w4, H, S, H, lds + L.dlp, L.stride, red, [](int, int) { return 0.f; },
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(1024) void mrssm_bwd_kernel(const MtrssmMrssmDims d
         for (int rb = 0; rb < RB; ++rb) lds[rb * L.stride + L.cs + s] = acc[rb];
       }
     }
-    __syncthreads();
+    lds_barrier();
   }
 
   for (int rb = 0; rb < RB; ++rb) {

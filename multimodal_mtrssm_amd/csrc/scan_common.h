@@ -31,6 +31,15 @@ __device__ __forceinline__ float act_grad_from_out(float h, int act) {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
+// Workgroup barrier for kernels whose waves talk to each other through LDS only.  __syncthreads() is a workgroup-scope
+// release/acquire fence + s_barrier, and the fence drains the vector-memory counter too (s_waitcnt vmcnt(0)): every barrier
+// that follows a global STORE -- the scan kernels write their per-step outputs and saved activations between almost any two
+// barriers -- then waits for the HBM write acknowledgement, a full memory round trip on the timestep's critical path
+// (measured in the cluster scan: ~1,000 cycles per barrier, 9 barriers per step).  Here only LDS traffic is drained.
+// Safe because no wave of these kernels reads global memory that another wave of the same launch wrote with a plain store
+// (outputs are read by later launches; the cluster exchanges are polled sc1 granules).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
@@ -130,7 +139,7 @@ __device__ __forceinline__ void gemv_sk(const float* __restrict__ M, int ld, int
 #pragma unroll
         for (int j = 0; j < W; ++j) red[((size_t)ks * RB + rb) * OP + cg * W + j] = acc[rb][j];
     }
-    __syncthreads();
+    lds_barrier();
     const int o_lo = base * W;
     const int o_hi = (base + CGP) * W < O ? (base + CGP) * W : O;
     for (int o = o_lo + t; o < o_hi; o += nthr) {
@@ -141,7 +150,7 @@ __device__ __forceinline__ void gemv_sk(const float* __restrict__ M, int ld, int
         fin(rb, o, sum);
       }
     }
-    __syncthreads();
+    lds_barrier();
   }
 }
 
@@ -165,49 +174,58 @@ __device__ __forceinline__ void wave_dot(const float* __restrict__ wrow, int R, 
 // Categorical helpers, executed by ONE wave for one row.  Logits are flat [K*C] in LDS.
 // ---------------------------------------------------------------------------------------
 
+// exp / log of the categorical helpers.  FAST = the hardware transcendentals (v_exp_f32 / v_log_f32, ~1e-6 relative): the
+// cluster scan's categorical block sits on every timestep's critical path, where the libm versions cost ~5 us per step.
+template <bool FAST> __device__ __forceinline__ float cexp(float x) { return FAST ? __expf(x) : expf(x); }
+template <bool FAST> __device__ __forceinline__ float clog(float x) { return FAST ? __logf(x) : logf(x); }
+
 // flat log-sum-exp pieces over S entries: returns (max, log(sum exp(x - max))), torch.log_softmax form
+template <bool FAST = false>
 __device__ __forceinline__ void wave_flat_lse(const float* x, int S, int lane, float& mx, float& lsum) {
   float m = -INFINITY;
   for (int s = lane; s < S; s += kWave) m = fmaxf(m, x[s]);
   m = wave_max(m);
   float acc = 0.f;
-  for (int s = lane; s < S; s += kWave) acc += expf(x[s] - m);
+  for (int s = lane; s < S; s += kWave) acc += cexp<FAST>(x[s] - m);
   acc = wave_sum(acc);
   mx = m;
-  lsum = logf(acc);
+  lsum = clog<FAST>(acc);
 }
 
 // MoPoE mix of two experts' flat logits (core.py:241-243 + 112-163) -> mixed[S] (LDS)
+template <bool FAST = false>
 __device__ __forceinline__ void wave_mopoe_mix(const float* la, const float* lv, float* mixed, int S, int lane) {
   float ma, lsa, mv, lsv;
-  wave_flat_lse(la, S, lane, ma, lsa);
-  wave_flat_lse(lv, S, lane, mv, lsv);
+  wave_flat_lse<FAST>(la, S, lane, ma, lsa);
+  wave_flat_lse<FAST>(lv, S, lane, mv, lsv);
   for (int s = lane; s < S; s += kWave) {
     const float a = (la[s] - ma) - lsa;
     const float v = (lv[s] - mv) - lsv;
     const float f = a + v;
     const float x1 = kLogThird + a, x2 = kLogThird + v, x3 = kLogThird + f;
     const float m = fmaxf(x1, fmaxf(x2, x3));
-    mixed[s] = logf(expf(x1 - m) + expf(x2 - m) + expf(x3 - m)) + m;
+    mixed[s] = clog<FAST>(cexp<FAST>(x1 - m) + cexp<FAST>(x2 - m) + cexp<FAST>(x3 - m)) + m;
   }
 }
 
 // Per-categorical softmax statistics for category k: max and log-sum
+template <bool FAST = false>
 __device__ __forceinline__ void cat_stats(const float* x, int C, float& mx, float& sum) {
   float m = x[0];
   for (int c = 1; c < C; ++c) m = fmaxf(m, x[c]);
   float s = 0.f;
-  for (int c = 0; c < C; ++c) s += expf(x[c] - m);
+  for (int c = 0; c < C; ++c) s += cexp<FAST>(x[c] - m);
   mx = m;
   sum = s;
 }
 
 // inverse-CDF index: number of c in [0, C-2] whose inclusive cumulative probability is <= u
+template <bool FAST = false>
 __device__ __forceinline__ int cat_sample(const float* x, int C, float mx, float sum, float u) {
   float acc = 0.f;
   int idx = 0;
   for (int c = 0; c + 1 < C; ++c) {
-    acc += expf(x[c] - mx) / sum;
+    acc += cexp<FAST>(x[c] - mx) / sum;
     idx += (acc <= u) ? 1 : 0;
   }
   return idx;
@@ -221,7 +239,7 @@ __device__ __forceinline__ int cat_sample(const float* x, int C, float mx, float
 //   !POST: prior sample -> s_lds (+ prior_stoch_g); returns 0.
 // Follows state.py:17 (sample on construction) and core.py:212-216 (KL over independent(1)).
 // ---------------------------------------------------------------------------------------
-template <bool POST>
+template <bool POST, bool FAST = false>
 __device__ __forceinline__ float cat_block_fwd(const float* q_logits, const float* p_logits, int K, int C, int lane,
                                                const float* u_post, const float* u_prior, float* s_lds,
                                                float* post_stoch_g, float* prior_stoch_g, bool ok) {
@@ -229,30 +247,30 @@ __device__ __forceinline__ float cat_block_fwd(const float* q_logits, const floa
   for (int k = lane; k < K; k += kWave) {
     const float* pl = p_logits + k * C;
     float pm, ps;
-    cat_stats(pl, C, pm, ps);
+    cat_stats<FAST>(pl, C, pm, ps);
     if (POST) {
       const float* ql = q_logits + k * C;
       float qm, qs;
-      cat_stats(ql, C, qm, qs);
-      const float lqs = logf(qs), lps = logf(ps);
+      cat_stats<FAST>(ql, C, qm, qs);
+      const float lqs = clog<FAST>(qs), lps = clog<FAST>(ps);
       float klk = 0.f;
       for (int c = 0; c < C; ++c) {
-        const float qc = expf(ql[c] - qm) / qs;
+        const float qc = cexp<FAST>(ql[c] - qm) / qs;
         klk += qc * (((ql[c] - qm) - lqs) - ((pl[c] - pm) - lps));
       }
       kl += klk;
-      const int idx = cat_sample(ql, C, qm, qs, u_post[k]);
+      const int idx = cat_sample<FAST>(ql, C, qm, qs, u_post[k]);
       for (int c = 0; c < C; ++c) {
         const float v = c == idx ? 1.f : 0.f;
         s_lds[k * C + c] = v;
         if (ok) post_stoch_g[k * C + c] = v;
       }
       if (u_prior && prior_stoch_g && ok) {
-        const int pidx = cat_sample(pl, C, pm, ps, u_prior[k]);
+        const int pidx = cat_sample<FAST>(pl, C, pm, ps, u_prior[k]);
         for (int c = 0; c < C; ++c) prior_stoch_g[k * C + c] = c == pidx ? 1.f : 0.f;
       }
     } else {
-      const int pidx = cat_sample(pl, C, pm, ps, u_prior[k]);
+      const int pidx = cat_sample<FAST>(pl, C, pm, ps, u_prior[k]);
       for (int c = 0; c < C; ++c) {
         const float v = c == pidx ? 1.f : 0.f;
         s_lds[k * C + c] = v;
