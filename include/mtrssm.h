@@ -195,6 +195,14 @@ typedef struct MtrssmMrssmBwdIO {
   float* d_lv;      /* [B,T,S]  grad at vision logits */
 } MtrssmMrssmBwdIO;
 
+/* The reverse-time scan on the same four-CU clusters (csrc/mrssm_cluster.hip: mrssm_bwd_cluster_kernel): weights as in
+ * MtrssmMrssmClusterWeights (bias fields unused).  io->sv_h2 is not read and io->d_h2 is NOT written (the fused input path
+ * has no h2 inside the scan): form d_h2 = d_gi . W_ih afterwards (one GEMM).  Workspace / status word / co-residency as for
+ * the forward cluster call; S <= 32. */
+int64_t mtrssm_mrssm_cluster_bwd_workspace_bytes(const MtrssmMrssmDims* dims);
+int mtrssm_mrssm_rollout_bwd_cluster(const MtrssmMrssmDims* dims, const MtrssmMrssmClusterWeights* weights, const MtrssmMrssmBwdIO* io,
+                                     void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Reverse-time scan (BPTT).  Weight gradients are NOT accumulated inside the serial loop: the
  * kernel emits the per-step pre-activation gradients above and the caller forms every dW as one
  * batched [out x B*T] . [B*T x in] library GEMM (rocBLAS), which is where MFMA belongs. */

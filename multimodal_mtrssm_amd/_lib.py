@@ -91,6 +91,8 @@ SYMBOLS: dict[str, tuple[type | None, list[type]]] = {
     "mtrssm_mrssm_cluster_supported": (C.c_int, [C.POINTER(MrssmDims)]),
     "mtrssm_mrssm_cluster_workspace_bytes": (C.c_int64, [C.POINTER(MrssmDims)]),
     "mtrssm_mrssm_rollout_fwd_cluster": (C.c_int, [C.POINTER(MrssmDims), C.POINTER(MrssmClusterWeights), C.POINTER(MrssmFwdIO), _p, C.c_int64, _p]),
+    "mtrssm_mrssm_cluster_bwd_workspace_bytes": (C.c_int64, [C.POINTER(MrssmDims)]),
+    "mtrssm_mrssm_rollout_bwd_cluster": (C.c_int, [C.POINTER(MrssmDims), C.POINTER(MrssmClusterWeights), C.POINTER(MrssmBwdIO), _p, C.c_int64, _p]),
     "mtrssm_mrssm_rollout_bwd": (C.c_int, [C.POINTER(MrssmDims), C.POINTER(MrssmBwdWeights), C.POINTER(MrssmBwdIO), _p]),
     "mtrssm_mmtrssm_rollout_fwd": (C.c_int, [C.POINTER(MmtrssmDims), C.POINTER(MmtrssmFwdWeights), C.POINTER(MmtrssmFwdIO), _p]),
     "mtrssm_mmtrssm_rollout_bwd": (C.c_int, [C.POINTER(MmtrssmDims), C.POINTER(MmtrssmBwdWeights), C.POINTER(MmtrssmBwdIO), _p]),

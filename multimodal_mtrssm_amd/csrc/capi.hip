@@ -40,6 +40,8 @@ int gemm_launch(const MtrssmGemm*, hipStream_t);
 int debug_set_cluster_profile(void*);
 int mrssm_cluster_supported(const MtrssmMrssmDims*);
 size_t mrssm_cluster_workspace_bytes(const MtrssmMrssmDims*);
+size_t mrssm_cluster_bwd_workspace_bytes(const MtrssmMrssmDims*);
+int mrssm_bwd_cluster_launch(const MtrssmMrssmDims*, const MtrssmMrssmClusterWeights*, const MtrssmMrssmBwdIO*, void*, size_t, hipStream_t);
 int mrssm_fwd_cluster_launch(const MtrssmMrssmDims*, const MtrssmMrssmClusterWeights*, const MtrssmMrssmFwdIO*, void*, size_t, hipStream_t);
 int unpack_conv_grads_launch(const int64_t*, int, int, hipStream_t);
 int adamw_prepare_launch(const float*, int64_t, float*, float*, float, float, hipStream_t);
@@ -94,6 +96,11 @@ MTRSSM_API int mtrssm_mrssm_rollout_fwd_cluster(const MtrssmMrssmDims* d, const 
 }
 /* development aid, not part of the documented ABI (tools/cluster_probe.py) */
 extern "C" __attribute__((visibility("default"))) int mtrssm_debug_set_cluster_profile(void* buf) { return debug_set_cluster_profile(buf); }
+MTRSSM_API int64_t mtrssm_mrssm_cluster_bwd_workspace_bytes(const MtrssmMrssmDims* d) { return (int64_t)mrssm_cluster_bwd_workspace_bytes(d); }
+MTRSSM_API int mtrssm_mrssm_rollout_bwd_cluster(const MtrssmMrssmDims* d, const MtrssmMrssmClusterWeights* w, const MtrssmMrssmBwdIO* io,
+                                                void* workspace, int64_t workspace_bytes, void* stream) {
+  return mrssm_bwd_cluster_launch(d, w, io, workspace, workspace_bytes < 0 ? 0 : (size_t)workspace_bytes, static_cast<hipStream_t>(stream));
+}
 MTRSSM_API int mtrssm_gemm(const MtrssmGemm* g, void* stream) { return gemm_launch(g, static_cast<hipStream_t>(stream)); }
 MTRSSM_API int mtrssm_adamw_prepare(const float* grad, int64_t n, float* sumsq, float* state, float beta1, float beta2, void* stream) {
   return adamw_prepare_launch(grad, n, sumsq, state, beta1, beta2, static_cast<hipStream_t>(stream));

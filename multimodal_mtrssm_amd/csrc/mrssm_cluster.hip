@@ -344,6 +344,418 @@ __global__ __launch_bounds__(kCluThreads) void mrssm_fwd_cluster_kernel(const Mt
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// backward (reverse-time scan), same cluster layout.  Member m owns deter units [m UD, (m+1) UD) and UH units of each head.
+//   every member   categorical block, MoPoE mix, flat log-softmaxes backward  -> dlp, dla, dlv          (redundant)
+//   member m       dzh[own units] = act'(hd) * W2nd^T dl                        (columns of the second layers: registers)
+//   member m       partial dd[i] = sum_{own j} Wh1[j][i] dzh[j] for ALL i       (head matrix slice: LDS)   -> exchange 1:
+//                  publish D partials, gather the partials of the own units (4 x UD)
+//   member m       gates backward for the own units -> dgi, dgh (own 3 UD each)
+//   member m       partial carry_d[i] = sum_{own j} W_hh[j][i] dgh[j],  partial dh1[k] = sum_{own j} (W_ih W2)[j][k] dgi[j]
+//                  for ALL i, k (rows of the own columns: registers, pieces over all threads)               -> exchange 2:
+//                  publish 2 D partials, gather carry partials of the own units (4 x UD) and all dh1 partials (4 x D)
+//   every member   dz1 = act'(h1) * dh1,  carry_s = W1s dz1                                             (redundant)
+// d_h2 is NOT written (the fused input path has no h2 inside the scan): the caller forms it as d_gi . W_ih (one GEMM).
+// ------------------------------------------------------------------------------------------------
+template <int NJ, typename Map>
+__device__ __forceinline__ bool wave_gather_map(int total, unsigned epoch, int lane, Map map) {  // map(i, &slot, &dst)
+  unsigned done = 0;
+  const unsigned full = (1u << NJ) - 1u;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+    if (lane + 64 * j >= total) done |= 1u << j;
+  for (unsigned spins = 0;; ++spins) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      if (!(done & (1u << j))) {
+        const unsigned long long* slot;
+        float* dst;
+        map(lane + 64 * j, slot, dst);
+        const unsigned long long x = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(x >> 32) == epoch) {
+          *dst = __uint_as_float((unsigned)x);
+          done |= 1u << j;
+        }
+      }
+    }
+    if (__all(done == full)) return true;
+    if (spins > kSpinLimit) return false;
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+// NPB parts of KPB = 3 UD / NPB own gate columns per row piece; thread t holds row pieces t * PPT .. (row = piece / NPB of
+// the stacked [W_hh^T rows ; (W_ih W2)^T rows] (2 DH rows), part = piece % NPB).
+template <int DH, int NPB, int PPT>
+__global__ __launch_bounds__(kCluThreads) void mrssm_bwd_cluster_kernel(const MtrssmMrssmDims dm, const MtrssmMrssmClusterWeights w,
+                                                                        const MtrssmMrssmBwdIO io, unsigned long long* __restrict__ gran,
+                                                                        int* __restrict__ status, int nclusters) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int D = DH, H = DH;
+  constexpr int UD = D / kClu, UH = H / kClu;
+  constexpr int NG = 3 * UD, NH = 3 * UH;
+  constexpr int NHP = (NH + 3) & ~3;       // padded row of the head-matrix slice (16-byte aligned rows)
+  constexpr int KPB = NG / NPB;            // own gate columns per row piece
+  constexpr int NPIECE = 2 * DH * NPB;
+  constexpr int W1P = 8;                   // parts of the carry_s reduction over H
+  constexpr int KW1 = (DH + W1P - 1) / W1P;
+  static_assert(NG % NPB == 0 && KPB % 2 == 0, "row pieces are whole float2 runs");
+  static_assert(PPT * kCluThreads >= NPIECE, "every row piece has a thread");
+  const int K = dm.K, C = dm.C, S = K * C, T = dm.T, act = dm.act;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  const int blk = blockIdx.x;
+  const int member = (blk >> 3) & (kClu - 1);
+  const int cluster = (blk & 7) + 8 * (blk >> 5);
+  if (cluster >= nclusters) return;
+
+  int o = 0;
+  auto take = [&](int n) { const int r = o; o += (n + 3) & ~3; return r; };
+  const int Lla = take(S), Llv = take(S), Lmx = take(S), Llp = take(S), Ldmx = take(S), Ldlp = take(S), Ldla = take(S), Ldlv = take(S);
+  const int Lgps = take(S), Lcs = take(S);                   // g_post_stoch row, carry_s
+  const int Lhd = take(NHP), Ldzh = take(NHP);               // own head units: saved act, pre-activation gradient
+  const int Lgate = take(4 * UD), Ldprev = take(UD), Lgd = take(UD), Lcd = take(UD);   // own deter units
+  const int Ldg = take(2 * NG);                              // [dgi own | dgh own]
+  const int Lh1 = take(DH), Ldz1 = take(DH);
+  const int Lpdd = take(kClu * UD);                          // gathered dd partials of the own units
+  const int Lpcd = take(kClu * UD), Lpdh = take(kClu * DH);  // gathered carry / dh1 partials
+  const int Lred = take(NPIECE > DH ? NPIECE : DH);
+  const int Lred2 = take(W1P * 64 > 3 * 64 ? W1P * 64 : 3 * 64);
+  const int Lwh = take(D * NHP);                             // [i][own head unit]: this member's columns of the head layer 0
+  const int Lw2 = take(32 * NHP);                            // [s][own head unit]: this member's columns of the second layers
+  const int Lflag = take(4);
+  (void)o;
+  int* abort_flag = reinterpret_cast<int*>(lds + Lflag);
+  float* gk_lds = lds + Lflag + 1;
+
+  // ---- resident weights
+  // (a) row pieces of the own gate columns: rows of W_hh^T (carry_d) then rows of (W_ih W2)^T (dh1)
+  float wreg[PPT][KPB];
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int pc = tid * PPT + i;
+    const int pcc = pc < NPIECE ? pc : NPIECE - 1;
+    const int rowi = pcc / NPB, part = pcc - rowi * NPB;
+    const bool is_f = rowi >= DH;                                   // second half: rows of wf_t
+    const float* src = (is_f ? w.wf_t : w.whh_t) + (size_t)(is_f ? rowi - DH : rowi) * 3 * D;
+#pragma unroll
+    for (int k = 0; k < KPB; ++k) {
+      const int og = part * KPB + k;                                // own gate output g * UD + u
+      wreg[i][k] = src[(og / UD) * D + member * UD + (og % UD)];
+    }
+  }
+  // (b) the second layers' columns of the own head units, [s][unit] in LDS (thread j reads column j: conflict-free)
+  for (int idx = tid; idx < 32 * NHP; idx += kCluThreads) {
+    const int s2 = idx / NHP, j = idx - s2 * NHP;
+    float v = 0.f;
+    if (s2 < S && j < NH) {
+      const int which = j / UH, u = j - which * UH;
+      v = (which == 0 ? w.w4 : (which == 1 ? w.wa2 : w.wv2))[(size_t)s2 * H + member * UH + u];
+    }
+    lds[Lw2 + idx] = v;
+  }
+  // (c) thread (s, part) = (tid / W1P, tid % W1P), s < S: KW1 values of row s of W1s^T
+  float w1r[KW1];
+  {
+    const int srow = tid / W1P < S ? tid / W1P : 0, part = tid % W1P;
+#pragma unroll
+    for (int k = 0; k < KW1; ++k) {
+      const int kk = part * KW1 + k;
+      w1r[k] = w.w1s_t[(size_t)srow * H + (kk < H ? kk : H - 1)];
+    }
+  }
+  for (int idx = tid; idx < D * NHP; idx += kCluThreads) {
+    const int k = idx / NHP, oh = idx - k * NHP;
+    lds[Lwh + idx] = oh < NH ? w.wh1_t[(size_t)k * 3 * H + (oh / UH) * H + member * UH + (oh % UH)] : 0.f;
+  }
+  for (int i = tid; i < NHP; i += kCluThreads) { lds[Lhd + i] = 0.f; lds[Ldzh + i] = 0.f; }
+  if (tid == 0) *abort_flag = 0;
+
+  // granule slots of this cluster: [parity][ exchange 1: member x D | exchange 2: member x 2D ]
+  const int per_parity = kClu * 3 * D;
+  unsigned long long* gbase = gran + (size_t)cluster * 2 * per_parity;
+  unsigned epoch = 0;
+
+  for (int row = cluster; row < dm.B; row += nclusters) {
+    lds_barrier();
+    for (int i = tid; i < UD; i += kCluThreads) lds[Lcd + i] = 0.f;
+    for (int i = tid; i < S; i += kCluThreads) lds[Lcs + i] = 0.f;
+    lds_barrier();
+
+    for (int t = T - 1; t >= 0; --t) {
+      const size_t bt = (size_t)row * T + t;
+      unsigned long long* gpar = gbase + (size_t)(t & 1) * per_parity;
+
+      // (a) stage this step's saved vectors and incoming gradients (own parts)
+      for (int i = tid; i < 4 * S; i += kCluThreads) {
+        const int which = i / S, s2 = i - which * S;
+        const float* src = which == 0 ? io.sv_la : (which == 1 ? io.sv_lv : (which == 2 ? io.post_logits : io.prior_logits));
+        lds[(which == 0 ? Lla : (which == 1 ? Llv : (which == 2 ? Lmx : Llp))) + s2] = src[bt * S + s2];
+      }
+      if (tid < S) lds[Lgps + tid] = io.g_post_stoch ? io.g_post_stoch[bt * S + tid] : 0.f;
+      if (tid < NH) {
+        const int which = tid / UH, u = tid - which * UH;
+        lds[Lhd + tid] = io.sv_heads[bt * 3 * H + which * H + member * UH + u];
+      }
+      if (tid < 4 * UD) {
+        const int g = tid / UD, u = tid - g * UD;
+        lds[Lgate + tid] = io.sv_gates[bt * 4 * D + g * D + member * UD + u];
+      }
+      if (tid < H) lds[Lh1 + tid] = io.sv_h1[bt * H + tid];
+      if (tid < UD) {
+        const int unit = member * UD + tid;
+        lds[Ldprev + tid] = t > 0 ? io.deter[(bt - 1) * D + unit] : io.deter0[(size_t)row * D + unit];
+        lds[Lgd + tid] = io.g_deter ? io.g_deter[bt * D + unit] : 0.f;
+      }
+      if (tid == 0) *gk_lds = io.g_kl ? io.g_kl[bt] : 0.f;
+      lds_barrier();
+
+      // (b) categorical block: straight-through sample, KL, per-categorical softmax, MoE/PoE, flat log-softmax (one wave)
+      if (wave == 3) {
+        cat_block_bwd(lds + Lmx, lds + Llp, K, C, lane, lds + Lgps, lds + Lcs, io.g_prior_stoch ? io.g_prior_stoch + bt * S : nullptr,
+                      io.g_post_logits ? io.g_post_logits + bt * S : nullptr, io.g_prior_logits ? io.g_prior_logits + bt * S : nullptr,
+                      *gk_lds, dm.kl_w_post, dm.kl_w_prior, lds + Ldmx, lds + Ldlp);
+        wave_mopoe_mix_bwd(lds + Lla, lds + Llv, lds + Lmx, lds + Ldmx, lds + Ldla, lds + Ldlv, S, lane);
+        if (member == 0) {
+          for (int s2 = lane; s2 < S; s2 += kWave) {
+            io.d_la[bt * S + s2] = lds[Ldla + s2];
+            io.d_lv[bt * S + s2] = lds[Ldlv + s2];
+            io.d_lp[bt * S + s2] = lds[Ldlp + s2];
+          }
+        }
+      }
+      lds_barrier();
+
+      // (c) head layer 1 transposed, own units: dzh[j] = act'(hd[j]) * sum_s W[s][j] dl[s]
+      if (tid < NH) {
+        const int which = tid / UH;
+        const float* dl = lds + (which == 0 ? Ldlp : (which == 1 ? Ldla : Ldlv));
+        const float* wc2 = lds + Lw2 + tid;
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < 32; s2 += 2) {  // rows s >= S of the LDS image are zero
+          a0 = fmaf(wc2[s2 * NHP], s2 < S ? dl[s2] : 0.f, a0);
+          a1 = fmaf(wc2[(s2 + 1) * NHP], s2 + 1 < S ? dl[s2 + 1] : 0.f, a1);
+        }
+        const float g = (a0 + a1) * act_grad_from_out(lds[Lhd + tid], act);
+        lds[Ldzh + tid] = g;
+        const int u = tid - which * UH;
+        io.d_zh[bt * 3 * H + which * H + member * UH + u] = g;
+      }
+      lds_barrier();
+
+      // (d) partial dd[i] over the own head units, for ALL i; publish (exchange 1)
+      ++epoch;
+      if (tid < D) {
+        const float* wr = lds + Lwh + (size_t)tid * NHP;
+        const float* dz = lds + Ldzh;
+        float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NHP; j += 4) {
+          const float4 a = *reinterpret_cast<const float4*>(wr + j);
+          const float4 b = *reinterpret_cast<const float4*>(dz + j);
+          p0 = fmaf(a.x, b.x, p0); p1 = fmaf(a.y, b.y, p1); p2 = fmaf(a.z, b.z, p2); p3 = fmaf(a.w, b.w, p3);
+        }
+        granule_store(gpar + (size_t)member * D + tid, epoch, (p0 + p1) + (p2 + p3));
+      }
+      if (wave == 3) {  // the four members' partials for the own units
+        const bool ok = wave_gather_map<4>(kClu * UD, epoch, lane, [&](int i, const unsigned long long*& slot, float*& dst) {
+          const int m2 = i / UD, u = i - m2 * UD;
+          slot = gpar + (size_t)m2 * D + member * UD + u;
+          dst = lds + Lpdd + i;
+        });
+        if (!ok && lane == 0) { *abort_flag = 1; atomicExch(status, 1 + 2 * t); }
+      }
+      lds_barrier();
+      if (*abort_flag) return;
+
+      // (e) GRU gate gradients of the own units
+      if (tid < UD) {
+        float dd = lds[Lgd + tid] + lds[Lcd + tid];
+#pragma unroll
+        for (int m2 = 0; m2 < kClu; ++m2) dd += lds[Lpdd + m2 * UD + tid];
+        const float rg = lds[Lgate + tid], zg = lds[Lgate + UD + tid], ng = lds[Lgate + 2 * UD + tid], ghn = lds[Lgate + 3 * UD + tid];
+        const float dprev = lds[Ldprev + tid];
+        const float dn = dd * (1.f - zg);
+        const float dz = dd * (dprev - ng);
+        const float dn_pre = dn * (1.f - ng * ng);
+        const float dr = dn_pre * ghn;
+        const float dr_pre = dr * rg * (1.f - rg);
+        const float dz_pre = dz * zg * (1.f - zg);
+        lds[Lcd + tid] = dd * zg;  // direct path into d_prev; the W_hh path is added after exchange 2
+        lds[Ldg + tid] = dr_pre; lds[Ldg + UD + tid] = dz_pre; lds[Ldg + 2 * UD + tid] = dn_pre;
+        lds[Ldg + NG + tid] = dr_pre; lds[Ldg + NG + UD + tid] = dz_pre; lds[Ldg + NG + 2 * UD + tid] = dn_pre * rg;
+        const int unit = member * UD + tid;
+        float* gi = io.d_gi + bt * 3 * D;
+        float* gh = io.d_gh + bt * 3 * D;
+        gi[unit] = dr_pre; gi[D + unit] = dz_pre; gi[2 * D + unit] = dn_pre;
+        gh[unit] = dr_pre; gh[D + unit] = dz_pre; gh[2 * D + unit] = dn_pre * rg;
+      }
+      lds_barrier();
+
+      // (f) row pieces: partial carry_d[i] (W_hh^T rows times dgh) and partial dh1[k] ((W_ih W2)^T rows times dgi)
+#pragma unroll
+      for (int i = 0; i < PPT; ++i) {
+        const int pc = tid * PPT + i;
+        const int pcc = pc < NPIECE ? pc : NPIECE - 1;
+        const int rowi = pcc / NPB, part = pcc - rowi * NPB;
+        const float* xv = lds + Ldg + (rowi >= DH ? 0 : NG) + part * KPB;
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < KPB; k += 2) {
+          const float2 x = *reinterpret_cast<const float2*>(xv + k);
+          a0 = fmaf(wreg[i][k], x.x, a0);
+          a1 = fmaf(wreg[i][k + 1], x.y, a1);
+        }
+        if (pc < NPIECE) lds[Lred + pc] = a0 + a1;
+      }
+      lds_barrier();
+      ++epoch;
+      unsigned long long* g2 = gpar + (size_t)kClu * D;
+      for (int r2 = tid; r2 < 2 * DH; r2 += kCluThreads) {
+        float a = 0.f;
+#pragma unroll
+        for (int q = 0; q < NPB; ++q) a += lds[Lred + r2 * NPB + q];
+        granule_store(g2 + (size_t)member * 2 * D + r2, epoch, a);
+      }
+      // exchange 2: wave 1 the carry partials of the own units, waves 2 and 3 the dh1 partials of two members each
+      if (wave >= 1) {
+        bool ok;
+        if (wave == 1) {
+          ok = wave_gather_map<4>(kClu * UD, epoch, lane, [&](int i, const unsigned long long*& slot, float*& dst) {
+            const int m2 = i / UD, u = i - m2 * UD;
+            slot = g2 + (size_t)m2 * 2 * D + member * UD + u;
+            dst = lds + Lpcd + i;
+          });
+        } else {
+          const int mb = (wave - 2) * 2;
+          ok = wave_gather_map<(2 * DH + 63) / 64>(2 * DH, epoch, lane, [&](int i, const unsigned long long*& slot, float*& dst) {
+            const int m2 = mb + i / DH, k = i % DH;
+            slot = g2 + (size_t)m2 * 2 * D + D + k;
+            dst = lds + Lpdh + m2 * DH + k;
+          });
+        }
+        if (!ok && lane == 0) { *abort_flag = 1; atomicExch(status, 2 + 2 * t); }
+      }
+      lds_barrier();
+      if (*abort_flag) return;
+
+      // (g) carry_d of the own units; dz1 = act'(h1) * dh1 (all H, every member)
+      if (tid < UD) {
+        float a = lds[Lcd + tid];
+#pragma unroll
+        for (int m2 = 0; m2 < kClu; ++m2) a += lds[Lpcd + m2 * UD + tid];
+        lds[Lcd + tid] = a;
+      }
+      if (tid < H) {
+        float a = 0.f;
+#pragma unroll
+        for (int m2 = 0; m2 < kClu; ++m2) a += lds[Lpdh + m2 * DH + tid];
+        const float g = a * act_grad_from_out(lds[Lh1 + tid], act);
+        lds[Ldz1 + tid] = g;
+        if (member == 0) io.d_z1[bt * H + tid] = g;
+      }
+      lds_barrier();
+      // (h) carry_s[s] = sum_k W1s[s][k] dz1[k]: W1P partial sums per s, then their sum
+      {
+        const int srow = tid / W1P, part = tid % W1P;
+        if (srow < S) {
+          float a0 = 0.f;
+#pragma unroll
+          for (int k = 0; k < KW1; ++k) {
+            const int kk = part * KW1 + k;
+            a0 = fmaf(w1r[k], kk < H ? lds[Ldz1 + kk] : 0.f, a0);
+          }
+          lds[Lred2 + srow * W1P + part] = a0;
+        }
+      }
+      lds_barrier();
+      if (tid < S) {
+        float a = 0.f;
+#pragma unroll
+        for (int q = 0; q < W1P; ++q) a += lds[Lred2 + tid * W1P + q];
+        lds[Lcs + tid] = a;
+      }
+      lds_barrier();
+    }
+    if (tid < UD) io.g_deter0[(size_t)row * D + member * UD + tid] = lds[Lcd + tid];
+    if (member == 0 && tid < S) io.g_stoch0[(size_t)row * S + tid] = lds[Lcs + tid];
+  }
+}
+
+static int cluster_npb(int DH) { return (DH == 200 || DH == 128) ? 3 : 1; }
+
+static size_t cluster_bwd_lds_floats(int DH, int S) {
+  const int UD = DH / kClu, NG = 3 * UD, NH = NG, NHP = (NH + 3) & ~3, NPB = cluster_npb(DH), NPIECE = 2 * DH * NPB;
+  size_t o = 0;
+  auto take = [&](size_t n) { o += (n + 3) & ~(size_t)3; };
+  for (int i = 0; i < 10; ++i) take(S);
+  take(NHP); take(NHP);
+  take((size_t)4 * UD); take(UD); take(UD); take(UD);
+  take((size_t)2 * NG);
+  take(DH); take(DH);
+  take((size_t)kClu * UD);
+  take((size_t)kClu * UD); take((size_t)kClu * DH);
+  take((size_t)(NPIECE > DH ? NPIECE : DH));
+  take((size_t)(8 * 64));
+  take((size_t)DH * NHP);
+  take((size_t)32 * NHP);
+  take(4);
+  return o;
+}
+
+size_t mrssm_cluster_bwd_workspace_bytes(const MtrssmMrssmDims* d) {
+  if (!d || d->B <= 0 || d->D <= 0) return 0;
+  const int nclusters = d->B < 64 ? d->B : 64;
+  return 16 + (size_t)nclusters * 2 * (size_t)kClu * 3 * d->D * sizeof(unsigned long long);
+}
+
+int mrssm_cluster_supported(const MtrssmMrssmDims* d);
+
+int mrssm_bwd_cluster_launch(const MtrssmMrssmDims* d, const MtrssmMrssmClusterWeights* w, const MtrssmMrssmBwdIO* io, void* workspace,
+                             size_t workspace_bytes, hipStream_t stream) {
+  if (!mrssm_cluster_supported(d) || d->K * d->C > 32) {
+    set_error("mrssm_rollout_bwd_cluster: dims outside the cluster kernel's regime (ask mtrssm_mrssm_cluster_supported first; S <= 32)");
+    return MTRSSM_EINVAL;
+  }
+  if (!w || !io || !workspace || !w->w1s_t || !w->wf_t || !w->whh_t || !w->wh1_t || !w->w4 || !w->wa2 || !w->wv2 || !io->deter0 ||
+      !io->deter || !io->prior_logits || !io->post_logits || !io->sv_h1 || !io->sv_gates || !io->sv_heads || !io->sv_la || !io->sv_lv ||
+      !io->g_deter0 || !io->g_stoch0 || !io->d_z1 || !io->d_gi || !io->d_gh || !io->d_zh || !io->d_lp || !io->d_la || !io->d_lv) {
+    set_error("mrssm_rollout_bwd_cluster: null required pointer");
+    return MTRSSM_EINVAL;
+  }
+  if (workspace_bytes < mrssm_cluster_bwd_workspace_bytes(d) || ((uintptr_t)workspace & 15)) {
+    set_error("mrssm_rollout_bwd_cluster: workspace too small (%zu < %zu) or not 16-byte aligned", workspace_bytes,
+              mrssm_cluster_bwd_workspace_bytes(d));
+    return MTRSSM_EINVAL;
+  }
+  const int nclusters = d->B < 64 ? d->B : 64;
+  const int grid = ((nclusters + 7) / 8) * 32;
+  const size_t lds = cluster_bwd_lds_floats(d->D, d->K * d->C) * sizeof(float);
+  if (lds > 160 * 1024) { set_error("mrssm_rollout_bwd_cluster: %zu bytes of LDS", lds); return MTRSSM_ELDS; }
+  hipError_t e = hipMemsetAsync(workspace, 0, mrssm_cluster_bwd_workspace_bytes(d), stream);
+  if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return MTRSSM_ELAUNCH; }
+  int* status = reinterpret_cast<int*>(workspace);
+  unsigned long long* gran = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(workspace) + 16);
+#define MTRSSM_CLUB_LAUNCH(DHV, NPV, PPTV)                                                                                         \
+  {                                                                                                                               \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(mrssm_bwd_cluster_kernel<DHV, NPV, PPTV>),                              \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                               \
+    if (e != hipSuccess) { set_error("hipFuncSetAttribute(max dynamic LDS=%zu): %s", lds, hipGetErrorString(e)); return MTRSSM_ELAUNCH; } \
+    set_last_kernel("mtrssm::mrssm_bwd_cluster_kernel<" #DHV ", " #NPV ", " #PPTV ">");                                          \
+    hipLaunchKernelGGL((mrssm_bwd_cluster_kernel<DHV, NPV, PPTV>), dim3(grid), dim3(kCluThreads), lds, stream, *d, *w, *io, gran,   \
+                       status, nclusters);                                                                                        \
+  }
+  // row pieces per thread = ceil(2 DH NPB / 256)
+  if (d->D == 32) MTRSSM_CLUB_LAUNCH(32, 1, 1)
+  else if (d->D == 64) MTRSSM_CLUB_LAUNCH(64, 1, 1)
+  else if (d->D == 128) MTRSSM_CLUB_LAUNCH(128, 3, 3)
+  else MTRSSM_CLUB_LAUNCH(200, 3, 5)
+#undef MTRSSM_CLUB_LAUNCH
+  e = hipGetLastError();
+  if (e != hipSuccess) { set_error("cluster backward scan launch failed: %s", hipGetErrorString(e)); return MTRSSM_ELAUNCH; }
+  return MTRSSM_OK;
+}
+
 int debug_set_cluster_profile(void* buf) {
   unsigned long long* p = static_cast<unsigned long long*>(buf);
   return hipMemcpyToSymbol(HIP_SYMBOL(g_cluster_prof), &p, sizeof(p)) == hipSuccess ? MTRSSM_OK : MTRSSM_ELAUNCH;

@@ -195,7 +195,9 @@ class _MrssmScan(torch.autograd.Function):
                                         C.byref(io), _lib.raw_ptr(ws), ws.numel() * 8, _lib.stream_ptr(xa.device),
                                         flops=2.0 * B * T * macs, nbytes=4.0 * B * T * per_bt), "mtrssm_mrssm_rollout_fwd_cluster")
             sv["sv_h2"] = None
+            ctx.cluster_w = (wf_t, fw._refs["whh_t"], fw._refs["wh1_t"])  # noqa: SLF001
         else:
+            ctx.cluster_w = None
             _lib.check(_lib.TIMERS.call("mtrssm_mrssm_rollout_fwd", lib.mtrssm_mrssm_rollout_fwd, C.byref(dims), C.byref(fw), C.byref(io),
                                         _lib.stream_ptr(xa.device), flops=2.0 * B * T * macs, nbytes=4.0 * B * T * per_bt),
                        "mtrssm_mrssm_rollout_fwd")
@@ -241,9 +243,25 @@ class _MrssmScan(torch.autograd.Function):
         dims = _lib.MrssmDims(B, T, D, H, cfg.cats, cfg.classes, cfg.act, 1, wp, wq, cfg.rows_per_block, cfg.threads)
         per_bt = (2 * H + 4 * D + 3 * H + 2 * S) + D + 2 * S + (D + S + 1) + 2 * H + 6 * D + 3 * H + 3 * S
         macs = S * H + H * H + 3 * D * H + 3 * D * D + 3 * H * D + 3 * S * H
-        _lib.check(_lib.TIMERS.call("mtrssm_mrssm_rollout_bwd", lib.mtrssm_mrssm_rollout_bwd, C.byref(dims), C.byref(bw), C.byref(io),
-                                     _lib.stream_ptr(deter.device), flops=2.0 * B * T * macs, nbytes=4.0 * B * T * per_bt),
-                   "mtrssm_mrssm_rollout_bwd")
+        cw3 = getattr(ctx, "cluster_w", None)
+        if cw3 is not None and CLUSTER_SCAN and cfg.classes * cfg.cats <= 32:  # noqa: PLR2004
+            # the forward ran on four-CU clusters: so does the reverse scan (same resident-weight layout, csrc/mrssm_cluster.hip)
+            wf_t, whh_t, wh1_t = cw3
+            cw = _lib.fill(_lib.MrssmClusterWeights(), w1s_t=w1s_t, wf_t=wf_t, whh_t=whh_t, wh1_t=wh1_t, w4=_c(w4), wa2=_c(wa2), wv2=_c(wv2))
+            nbytes_ws = int(lib.mtrssm_mrssm_cluster_bwd_workspace_bytes(C.byref(dims)))
+            key = ("bwd", deter.device, _lib.stream_ptr(deter.device), B, D, S)
+            ws = _CLUSTER_WS.get(key)
+            if ws is None or ws.numel() * 8 < nbytes_ws:
+                ws = _CLUSTER_WS[key] = torch.zeros((nbytes_ws + 7) // 8, device=deter.device, dtype=torch.int64)
+            _lib.check(_lib.TIMERS.call("mtrssm_mrssm_rollout_bwd_cluster", lib.mtrssm_mrssm_rollout_bwd_cluster, C.byref(dims), C.byref(cw),
+                                        C.byref(io), _lib.raw_ptr(ws), ws.numel() * 8, _lib.stream_ptr(deter.device),
+                                        flops=2.0 * B * T * macs, nbytes=4.0 * B * T * per_bt), "mtrssm_mrssm_rollout_bwd_cluster")
+            # d_h2 = d_gi . W_ih for all (b, t) at once (the fused input path has no h2 inside the scan)
+            gemm(_flat2(d_gi), wih, _flat2(d_h2), a_rmajor=False, b_rmajor=True)
+        else:
+            _lib.check(_lib.TIMERS.call("mtrssm_mrssm_rollout_bwd", lib.mtrssm_mrssm_rollout_bwd, C.byref(dims), C.byref(bw), C.byref(io),
+                                        _lib.stream_ptr(deter.device), flops=2.0 * B * T * macs, nbytes=4.0 * B * T * per_bt),
+                       "mtrssm_mrssm_rollout_bwd")
 
         # ---- weight gradients: one [out, B*T] x [B*T, in] GEMM each (csrc/gemm.hip), bias gradients in the same launches -----
         prev_stoch = _flat2(torch.cat([stoch0.unsqueeze(1), post_stoch[:, :-1]], dim=1))
