@@ -38,8 +38,15 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f
 # MFMA instructions issued per algorithmic multiply-add block, by conv MFMA mode (csrc/conv_split.h)
 MFMA_PRODUCTS = {"f32": 1, "bf16x3": 6, "bf16x2": 3, "bf16": 1}
 
-WORKLOAD = dict(batch_per_gpu=64, steps=50, deter=200, hidden=200, classes=5, cats=6, action=4, embed=256,
-                vision=(1, 64, 64), audio=(1, 128, 32))
+WORKLOADS = {
+    # BASELINE configs[1] / configs[2]: the metric's config
+    "base": dict(batch_per_gpu=64, steps=50, deter=200, hidden=200, classes=5, cats=6, action=4, embed=256,
+                 vision=(1, 64, 64), audio=(1, 128, 32)),
+    # BASELINE configs[4] "Large" (deter = 1024, stoch = 128 = 16 x 8, B = 256, T = 100 on 8 GPUs): the per-GPU shard, B = 32
+    "large": dict(batch_per_gpu=32, steps=100, deter=1024, hidden=1024, classes=8, cats=16, action=4, embed=1024,
+                  vision=(1, 64, 64), audio=(1, 128, 32)),
+}
+WORKLOAD = WORKLOADS["base"]  # main() switches it for --model large
 
 
 def build_model(device: str, kind: str = "mrssm"):  # noqa: ANN201
@@ -48,6 +55,7 @@ def build_model(device: str, kind: str = "mrssm"):  # noqa: ANN201
 
     w = WORKLOAD
     torch.manual_seed(42)  # yaml: seed_everything: 42
+    kind = "mrssm" if kind == "large" else kind
     if kind == "mmtrssm":  # BASELINE configs[2]: two-timescale MTState variant, same dims (ld = hd = 200, ls = hs = 30)
         feat = 2 * (w["deter"] + w["classes"] * w["cats"])
         model = mt.make_mmtrssm(
@@ -108,7 +116,7 @@ def oracle_model(kind: str):  # noqa: ANN201
     """The oracle (oracle/ref_model.py) at the bench's exact dims -- the CHECKER: used by cpu_baseline() and elbo_delta() only."""
     from oracle.cases import CASES, build_model
 
-    case = CASES["mrssm_bench" if kind == "mrssm" else "mmtrssm_bench"]
+    case = CASES[{"mrssm": "mrssm_bench", "mmtrssm": "mmtrssm_bench", "large": "mrssm_large_bench"}[kind]]
     return case, build_model(case)
 
 
@@ -128,7 +136,7 @@ def cpu_baseline(kind: str, seconds_budget: float = 30.0) -> dict[str, object]:
 
     def step() -> None:
         opt.zero_grad()
-        out = model.shared_step(batch, noise, wasteful=True) if kind == "mrssm" else model.shared_step(batch, noise)
+        out = model.shared_step(batch, noise, wasteful=True) if kind != "mmtrssm" else model.shared_step(batch, noise)
         out["loss"].backward()
         torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
         opt.step()
@@ -234,8 +242,9 @@ def parse_args() -> argparse.Namespace:
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-elbo-check", action="store_true")
-    ap.add_argument("--model", choices=("mrssm", "mmtrssm"), default="mrssm",
-                    help="mrssm = BASELINE configs[1] (the metric's config); mmtrssm = configs[2] (MTState variant)")
+    ap.add_argument("--model", choices=("mrssm", "mmtrssm", "large"), default="mrssm",
+                    help="mrssm = BASELINE configs[1] (the metric's config); mmtrssm = configs[2] (MTState variant); large = the "
+                         "per-GPU shard of configs[4] (MoPoE-MRSSM deter = hidden = embed = 1024, stoch 16 x 8, B = 32, T = 100)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group even for one rank (exercises the N>1 code path)")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="nccl = RCCL over xGMI (the product path); gloo only to rehearse the launcher and the sharded step on a box with fewer GPUs")
@@ -257,6 +266,8 @@ DTYPE_LABEL = {"bf16x2": "bf16x2-split, fp32 accumulate", "bf16x3": "bf16x3-spli
 
 def main() -> None:  # noqa: PLR0914, PLR0915
     args = parse_args()
+    global WORKLOAD  # noqa: PLW0603
+    WORKLOAD = WORKLOADS["large" if args.model == "large" else "base"]
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_workers(args.gpus))  # nothing above touched the GPU
 
@@ -405,7 +416,8 @@ def main() -> None:  # noqa: PLR0914, PLR0915
                                "tflops": round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 2) if v["total_ms"] else None}
                            for k, v in sorted(kernel_ms.items(), key=lambda kv: -kv[1]["total_ms"])}
         line = {
-            "metric": "seq-steps/s (BxT) MoPoE-MRSSM train step" if args.model == "mrssm" else "seq-steps/s (BxT) MoPoE-MMTRSSM train step",
+            "metric": {"mrssm": "seq-steps/s (BxT) MoPoE-MRSSM train step", "mmtrssm": "seq-steps/s (BxT) MoPoE-MMTRSSM train step",
+                       "large": "seq-steps/s (BxT) MoPoE-MRSSM Large train step"}[args.model],
             "value": seq_steps / (elapsed / args.steps),
             "unit": "seq-steps/s",
             "n_gpus": world,
@@ -419,9 +431,10 @@ def main() -> None:  # noqa: PLR0914, PLR0915
             "dtype": DTYPE_LABEL[args.conv_mfma],
             "data": "synthetic",
             "config": {
-                "workload": ("BASELINE configs[1]: MoPoE-MRSSM train step, B=64/GPU T=50 deter=200 stoch=30, vision 1x64x64 + audio 1x128x32 + action 4"
-                             if args.model == "mrssm" else
-                             "BASELINE configs[2]: MoPoE-MMTRSSM (MTState, tau 2/4) train step, B=64/GPU T=50 ld=hd=200 ls=hs=30, same frames"),
+                "workload": {"mrssm": "BASELINE configs[1]: MoPoE-MRSSM train step, B=64/GPU T=50 deter=200 stoch=30, vision 1x64x64 + audio 1x128x32 + action 4",
+                             "mmtrssm": "BASELINE configs[2]: MoPoE-MMTRSSM (MTState, tau 2/4) train step, B=64/GPU T=50 ld=hd=200 ls=hs=30, same frames",
+                             "large": "BASELINE configs[4] per-GPU shard: MoPoE-MRSSM Large train step, B=32/GPU (256 on 8) T=100 deter=hidden=embed=1024 "
+                                      "stoch=128 (16x8), vision 1x64x64 + audio 1x128x32 + action 4"}[args.model],
                 "global_batch": b * world, "seq_len": t, "parallelism": f"dp{world}",
                 "hidden": w["hidden"], "embed": w["embed"], "categoricals_x_classes": f"{w['cats']}x{w['classes']}",
                 "enc_channels": [8, 16, 32], "dec_channels": [32, 16, 1], "residual_blocks": 3, "activation": "ELU",
@@ -446,7 +459,7 @@ def main() -> None:  # noqa: PLR0914, PLR0915
             line["elbo_check"] = delta
         if world == 1:
             line["data_feed"] = feed_benchmark(device)
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.model != "large":  # (Large: one CPU step takes minutes)
             base = cpu_baseline(args.model)
             line["cpu_baseline"] = base
             line["speedup_vs_cpu"] = line["value"] / base["value"]

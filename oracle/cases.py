@@ -157,7 +157,7 @@ CASES: dict[str, Case] = {
     ),
     "mmtrssm_large": Case(
         "mmtrssm_large", "mmtrssm",
-        _mmtrssm_dims(512, (8, 16), 512, (8, 16), 512, 4, 512, (1, 16, 8), (1, 8, 8), **_SMALL), 3, 4, (1, 16, 8), (1, 8, 8), query=2,
+        _mmtrssm_dims(1024, (8, 16), 1024, (8, 16), 1024, 4, 1024, (1, 16, 8), (1, 8, 8), **_SMALL), 3, 4, (1, 16, 8), (1, 8, 8), query=2,
     ),
     # BASELINE configs[1] / configs[2] EXACTLY as bench.py builds them (bench.WORKLOAD): 1x128x32 audio + 1x64x64 vision
     # frames, conv channels [8,16,32] / [32,16,1], 3 residual blocks (64 / 128 intermediate channels), deter = hidden = 200,
@@ -170,6 +170,11 @@ CASES: dict[str, Case] = {
     "mmtrssm_bench": Case(
         "mmtrssm_bench", "mmtrssm",
         _mmtrssm_dims(200, (5, 6), 200, (5, 6), 200, 4, 256, (1, 128, 32), (1, 64, 64)), 2, 50, (1, 128, 32), (1, 64, 64), query=25,
+    ),
+    # BASELINE configs[4] "Large" with the bench's frames (bench.py --model large): two sequences, T = 100
+    "mrssm_large_bench": Case(
+        "mrssm_large_bench", "mrssm",
+        _mrssm_dims(1024, 1024, 8, 16, 4, 1024, (1, 128, 32), (1, 64, 64)), 2, 100, (1, 128, 32), (1, 64, 64), query=50,
     ),
 }
 
