@@ -106,6 +106,8 @@ __global__ __launch_bounds__(kCluThreads) void mrssm_fwd_cluster_kernel(const Mt
   const int Lred = take(NPIECE > NH * NP ? NPIECE : NH * NP);   // per-piece partial sums
   const int Lw1 = take(S * H);            // W1s^T [S][H]
   const int Lwh = take(D * NH);           // [k][o]: this member's columns of the head layer 0
+  const int Lbl = take(3 * S);            // biases of the 3 S logits
+  const int Lu = take(2 * 64);            // this step's uniforms: posterior [K], prior [K]
   const int Lflag = take(4);
   (void)o;
   int* abort_flag = reinterpret_cast<int*>(lds + Lflag);
@@ -142,6 +144,10 @@ __global__ __launch_bounds__(kCluThreads) void mrssm_fwd_cluster_kernel(const Mt
     lds[Lwh + idx] = w.wh1_t[(size_t)k * 3 * H + (oh / UH) * H + member * UH + (oh % UH)];
   }
   for (int i = tid; i < 3 * 64; i += kCluThreads) lds[Lhd + i] = 0.f;
+  for (int i = tid; i < 3 * S; i += kCluThreads) {
+    const int which = i / S, s2 = i - which * S;
+    lds[Lbl + i] = (which == 0 ? w.b4 : (which == 1 ? w.ba2 : w.bv2))[s2];
+  }
   // per-thread constants of the finishing threads
   float bias_g[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // thread u < UD: bf / bhh of its three gates
   if (tid < UD) {
@@ -168,16 +174,27 @@ __global__ __launch_bounds__(kCluThreads) void mrssm_fwd_cluster_kernel(const Mt
     for (int i = tid; i < S; i += kCluThreads) lds[Ls + i] = io.stoch0[(size_t)row * S + i];
     lds_barrier();
 
+    // The streamed inputs of a step (xa, pa / pv of the own head units, the uniforms) are loaded one step AHEAD into registers:
+    // loaded at the top of the step that consumes them, their HBM latency (~1 us) sat on the step's critical path.
+    auto load_inputs = [&](size_t q, float& xa_r, float& pa_r, float& up_r, float& ur_r) {
+      xa_r = tid < H ? io.xa[q * H + tid] : 0.f;
+      pa_r = 0.f;
+      if (tid >= UH && tid < NH) {
+        const int which = tid / UH, u = tid - which * UH;
+        pa_r = (which == 1 ? io.pa : io.pv)[q * H + member * UH + u];
+      }
+      up_r = (wave == 3 && lane < K) ? io.u_post[q * K + lane] : 0.f;
+      ur_r = (wave == 3 && lane < K && io.u_prior) ? io.u_prior[q * K + lane] : 0.f;
+    };
+    float xa_n, pav_n, up_n, ur_n;
+    load_inputs((size_t)row * T, xa_n, pav_n, up_n, ur_n);
+
     for (int t = 0; t < T; ++t) {
       const size_t bt = (size_t)row * T + t;
       unsigned long long* gpar = gbase + (size_t)(t & 1) * per_parity;
-      // early loads of this step's streamed inputs (consumed several barriers later)
-      const float xa_v = tid < H ? io.xa[bt * H + tid] : 0.f;
-      float pav = 0.f;
-      if (tid >= UH && tid < NH) {
-        const int which = tid / UH, u = tid - which * UH;
-        pav = (which == 1 ? io.pa : io.pv)[bt * H + member * UH + u];
-      }
+      const float xa_v = xa_n, pav = pav_n;
+      if (wave == 3 && lane < K) { lds[Lu + lane] = up_n; lds[Lu + 64 + lane] = ur_n; }
+      if (t + 1 < T) load_inputs(bt + 1, xa_n, pav_n, up_n, ur_n);
 
       MTRSSM_CLU_STAMP(0);
       // (1) h1 = act(xa + W1s s): every member, all H outputs                    networks.py:165-166
@@ -317,7 +334,7 @@ __global__ __launch_bounds__(kCluThreads) void mrssm_fwd_cluster_kernel(const Mt
         const bool writer = member == 0;
         for (int i = lane; i < 3 * S; i += kWave) {
           const int which = i / S, s2 = i - which * S;
-          float v = (which == 0 ? w.b4 : (which == 1 ? w.ba2 : w.bv2))[s2];
+          float v = lds[Lbl + i];
 #pragma unroll
           for (int m2 = 0; m2 < kClu; ++m2) v += lds[Lpart + m2 * 3 * S + i];
           lds[(which == 0 ? Llp : (which == 1 ? Lla : Llv)) + s2] = v;
@@ -330,8 +347,8 @@ __global__ __launch_bounds__(kCluThreads) void mrssm_fwd_cluster_kernel(const Mt
             if (io.sv_la) { io.sv_la[bt * S + s] = lds[Lla + s]; io.sv_lv[bt * S + s] = lds[Llv + s]; }
           }
         }
-        float kl = cat_block_fwd<true, true>(lds + Lmx, lds + Llp, K, C, lane, io.u_post + bt * K, io.u_prior ? io.u_prior + bt * K : nullptr,
-                                             lds + Ls, io.post_stoch + bt * S, io.prior_stoch ? io.prior_stoch + bt * S : nullptr, writer);
+        float kl = cat_block_fwd<true, true>(lds + Lmx, lds + Llp, K, C, lane, lds + Lu, io.u_prior ? lds + Lu + 64 : nullptr, lds + Ls,
+                                             io.post_stoch + bt * S, io.prior_stoch ? io.prior_stoch + bt * S : nullptr, writer);
         if (io.kl) {
           kl = wave_sum(kl);
           if (lane == 0 && writer) io.kl[bt] = kl;
@@ -481,32 +498,59 @@ __global__ __launch_bounds__(kCluThreads) void mrssm_bwd_cluster_kernel(const Mt
     for (int i = tid; i < S; i += kCluThreads) lds[Lcs + i] = 0.f;
     lds_barrier();
 
+    // staged values of one step, five registers per thread: r0 logits (4 S), r1 head units (NH) | g_post_stoch (S, threads
+    // NH..), r2 gates (4 UD) | g_kl (thread 4 UD), r3 h1 (H), r4 d_prev (UD) | g_deter (UD, threads 64..)
+    float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f, r4 = 0.f;
+    auto stage_load = [&](int tt) {
+      const size_t q = (size_t)row * T + tt;
+      if (tid < 4 * S) {
+        const int which = tid / S, s2 = tid - which * S;
+        const float* src = which == 0 ? io.sv_la : (which == 1 ? io.sv_lv : (which == 2 ? io.post_logits : io.prior_logits));
+        r0 = src[q * S + s2];
+      }
+      if (tid < NH) {
+        const int which = tid / UH, u = tid - which * UH;
+        r1 = io.sv_heads[q * 3 * H + which * H + member * UH + u];
+      } else if (tid < NH + S) {
+        r1 = io.g_post_stoch ? io.g_post_stoch[q * S + (tid - NH)] : 0.f;
+      }
+      if (tid < 4 * UD) {
+        const int g = tid / UD, u = tid - g * UD;
+        r2 = io.sv_gates[q * 4 * D + g * D + member * UD + u];
+      } else if (tid == 4 * UD) {
+        r2 = io.g_kl ? io.g_kl[q] : 0.f;
+      }
+      if (tid < H) r3 = io.sv_h1[q * H + tid];
+      if (tid < UD) {
+        const int unit = member * UD + tid;
+        r4 = tt > 0 ? io.deter[(q - 1) * D + unit] : io.deter0[(size_t)row * D + unit];
+      } else if (tid >= 64 && tid < 64 + UD) {
+        r4 = io.g_deter ? io.g_deter[q * D + member * UD + (tid - 64)] : 0.f;
+      }
+    };
+    auto stage_store = [&]() {
+      if (tid < 4 * S) {
+        const int which = tid / S, s2 = tid - which * S;
+        lds[(which == 0 ? Lla : (which == 1 ? Llv : (which == 2 ? Lmx : Llp))) + s2] = r0;
+      }
+      if (tid < NH) lds[Lhd + tid] = r1;
+      else if (tid < NH + S) lds[Lgps + tid - NH] = r1;
+      if (tid < 4 * UD) lds[Lgate + tid] = r2;
+      else if (tid == 4 * UD) *gk_lds = r2;
+      if (tid < H) lds[Lh1 + tid] = r3;
+      if (tid < UD) lds[Ldprev + tid] = r4;
+      else if (tid >= 64 && tid < 64 + UD) lds[Lgd + tid - 64] = r4;
+    };
+    stage_load(T - 1);
+
     for (int t = T - 1; t >= 0; --t) {
       const size_t bt = (size_t)row * T + t;
       unsigned long long* gpar = gbase + (size_t)(t & 1) * per_parity;
 
-      // (a) stage this step's saved vectors and incoming gradients (own parts)
-      for (int i = tid; i < 4 * S; i += kCluThreads) {
-        const int which = i / S, s2 = i - which * S;
-        const float* src = which == 0 ? io.sv_la : (which == 1 ? io.sv_lv : (which == 2 ? io.post_logits : io.prior_logits));
-        lds[(which == 0 ? Lla : (which == 1 ? Llv : (which == 2 ? Lmx : Llp))) + s2] = src[bt * S + s2];
-      }
-      if (tid < S) lds[Lgps + tid] = io.g_post_stoch ? io.g_post_stoch[bt * S + tid] : 0.f;
-      if (tid < NH) {
-        const int which = tid / UH, u = tid - which * UH;
-        lds[Lhd + tid] = io.sv_heads[bt * 3 * H + which * H + member * UH + u];
-      }
-      if (tid < 4 * UD) {
-        const int g = tid / UD, u = tid - g * UD;
-        lds[Lgate + tid] = io.sv_gates[bt * 4 * D + g * D + member * UD + u];
-      }
-      if (tid < H) lds[Lh1 + tid] = io.sv_h1[bt * H + tid];
-      if (tid < UD) {
-        const int unit = member * UD + tid;
-        lds[Ldprev + tid] = t > 0 ? io.deter[(bt - 1) * D + unit] : io.deter0[(size_t)row * D + unit];
-        lds[Lgd + tid] = io.g_deter ? io.g_deter[bt * D + unit] : 0.f;
-      }
-      if (tid == 0) *gk_lds = io.g_kl ? io.g_kl[bt] : 0.f;
+      // (a) this step's saved vectors and incoming gradients (own parts) were loaded one step ahead into registers
+      //     (stage_load below): to LDS now, then the loads of step t - 1 go out and fly during this whole step
+      stage_store();
+      if (t > 0) stage_load(t - 1);
       lds_barrier();
 
       // (b) categorical block: straight-through sample, KL, per-categorical softmax, MoE/PoE, flat log-softmax (one wave)
@@ -775,6 +819,8 @@ static size_t cluster_lds_floats(int D, int H, int S) {
   take((size_t)(2 * NG * NP > NH * NP ? 2 * NG * NP : NH * NP));
   take((size_t)S * H);
   take((size_t)D * NH);
+  take((size_t)3 * S);
+  take(2 * 64);
   take(4);
   return o;
 }
@@ -791,7 +837,7 @@ int mrssm_cluster_supported(const MtrssmMrssmDims* d) {
   if (!d || d->B <= 0 || d->T <= 0 || d->D <= 0 || d->H <= 0 || d->K <= 0 || d->C <= 0 || !d->post) return 0;
   const int S = d->K * d->C, D = d->D, H = d->H;
   if (D != H || (D != 32 && D != 64 && D != 128 && D != 200)) return 0;  // the instantiated square sizes
-  if (3 * S > kCluThreads || H / kClu > 64 || 3 * H / kClu > kCluThreads) return 0;  // logit rows / head units: one thread each
+  if (3 * S > kCluThreads || H / kClu > 64 || 3 * H / kClu > kCluThreads || d->K > 64) return 0;  // logit rows / head units: one thread each
   if (D > 4 * kWave || kClu * 3 * S > 6 * kWave) return 0;  // granules per gather (wave_gather<4> / <6>)
   if (cluster_lds_floats(D, H, S) * sizeof(float) > 160 * 1024) return 0;
   return 1;
