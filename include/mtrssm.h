@@ -485,6 +485,10 @@ int mtrssm_adamw_step(float* param, const float* grad, float* exp_avg, float* ex
  *   active (n bytes, may be NULL = all): 0 marks elements of parameters that never received a gradient; they are left
  *   untouched (no decay, no moments) as torch.optim.AdamW does for `.grad is None` -- MMTRSSM's l_posterior and dummy
  *   transition (mmtrssm/mopoe_mmtrssm/core.py:143-151,188). */
+/* Zero `bytes` (multiple of 4, 4-byte aligned) of device memory with a plain kernel: what FlatParameters.zero_grad() uses, so that a
+ * captured train step records no memset node (a captured multi-megabyte hipMemsetAsync left foreign bytes at the buffer's head
+ * on replay under ROCm 7.2). */
+int mtrssm_clear(void* p, int64_t bytes, void* stream);
 int mtrssm_adamw_prepare(const float* grad, int64_t n, float* sumsq, float* state, float beta1, float beta2, void* stream);
 int mtrssm_adamw_apply(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const uint8_t* active, int64_t n,
                        const float* sumsq, const float* state, float clip_norm, float grad_scale, float beta1, float beta2,

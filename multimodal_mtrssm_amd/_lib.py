@@ -112,6 +112,7 @@ SYMBOLS: dict[str, tuple[type | None, list[type]]] = {
     "mtrssm_sumsq": (C.c_int, [_p, C.c_int64, _p, _p]),
     "mtrssm_adamw_step": (C.c_int, [_p, _p, _p, _p, C.c_int64, _p, _f, _f, _f, _f, _f, _f, _f, _i, _p]),
     "mtrssm_gemm": (C.c_int, [C.POINTER(Gemm), _p]),
+    "mtrssm_clear": (C.c_int, [_p, C.c_int64, _p]),
     "mtrssm_adamw_prepare": (C.c_int, [_p, C.c_int64, _p, _p, _f, _f, _p]),
     "mtrssm_adamw_apply": (C.c_int, [_p, _p, _p, _p, _p, C.c_int64, _p, _p, _f, _f, _f, _f, _f, _f, _p]),
 }

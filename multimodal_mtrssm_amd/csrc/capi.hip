@@ -102,6 +102,9 @@ MTRSSM_API int mtrssm_mrssm_rollout_bwd_cluster(const MtrssmMrssmDims* d, const 
   return mrssm_bwd_cluster_launch(d, w, io, workspace, workspace_bytes < 0 ? 0 : (size_t)workspace_bytes, static_cast<hipStream_t>(stream));
 }
 MTRSSM_API int mtrssm_gemm(const MtrssmGemm* g, void* stream) { return gemm_launch(g, static_cast<hipStream_t>(stream)); }
+MTRSSM_API int mtrssm_clear(void* p, int64_t bytes, void* stream) {
+  return clear_async(p, bytes < 0 ? 0 : (size_t)bytes, static_cast<hipStream_t>(stream));
+}
 MTRSSM_API int mtrssm_adamw_prepare(const float* grad, int64_t n, float* sumsq, float* state, float beta1, float beta2, void* stream) {
   return adamw_prepare_launch(grad, n, sumsq, state, beta1, beta2, static_cast<hipStream_t>(stream));
 }

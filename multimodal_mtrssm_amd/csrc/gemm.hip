@@ -321,12 +321,9 @@ int gemm_launch(const MtrssmGemm* p, hipStream_t stream) {
       set_error("gemm: a split reduction into a strided C needs accumulate (C is zeroed by the caller)");
       return MTRSSM_EINVAL;
     }
-    hipError_t e = hipMemsetAsync(p->C, 0, (size_t)p->M * p->N * sizeof(float), stream);
-    if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return MTRSSM_ELAUNCH; }
-    if (finalize) {
-      e = hipMemsetAsync(p->tickets, 0, (size_t)ti * tj * sizeof(int), stream);
-      if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return MTRSSM_ELAUNCH; }
-    }
+    if (int rc = clear_async(p->C, (size_t)p->M * p->N * sizeof(float), stream)) return rc;
+    if (finalize)
+      if (int rc = clear_async(p->tickets, (size_t)ti * tj * sizeof(int), stream)) return rc;
   }
   g.tickets = finalize ? p->tickets : nullptr;
   g.splits = splits;

@@ -776,8 +776,8 @@ int mrssm_bwd_cluster_launch(const MtrssmMrssmDims* d, const MtrssmMrssmClusterW
   const int grid = ((nclusters + 7) / 8) * 32;
   const size_t lds = cluster_bwd_lds_floats(d->D, d->K * d->C) * sizeof(float);
   if (lds > 160 * 1024) { set_error("mrssm_rollout_bwd_cluster: %zu bytes of LDS", lds); return MTRSSM_ELDS; }
-  hipError_t e = hipMemsetAsync(workspace, 0, mrssm_cluster_bwd_workspace_bytes(d), stream);
-  if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return MTRSSM_ELAUNCH; }
+  if (int rc = clear_async(workspace, mrssm_cluster_bwd_workspace_bytes(d), stream)) return rc;
+  hipError_t e = hipSuccess;
   int* status = reinterpret_cast<int*>(workspace);
   unsigned long long* gran = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(workspace) + 16);
 #define MTRSSM_CLUB_LAUNCH(DHV, NPV, PPTV)                                                                                         \
@@ -864,9 +864,9 @@ int mrssm_fwd_cluster_launch(const MtrssmMrssmDims* d, const MtrssmMrssmClusterW
   const int groups = (nclusters + 7) / 8;            // 8 clusters per 32 consecutive blocks
   const int grid = groups * 32;
   const size_t lds = cluster_lds_floats(d->D, d->H, d->K * d->C) * sizeof(float);
-  // status word + granules: zeroed every launch (a memset node: replayed first under a graph)
-  hipError_t e = hipMemsetAsync(workspace, 0, mrssm_cluster_workspace_bytes(d), stream);
-  if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return MTRSSM_ELAUNCH; }
+  // status word + granules: zeroed every launch (first node of the launch under a graph)
+  if (int rc = clear_async(workspace, mrssm_cluster_workspace_bytes(d), stream)) return rc;
+  hipError_t e = hipSuccess;
   int* status = reinterpret_cast<int*>(workspace);
   unsigned long long* gran = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(workspace) + 16);
   const int kw = cluster_kw(d->D, d->H);

@@ -8,6 +8,12 @@
 namespace mtrssm {
 
 constexpr int kWave = 64;
+
+// Zero `bytes` (a multiple of 4, 4-byte aligned) of device memory on `stream` with a plain kernel (train_ops.hip).  The library's
+// launch functions are captured into hipGraphs (graph.CapturedTrainStep); a captured hipMemsetAsync node of a few megabytes
+// went together with foreign bytes at the head of the buffer on replay (ROCm 7.2: the kernel arguments of an unrelated eager
+// launch showed up there), so no memset node is ever recorded.
+int clear_async(void* p, size_t bytes, hipStream_t stream);
 constexpr float kLogThird = -1.0986122886681098f;  // log(1/3), mrssm/mopoe_mrssm/core.py:141-142
 
 __device__ __forceinline__ float act_fwd(float z, int act) {

@@ -167,6 +167,19 @@ __global__ void adamw_masked_kernel(float* __restrict__ p, const float* __restri
   }
 }
 
+__global__ void clear_words_kernel(unsigned* __restrict__ p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+
+int clear_async(void* p, size_t bytes, hipStream_t stream) {
+  if (!p || (bytes & 3) || ((uintptr_t)p & 3)) { set_error("clear_async: needs a 4-byte aligned buffer of a multiple of 4 bytes"); return MTRSSM_EINVAL; }
+  const size_t n = bytes / 4;
+  if (n == 0) return MTRSSM_OK;
+  const size_t blocks = (n + kThreads - 1) / kThreads;
+  hipLaunchKernelGGL(clear_words_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(kThreads), 0, stream, static_cast<unsigned*>(p), n);
+  return hipGetLastError() == hipSuccess ? MTRSSM_OK : MTRSSM_ELAUNCH;
+}
+
 static int grid_for(int64_t n) {
   int64_t g = (n + kThreads - 1) / kThreads;
   return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
@@ -185,8 +198,7 @@ int nll_fwd_launch(const float* pred, const float* target, int64_t frames, int64
   if (!pred || !target || !out || frames <= 0 || event <= 0) { set_error("gaussian_nll_fwd: bad argument"); return MTRSSM_EINVAL; }
   if (act != MTRSSM_ACT_IDENTITY && act != MTRSSM_ACT_TANH) { set_error("gaussian_nll: the fused output activation is Identity or Tanh (got %d)", act); return MTRSSM_EINVAL; }
   if (((uintptr_t)pred | (uintptr_t)target) & 15) { set_error("gaussian_nll_fwd: pred/target must be 16-byte aligned"); return MTRSSM_EINVAL; }
-  hipError_t e = hipMemsetAsync(out, 0, sizeof(float), s);
-  if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return MTRSSM_ELAUNCH; }
+  if (int rc = clear_async(out, sizeof(float), s)) return rc;
   const int64_t n = frames * event;
   const float constant = 0.5f * 1.8378770664093453f * (float)event;  // 0.5 log(2 pi) per element
   set_last_kernel("mtrssm::nll_fwd_kernel");
@@ -213,8 +225,7 @@ int nll_bwd_launch(const float* pred, const float* target, const float* g_out, i
 int sumsq_launch(const float* x, int64_t n, float* out, hipStream_t s) {
   if (!x || !out || n <= 0) { set_error("sumsq: bad argument"); return MTRSSM_EINVAL; }
   if ((uintptr_t)x & 15) { set_error("sumsq: x must be 16-byte aligned"); return MTRSSM_EINVAL; }
-  hipError_t e = hipMemsetAsync(out, 0, sizeof(float), s);
-  if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return MTRSSM_ELAUNCH; }
+  if (int rc = clear_async(out, sizeof(float), s)) return rc;
   set_last_kernel("mtrssm::sumsq_kernel");
   hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n / 4)), dim3(kThreads), 0, s, x, n, out);
   return check_launch("sumsq");
@@ -233,8 +244,7 @@ int adamw_launch(float* p, const float* g, float* m, float* v, int64_t n, const 
 int adamw_prepare_launch(const float* g, int64_t n, float* sumsq, float* state, float b1, float b2, hipStream_t s) {
   if (!g || !sumsq || !state || n <= 0) { set_error("adamw_prepare: bad argument"); return MTRSSM_EINVAL; }
   if ((uintptr_t)g & 15) { set_error("adamw_prepare: grad must be 16-byte aligned"); return MTRSSM_EINVAL; }
-  hipError_t e = hipMemsetAsync(sumsq, 0, sizeof(float), s);
-  if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return MTRSSM_ELAUNCH; }
+  if (int rc = clear_async(sumsq, sizeof(float), s)) return rc;
   set_last_kernel("mtrssm::sumsq_tick_kernel");
   hipLaunchKernelGGL(sumsq_tick_kernel, dim3(grid_for(n / 4)), dim3(kThreads), 0, s, g, n, sumsq, state, b1, b2);
   return check_launch("adamw_prepare");

@@ -102,7 +102,13 @@ class FlatParameters:
         return mask.to(self.param.device)
 
     def zero_grad(self) -> None:
-        self.grad_full.zero_()
+        """One launch over the flat gradient buffer (+ tail).  On the GPU a plain kernel (``mtrssm_clear``), not a memset:
+        inside a captured train step a 16 MB memset node came back with foreign bytes at the buffer's head on replay."""
+        g = self.grad_full
+        if g.is_cuda:
+            _lib.check(_lib.load().mtrssm_clear(_lib.ptr(g), g.numel() * 4, _lib.stream_ptr(g.device)), "mtrssm_clear")
+        else:
+            g.zero_()
 
     def check_views(self) -> None:
         """Raise if something replaced a ``.grad`` (e.g. a stock ``model.zero_grad()``, whose set_to_none=True makes autograd

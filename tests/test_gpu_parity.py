@@ -329,9 +329,10 @@ def test_full_size_properties(name: str, lib_loaded: None) -> None:
 # ---------------------------------------------------------------------------------------------
 # the EXACT model bench.py times (BASELINE configs[1] / configs[2] at their stated frame sizes, T = 50)
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", ["mrssm_bench", "mmtrssm_bench"])
+@pytest.mark.parametrize("name", ["mrssm_bench", "mmtrssm_bench", "mrssm_large_bench"])
 def test_bench_model_matches_oracle(name: str, lib_loaded: None) -> None:
-    """bench.py's model (1x128x32 + 1x64x64 frames, channels [8,16,32], 3 residual blocks, deter 200, stoch 6x5, T = 50) on
+    """bench.py's models -- configs[1] / configs[2] (1x128x32 + 1x64x64 frames, channels [8,16,32], 3 residual blocks, deter 200,
+    stoch 6x5, T = 50) and the "Large" configs[4] model of `--model large` (deter = hidden = embed = 1024, stoch 16x8, T = 100) -- on
     two sequences against the oracle: losses <= 1e-4 relative (north_star), posterior / prior probabilities <= 1e-5, every
     one-hot sample exact, EVERY gradient <= 2e-4 of its tensor's largest entry.  The noise seed is screened so that no draw
     sits within 1e-4 of a CDF edge (two fp32 implementations differ by ~1e-6 there)."""
@@ -339,8 +340,11 @@ def test_bench_model_matches_oracle(name: str, lib_loaded: None) -> None:
     case = CASES[name]
     oracle = build_model(case)
     batch = build_batch(case)
-    noise, margin, _seed = screened_noise(case, oracle, batch)
-    assert margin >= 1e-4, margin
+    # 16 categoricals x 100 steps: a seed that keeps 1e-4 from all ~20 000 CDF edges does not turn up in 40 tries; 2e-5 is
+    # still 20 x the distance two fp32 implementations land apart
+    want_margin = 2e-5 if "large" in name else 1e-4
+    noise, margin, _seed = screened_noise(case, oracle, batch, margin=want_margin)
+    assert margin >= want_margin, margin
     ref = oracle.shared_step(batch, noise)
     ref["loss"].backward()
     model = product_from_case(case, oracle, DEV)
@@ -932,6 +936,51 @@ def test_flat_adamw_matches_torch(lib_loaded: None) -> None:
     net(x).square().sum().backward()
     with pytest.raises(RuntimeError, match="no longer aliases"):
         opt.step()
+
+
+@pytest.mark.parametrize("name", ["mrssm_default", "mmtrssm_default", "mrssm_cfg2dims"])
+def test_captured_train_step_matches_eager(name: str, lib_loaded: None) -> None:
+    """graph.CapturedTrainStep (zero_grad + shared_step + backward + clip + AdamW recorded once as a hipGraph, replayed per
+    step; uniforms drawn outside into fixed buffers) against the same steps enqueued eagerly: same losses step by step and the
+    same parameters after five steps (up to the arrival order of fp32 atomics), the device-side step count advanced, the
+    cluster scans' status words clean."""
+    import multimodal_mtrssm_amd as mt
+    from multimodal_mtrssm_amd import scan
+    from multimodal_mtrssm_amd.graph import CapturedTrainStep
+    from multimodal_mtrssm_amd.optim import FlatParameters
+
+    case = with_sizes(CASES[name], 6, 9)
+    oracle = build_model(case)
+    batch = tuple(b.to(DEV) for b in build_batch(case))
+    results = {}
+    for mode in ("eager", "graph"):
+        model = product_from_case(case, oracle, DEV)
+        flat = FlatParameters(model, extra=8)
+        dp = mt.FlatDataParallel(flat)
+        opt = mt.FlatAdamW(flat, lr=1e-3, clip_norm=10.0)
+        source = dp.noise_source(seed=11)
+        shapes = model.noise_shapes(6, 9)
+        losses = []
+        if mode == "eager":
+            for _ in range(3 + 5):  # the capture's three warm-up steps are real optimizer steps too
+                noise = source.draw(shapes)
+                opt.zero_grad()
+                out = model.shared_step(batch, noise)
+                out["loss"].backward()
+                dp.sync({k: out[k] for k in out})
+                opt.step(grad_scale=dp.grad_scale)
+                losses.append(float(out["loss"]))
+            losses = losses[3:]
+        else:
+            cap = CapturedTrainStep(model, flat, opt, dp, batch, source, warmup=3)
+            for _ in range(5):
+                losses.append(float(cap.step()["loss"]))
+            assert float(opt.state[1]) == 8.0 and opt.steps == 8
+        scan.check_cluster_status()
+        results[mode] = (losses, flat.param.clone())
+    np.testing.assert_allclose(results["graph"][0], results["eager"][0], rtol=2e-5)
+    scale = float(results["eager"][1].abs().max())
+    np.testing.assert_allclose(_np(results["graph"][1]), _np(results["eager"][1]), rtol=1e-3, atol=1e-5 * scale)
 
 
 def test_cpu_tensors_are_refused(lib_loaded: None) -> None:

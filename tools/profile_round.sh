@@ -20,6 +20,10 @@ timeout -k 10 200 python3 bench.py --no-cpu-baseline --conv-mfma bf16 > $OUT/ben
 timeout -k 10 200 python3 bench.py --no-cpu-baseline --conv-mfma f32 > $OUT/bench_f32.json 2>/dev/null || exit 1
 timeout -k 10 200 python3 bench.py --no-cpu-baseline --model mmtrssm > $OUT/bench_mmtrssm.json 2>/dev/null || exit 1
 timeout -k 10 200 python3 bench.py --no-cpu-baseline --force-dist > $OUT/bench_force_dist.json 2>/dev/null || exit 1
+timeout -k 10 200 python3 bench.py --no-cpu-baseline --graph on > $OUT/bench_graph.json 2>/dev/null || exit 1
+timeout -k 10 400 python3 bench.py --model large --steps 5 --warmup 2 > $OUT/bench_large.json 2>/dev/null || exit 1
+MTRSSM_SCAN_CLUSTER=0 timeout -k 10 200 python3 bench.py --no-cpu-baseline > $OUT/bench_single_cu_scan.json 2>/dev/null || exit 1
+timeout -k 10 200 python3 bench.py --gpus 2 --backend gloo --share-device --steps 6 --warmup 2 --no-elbo-check > $OUT/bench_dp2_gloo_shared.json 2>/dev/null || exit 1
 echo modes done
 find $OUT/pmc_fetch $OUT/pmc_write -name "*.csv" -size +2M -delete
 ls $OUT $OUT/stats/*
