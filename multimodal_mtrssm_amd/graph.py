@@ -80,8 +80,7 @@ class CapturedTrainStep:
         torch.cuda.synchronize(dev)
         self.flat.check_views()
         self.opt.active_mask()  # built from what the warm-up steps touched; a fixed buffer from here on
-        self.noise.draw(self.shapes, out=self.uniforms)
-        self.opt.sync_lr()
+        self.opt.sync_lr()  # (no draw here: the recorded step is not executed, and a draw would shift the stream of uniforms)
         conv.reset_scratch(pin=True)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
