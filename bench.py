@@ -326,7 +326,7 @@ def main() -> None:  # noqa: PLR0914, PLR0915
     batch = synthetic_batch(b, device, seed=1000 + rank)  # each rank owns its own 64 sequences (weak scaling)
     # sampling uniforms keyed by GLOBAL batch row: the same generator state on every rank, the whole
     # global batch drawn, this rank's rows kept -- a row's trajectory does not depend on the number of ranks
-    noise_source = dp.noise_source(seed=int(os.environ.get("DBG_NOISE_SEED", "7")))
+    noise_source = dp.noise_source(seed=7)
     shapes = model.noise_shapes(b, t)
 
     def eager_step() -> dict[str, torch.Tensor]:
@@ -361,9 +361,6 @@ def main() -> None:  # noqa: PLR0914, PLR0915
     marks[args.steps].record()
     barrier()
     elapsed = time.perf_counter() - t0
-    if os.environ.get("MTRSSM_DEBUG_WS"):
-        for key, ws_ in scan._CLUSTER_WS.items():  # noqa: SLF001
-            print("ws", key[0] if isinstance(key[0], str) else "fwd", key, ws_[:4].view(torch.int32).tolist(), file=sys.stderr)
     scan.check_cluster_status()  # a cluster-scan exchange that timed out would have left invalid results
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     median_ms = step_ms[len(step_ms) // 2]

@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage (on the GPU box): tools/profile_round.sh   -> gpurun_out/final/{stats,pmc_fetch,pmc_write}/ + bench_*.json
-# The passes behind profiles/round1_*: kernel trace + stats of the default bench command, the two HBM counter passes
+# The passes behind profiles/roundN_*: kernel trace + stats of the default bench command, the two HBM counter passes
 # (separately, as MI355X_MICROARCH.md prescribes), then one plain bench line per mode.
 set -o pipefail
 ROOT=$GRAFT_REPO_ROOT
@@ -15,15 +15,15 @@ echo pmc done
 python3 tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_summary.json "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline" > /dev/null || exit 1
 timeout -k 10 300 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err || exit 1
 echo default done
-timeout -k 10 200 python3 bench.py --no-cpu-baseline --conv-mfma bf16x3 > $OUT/bench_bf16x3.json 2>/dev/null || exit 1
-timeout -k 10 200 python3 bench.py --no-cpu-baseline --conv-mfma bf16 > $OUT/bench_bf16.json 2>/dev/null || exit 1
-timeout -k 10 200 python3 bench.py --no-cpu-baseline --conv-mfma f32 > $OUT/bench_f32.json 2>/dev/null || exit 1
-timeout -k 10 200 python3 bench.py --no-cpu-baseline --model mmtrssm > $OUT/bench_mmtrssm.json 2>/dev/null || exit 1
-timeout -k 10 200 python3 bench.py --no-cpu-baseline --force-dist > $OUT/bench_force_dist.json 2>/dev/null || exit 1
-timeout -k 10 200 python3 bench.py --no-cpu-baseline --graph on > $OUT/bench_graph.json 2>/dev/null || exit 1
-timeout -k 10 400 python3 bench.py --model large --steps 5 --warmup 2 > $OUT/bench_large.json 2>/dev/null || exit 1
-MTRSSM_SCAN_CLUSTER=0 timeout -k 10 200 python3 bench.py --no-cpu-baseline > $OUT/bench_single_cu_scan.json 2>/dev/null || exit 1
-timeout -k 10 200 python3 bench.py --gpus 2 --backend gloo --share-device --steps 6 --warmup 2 --no-elbo-check > $OUT/bench_dp2_gloo_shared.json 2>/dev/null || exit 1
+timeout -k 10 200 python3 bench.py --no-cpu-baseline --conv-mfma bf16x3 > $OUT/bench_bf16x3.json 2>/dev/null || echo "FAILED: $_"
+timeout -k 10 200 python3 bench.py --no-cpu-baseline --conv-mfma bf16 > $OUT/bench_bf16.json 2>/dev/null || echo "FAILED: $_"
+timeout -k 10 200 python3 bench.py --no-cpu-baseline --conv-mfma f32 > $OUT/bench_f32.json 2>/dev/null || echo "FAILED: $_"
+timeout -k 10 200 python3 bench.py --no-cpu-baseline --model mmtrssm > $OUT/bench_mmtrssm.json 2>/dev/null || echo "FAILED: $_"
+timeout -k 10 200 python3 bench.py --no-cpu-baseline --force-dist > $OUT/bench_force_dist.json 2>/dev/null || echo "FAILED: $_"
+timeout -k 10 200 python3 bench.py --no-cpu-baseline --graph on > $OUT/bench_graph.json 2>/dev/null || echo "FAILED: $_"
+timeout -k 10 400 python3 bench.py --model large --steps 5 --warmup 2 > $OUT/bench_large.json 2>/dev/null || echo "FAILED: $_"
+MTRSSM_SCAN_CLUSTER=0 timeout -k 10 200 python3 bench.py --no-cpu-baseline > $OUT/bench_single_cu_scan.json 2>/dev/null || echo "FAILED single-cu"
+timeout -k 10 200 python3 bench.py --gpus 2 --backend gloo --share-device --steps 6 --warmup 2 --no-elbo-check > $OUT/bench_dp2_gloo_shared.json 2>/dev/null || echo "FAILED: $_"
 echo modes done
 find $OUT/pmc_fetch $OUT/pmc_write -name "*.csv" -size +2M -delete
 ls $OUT $OUT/stats/*
