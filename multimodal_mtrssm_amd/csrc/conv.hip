@@ -651,6 +651,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_gather_gemm_patch_kernel(
 
 }  // namespace mtrssm
 #include "conv_split.h"
+#include "conv_resident.h"
 namespace mtrssm {
 
 // ------------------------------------------------------------------------------------------------
@@ -1026,13 +1027,30 @@ static int launched(const char* who) {
 
 // ---- split-bf16 gather kernels: plan (which kernel, which tiling) and launch of one or two problems
 struct SplitPlan {
-  int kind = 0;  // 0: not covered, 1: conv1x1_split_kernel, 2: conv_gather_split_kernel
+  int kind = 0;  // 0: not covered, 1: conv1x1_split_kernel, 2: conv_gather_split_kernel, 3: conv3x3_resident_kernel
   int tco = 0, ny = 0, nx = 0, sp = 0, pit = 0, tgs = 0, ngroups = 0;
+  int res = 0;  // kind 3: CIN * 1000 + Cout (the instantiation)
   size_t lds = 0;
   bool same_kernel(const SplitPlan& o) const {
+    if (kind == 3) return o.kind == 3 && res == o.res;
     return kind == o.kind && kind != 0 && tco == o.tco && ny == o.ny && sp == o.sp && pit == o.pit && tgs == o.tgs && ngroups == o.ngroups;
   }
 };
+
+// MTRSSM_CONV_RESIDENT=0: the patch-staged kernel for every layer (A/B runs of conv3x3_resident_kernel)
+static bool resident_enabled() {
+  static const bool on = [] { const char* e = getenv("MTRSSM_CONV_RESIDENT"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
+static int cu_count() {
+  static const int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    return v;
+  }();
+  return n;
+}
 
 static SplitPlan plan_split(const MtrssmConvGeom* g, bool has_wq) {
   SplitPlan pl;
@@ -1048,6 +1066,20 @@ static SplitPlan plan_split(const MtrssmConvGeom* g, bool has_wq) {
   pl.nx = (int)((ptot + kTP - 1) / kTP);
   pl.sp = sp;
   if ((long)g->N * g->Cout * g->Ho * g->Wo >= (1L << 31)) return pl;
+  // 3x3 / stride 1 / pad 1 layers of the residual stacks on 64-pixel planes (8x8, 16x4, 4x16): weights resident in registers (conv_resident.h)
+  if (sp == 2 && resident_enabled() && g->KH == 3 && g->KW == 3 && g->SS == 1 && g->OS == 1 && g->QY == 0 && g->QX == 0 && g->C2 == 0 &&
+      (g->Ws == 4 || g->Ws == 8 || g->Ws == 16) && g->Hs * g->Ws == 64 && g->Hq == g->Hs && g->Wq == g->Ws && g->Ho == g->Hs && g->Wo == g->Ws && g->Cpad == g->C && g->OFFY == -g->TS &&
+      g->OFFX == -g->TS && (long)g->N * g->C * 64 < (1L << 31) && g->act != MTRSSM_ACT_TANH) {
+    const int key = g->C * 1000 + g->Cout;
+    if (key == 64064 || key == 64128 || key == 128064 || key == 32064) {
+      pl.kind = 3;
+      pl.res = key;
+      pl.nx = g->N;  // frames; launch_split turns them into workgroups
+      pl.lds = key == 64064 ? res_lds_bytes<64, 2, 1>() : key == 64128 ? res_lds_bytes<64, 4, 1>() : key == 128064 ? res_lds_bytes<128, 2, 2>()
+                                                                                                     : res_lds_bytes<32, 2, 1>();
+      return pl;
+    }
+  }
   if (taps == 1 && g->SS == 1 && g->OS == 1 && g->OFFY == 0 && g->OFFX == 0 && g->C2 == 0 && g->Hs == g->Hq && g->Ws == g->Wq &&
       g->Ho == g->Hq && g->Wo == g->Wq && g->Cpad % 64 == 0) {  // 1x1 layers: 64 channels per step
     pl.kind = 1;
@@ -1079,6 +1111,44 @@ static GatherProblem make_problem(const MtrssmConvGeom* g, const SplitPlan& pl, 
 
 // launches pa (and pb when pb.nx > 0: same kernel, its workgroups appended to the grid)
 static int launch_split(const SplitPlan& pl, size_t lds, const GatherProblem& pa, const GatherProblem& pb, hipStream_t stream) {
+  if (pl.kind == 3) {
+    // persistent workgroups, one per CU; a pair shares the CUs in proportion to its frames (each workgroup keeps ONE
+    // problem's weights in registers)
+    const int fpt = pl.res == 64064 || pl.res == 32064 ? 2 : 1;  // frames per tile
+    const long ta = (pa.nx + fpt - 1) / fpt, tb = (pb.nx + fpt - 1) / fpt;
+    const int ncu = cu_count();
+    GatherProblem qa = pa, qb = pb;
+    if (tb == 0) {
+      qa.nx = (int)(ta < ncu ? ta : ncu);
+      qb.nx = 0;
+    } else {
+      long na = (ncu * ta + (ta + tb) / 2) / (ta + tb);
+      na = na < 1 ? 1 : (na > ncu - 1 ? ncu - 1 : na);
+      qa.nx = (int)(na < ta ? na : ta);
+      qb.nx = (int)(ncu - na < tb ? ncu - na : tb);
+    }
+    const dim3 rgrid((unsigned)(qa.nx + qb.nx));
+#define MTRSSM_RES_LAUNCH(CIN_, NCT_, KS_)                                                                           \
+  {                                                                                                                   \
+    static bool attr_done = false;                                                                                    \
+    const size_t rl = res_lds_bytes<CIN_, NCT_, KS_>();                                                               \
+    if (!attr_done) {                                                                                                 \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_resident_kernel<CIN_, NCT_, KS_>),              \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl);                                 \
+      attr_done = true;                                                                                               \
+    }                                                                                                                 \
+    set_last_kernel("mtrssm::conv3x3_resident_kernel<" #CIN_ ", " #NCT_ ", " #KS_ ">");                                \
+    hipLaunchKernelGGL((conv3x3_resident_kernel<CIN_, NCT_, KS_>), rgrid, dim3(kResThreads), rl, stream, qa, qb);     \
+    return launched("conv_gather_gemm(resident)");                                                                    \
+  }
+    if (pl.res == 64064) MTRSSM_RES_LAUNCH(64, 2, 1)
+    if (pl.res == 64128) MTRSSM_RES_LAUNCH(64, 4, 1)
+    if (pl.res == 128064) MTRSSM_RES_LAUNCH(128, 2, 2)
+    if (pl.res == 32064) MTRSSM_RES_LAUNCH(32, 2, 1)
+#undef MTRSSM_RES_LAUNCH
+    set_error("conv_gather_gemm: no resident kernel for this plan");
+    return MTRSSM_EINVAL;
+  }
   const dim3 grid((unsigned)(pa.nx + pb.nx), pl.ny);
   const int sp = pl.sp;
 #define MTRSSM_ATTR_ONCE(K_)                                                                                         \
@@ -1122,6 +1192,11 @@ static int launch_split(const SplitPlan& pl, size_t lds, const GatherProblem& pa
 #undef MTRSSM_ATTR_ONCE
   set_error("conv_gather_gemm: no split kernel for this plan");
   return MTRSSM_EINVAL;
+}
+
+int debug_set_resident_profile(void* buf) {
+  unsigned long long* p = static_cast<unsigned long long*>(buf);
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_res_prof), &p, sizeof(p)) == hipSuccess ? MTRSSM_OK : MTRSSM_ELAUNCH;
 }
 
 int pack_conv_weight_launch(const float* w, int O, int I, int KH, int KW, long so, long si, long sh, long sw, int OPad, int IPad,
