@@ -36,10 +36,18 @@ __device__ unsigned long long* g_res_prof = nullptr;
 // slots of the 256-byte bank window, and every address is (lane base) + (tap: a scalar) + (channel block, piece: immediates).
 __host__ __device__ constexpr int res_row_bytes(int cin) { return cin * 2 + 16; }
 
+// Weight staging (prologue): groups of output-channel rows go through LDS in rows of 9 * CIN bf16 + 16 bytes (an odd number
+// of 16-byte slots: the 16 lanes of a ds_read_b128 cycle, 16 rows, fall on 16 different slots of the bank window).
+__host__ __device__ constexpr int res_wrow_bytes(int cin) { return 9 * cin * 2 + 16; }
+__host__ __device__ constexpr int res_group_rows(int cin) { return cin >= 128 ? 32 : 64; }
+
 template <int CIN, int NCT, int KS>
 __host__ __device__ constexpr size_t res_lds_bytes() {
   constexpr int NPG = 4 / (NCT * KS);
-  return (size_t)4 * NPG * kResPos * res_row_bytes(CIN) + (size_t)NCT * 32 * sizeof(float) + (KS == 2 ? (size_t)NCT * 2 * 16 * 64 * sizeof(float) : 0);
+  constexpr size_t run = (size_t)4 * NPG * kResPos * res_row_bytes(CIN) + (size_t)NCT * 32 * sizeof(float) +
+                         (KS == 2 ? (size_t)NCT * 2 * 16 * 64 * sizeof(float) : 0);
+  constexpr size_t stage = (size_t)res_group_rows(CIN) * res_wrow_bytes(CIN);
+  return run > stage ? run : stage;
 }
 
 template <int CIN, int NCT, int KS>
@@ -80,22 +88,47 @@ __global__ __launch_bounds__(kResThreads, 1) void conv3x3_resident_kernel(const 
 
   unsigned long long* prof = (blockIdx.x == 0 && tid == 0) ? g_res_prof : nullptr;
   if (prof) prof[0] = __builtin_readcyclecounter();
-  // ---- zero both images once (the halo stays zero for the whole launch)
-  for (int o = tid * 16; o < 4 * IMG; o += kResThreads * 16) *reinterpret_cast<u32x4*>(patch + o) = u32x4{0u, 0u, 0u, 0u};
-
-  // ---- this wave's weights: MFMA A operands (row = output channel il of tile ct, 8 k-values per lane) for every k-block
+  // ---- this wave's weights: MFMA A operands (row = output channel il of tile ct, 8 k-values per lane) for every k-block.
+  // Read straight from the packed layout a lane's 16 bytes sit 18 * CIN bytes from its neighbour's: every load touches 32
+  // lines for 1 KB and the 72 loads of a wave re-touch each line four times -- 19 k cycles of L2 traffic per launch
+  // (measured).  Instead the rows go through LDS: coalesced 16-byte chunks in, fragments out.
   bf16x8 a[KB][2];
   {
-    const size_t piece = (size_t)g.CoutPad * 9 * g.Cpad;
-    const unsigned short* wrow = wq + (size_t)(ct * 32 + il) * 9 * g.Cpad + kh * CW + 8 * kl;
+    constexpr int GR = res_group_rows(CIN), WROW = res_wrow_bytes(CIN), CPR = 9 * CIN * 2 / 16;  // chunks per row
+    constexpr int NGRP = NCT * 32 / GR > 0 ? NCT * 32 / GR : 1;
+    constexpr int ROWS = NCT * 32 < GR ? NCT * 32 : GR;
+    const size_t piece = (size_t)g.CoutPad * 9 * g.Cpad;  // host: Cpad == CIN
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-      const int t = kb / CB, cb = kb % CB;
+    for (int s = 0; s < 2; ++s) {
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
-        a[kb][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wrow + s * piece + (size_t)t * g.Cpad + cb * 16));
+      for (int grp = 0; grp < NGRP; ++grp) {
+        const u32x4* gsrc = reinterpret_cast<const u32x4*>(wq + s * piece + (size_t)grp * ROWS * 9 * CIN);
+        constexpr int NCH = ROWS * CPR / kResThreads;  // chunks per thread: all requested before the first is stored
+        static_assert(ROWS * CPR % kResThreads == 0, "whole chunks per thread");
+        u32x4 wv[NCH];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) wv[i] = gsrc[tid + i * kResThreads];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+          const int c = tid + i * kResThreads, row = c / CPR, col = c - row * CPR;
+          *reinterpret_cast<u32x4*>(lds_raw + row * WROW + col * 16) = wv[i];
+        }
+        __syncthreads();
+        if (NGRP == 1 || (ct * 32) / ROWS == grp) {  // wave-uniform
+          const unsigned char* wl = lds_raw + ((ct * 32) % ROWS + il) * WROW + (kh * CW + 8 * kl) * 2;
+#pragma unroll
+          for (int kb = 0; kb < KB; ++kb) {
+            const int t = kb / CB, cb = kb % CB;
+            a[kb][s] = *reinterpret_cast<const bf16x8*>(wl + (t * CIN + cb * 16) * 2);
+          }
+        }
+        __syncthreads();
+      }
     }
   }
+  if (prof) prof[56] = __builtin_readcyclecounter();
+  // ---- zero both images once (the halo stays zero for the whole launch)
+  for (int o = tid * 16; o < 4 * IMG; o += kResThreads * 16) *reinterpret_cast<u32x4*>(patch + o) = u32x4{0u, 0u, 0u, 0u};
   // this lane's 16 accumulator rows are output channels cbase + (r & 3) + 8 * (r >> 2) (host: Cout == 32 * NCT, no ragged
   // channel tile); the bias waits in LDS for the epilogue
   const int cbase = ct * 32 + 4 * kl;
@@ -154,8 +187,11 @@ __global__ __launch_bounds__(kResThreads, 1) void conv3x3_resident_kernel(const 
     }
   };
 
+  if (prof) prof[57] = __builtin_readcyclecounter();
   stage_load(wg);
+  if (prof) prof[58] = __builtin_readcyclecounter();
   __syncthreads();  // zero fill done before the interior is written
+  if (prof) prof[59] = __builtin_readcyclecounter();
   stage_store(0);
   __syncthreads();
 
@@ -251,7 +287,7 @@ __global__ __launch_bounds__(kResThreads, 1) void conv3x3_resident_kernel(const 
       const float* theirs = red + ((size_t)(ct * 2 + (kh ^ 1)) * 16) * 64 + lane;
 #pragma unroll
       for (int r = 0; r < 16; ++r) mine[r * 64] = kh == 0 ? acc[1][r] : acc[0][r];
-      __syncthreads();
+      lds_barrier();
 #pragma unroll
       for (int r = 0; r < 16; ++r) fin[0][r] = (kh == 0 ? acc[0][r] : acc[1][r]) + theirs[r * 64];
     } else {
@@ -290,7 +326,8 @@ __global__ __launch_bounds__(kResThreads, 1) void conv3x3_resident_kernel(const 
       }
     }
     MTRSSM_RES_STAMP(4);
-    __syncthreads();  // the next image is complete; everyone is done reading this one
+    lds_barrier();  // the next image is complete; everyone is done reading this one (LDS only: a __syncthreads would also
+                    // wait for this tile's stores and the next tile's frames in flight)
     MTRSSM_RES_STAMP(5);
   }
 }

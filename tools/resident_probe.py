@@ -40,7 +40,8 @@ if os.environ.get("STAMPS"):
     torch.cuda.synchronize()
     assert fn(None) == 0
     st = prof.cpu().tolist()
-    print("prologue ticks (10 ns):", st[1] - st[0])
+    print("prologue cycles:", st[1] - st[0], "zero fill", st[56] - st[0], "weights issued", st[57] - st[56], "stage loads issued", st[58] - st[57],
+          "barrier (all loads landed)", st[59] - st[58], "first image", st[1] - st[59])
     for k in range(6):
         r = st[2 + 8 * k: 2 + 8 * k + 6]
         if r[0]:
