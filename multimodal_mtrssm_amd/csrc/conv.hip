@@ -1071,7 +1071,8 @@ static SplitPlan plan_split(const MtrssmConvGeom* g, bool has_wq) {
       (g->Ws == 4 || g->Ws == 8 || g->Ws == 16) && g->Hs * g->Ws == 64 && g->Hq == g->Hs && g->Wq == g->Ws && g->Ho == g->Hs && g->Wo == g->Ws && g->Cpad == g->C && g->OFFY == -g->TS &&
       g->OFFX == -g->TS && (long)g->N * g->C * 64 < (1L << 31) && g->act != MTRSSM_ACT_TANH) {
     const int key = g->C * 1000 + g->Cout;
-    if (key == 64064 || key == 64128 || key == 128064 || key == 32064) {
+    const int fpt = key == 64064 || key == 32064 ? 2 : 1;  // frames per tile: whole tiles only
+    if ((key == 64064 || key == 64128 || key == 128064 || key == 32064) && g->N % fpt == 0) {
       pl.kind = 3;
       pl.res = key;
       pl.nx = g->N;  // frames; launch_split turns them into workgroups
@@ -1114,6 +1115,13 @@ static int launch_split(const SplitPlan& pl, size_t lds, const GatherProblem& pa
   if (pl.kind == 3) {
     // persistent workgroups, one per CU; a pair shares the CUs in proportion to its frames (each workgroup keeps ONE
     // problem's weights in registers)
+    const bool epi_a = pa.actgrad_in || pa.add_in, epi_b = pb.actgrad_in || pb.add_in;  // template switch of the kernel
+    if (pb.nx > 0 && epi_a != epi_b) {
+      GatherProblem none{};
+      none.nx = 0;
+      if (int rc = launch_split(pl, lds, pa, none, stream)) return rc;
+      return launch_split(pl, lds, pb, none, stream);
+    }
     const int fpt = pl.res == 64064 || pl.res == 32064 ? 2 : 1;  // frames per tile
     const long ta = (pa.nx + fpt - 1) / fpt, tb = (pb.nx + fpt - 1) / fpt;
     const int ncu = cu_count();
@@ -1128,23 +1136,26 @@ static int launch_split(const SplitPlan& pl, size_t lds, const GatherProblem& pa
       qb.nx = (int)(ncu - na < tb ? ncu - na : tb);
     }
     const dim3 rgrid((unsigned)(qa.nx + qb.nx));
-#define MTRSSM_RES_LAUNCH(CIN_, NCT_, KS_)                                                                           \
+#define MTRSSM_RES_LAUNCH_E(CIN_, NCT_, KS_, EPI_)                                                                   \
   {                                                                                                                   \
     static bool attr_done = false;                                                                                    \
     const size_t rl = res_lds_bytes<CIN_, NCT_, KS_>();                                                               \
     if (!attr_done) {                                                                                                 \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_resident_kernel<CIN_, NCT_, KS_>),              \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_resident_kernel<CIN_, NCT_, KS_, EPI_>),        \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl);                                 \
       attr_done = true;                                                                                               \
     }                                                                                                                 \
-    set_last_kernel("mtrssm::conv3x3_resident_kernel<" #CIN_ ", " #NCT_ ", " #KS_ ">");                                \
-    hipLaunchKernelGGL((conv3x3_resident_kernel<CIN_, NCT_, KS_>), rgrid, dim3(kResThreads), rl, stream, qa, qb);     \
+    set_last_kernel("mtrssm::conv3x3_resident_kernel<" #CIN_ ", " #NCT_ ", " #KS_ ", " #EPI_ ">");                      \
+    hipLaunchKernelGGL((conv3x3_resident_kernel<CIN_, NCT_, KS_, EPI_>), rgrid, dim3(kResThreads), rl, stream, qa, qb); \
     return launched("conv_gather_gemm(resident)");                                                                    \
   }
+#define MTRSSM_RES_LAUNCH(CIN_, NCT_, KS_) \
+  { if (epi_a) MTRSSM_RES_LAUNCH_E(CIN_, NCT_, KS_, true) else MTRSSM_RES_LAUNCH_E(CIN_, NCT_, KS_, false) }
     if (pl.res == 64064) MTRSSM_RES_LAUNCH(64, 2, 1)
     if (pl.res == 64128) MTRSSM_RES_LAUNCH(64, 4, 1)
     if (pl.res == 128064) MTRSSM_RES_LAUNCH(128, 2, 2)
     if (pl.res == 32064) MTRSSM_RES_LAUNCH(32, 2, 1)
+#undef MTRSSM_RES_LAUNCH_E
 #undef MTRSSM_RES_LAUNCH
     set_error("conv_gather_gemm: no resident kernel for this plan");
     return MTRSSM_EINVAL;

@@ -1,21 +1,24 @@
 // Weight-resident 3x3 gather kernel for the residual stacks (included by conv.hip after conv_split.h).
 //
 // The residual stacks run 3x3 / stride 1 / pad 1 layers with 32..128 channels on 64-pixel planes (8x8 vision, 16x4 audio)
-// over B*T = 3200 frames: a
-// layer is thousands of small tiles against ONE small weight matrix (64 x 576 values).  conv_gather_split_kernel
-// re-stages that matrix per tile and per 16-channel step through LDS (two barriers a step, ~12 steps a tile) and runs
-// at the length of that dependency chain: the MFMA pipe is 20 % busy (profiles/round1_notes.md, round2_notes.md).
-// Here a workgroup is persistent (one per CU, one wave per SIMD, 512 registers per lane) and keeps ITS share of the
-// weights -- both bf16 pieces of a 32-output-channel x K slab per wave, 288 registers at K = 576 -- in registers as
-// ready-made MFMA A operands for the whole launch.  Only the pixels stream: a tile's frames are activated, split into
-// bf16 pieces and written ONCE into a channel-innermost haloed image [frame][(H + 2) x (W + 2) positions][CIN] in LDS (the halo
-// is zeroed once per launch and never written again), every MFMA B operand is one ds_read_b128 from it (2/3 of a read
-// per MFMA: MI355X_MICROARCH.md "Issued between MFMAs by one wave per SIMD"), the next tile's frames are in flight in
-// registers under this tile's MFMAs (double-buffered image, one barrier per tile), and the epilogue operands of a tile
-// are requested before its MFMA loop.
+// over B*T = 3200 frames: a layer is thousands of small tiles against ONE small weight matrix (64 x 576 values).
+// conv_gather_split_kernel re-stages that matrix per tile and per 16-channel step through LDS (two barriers a step, ~12
+// steps a tile) and runs at the length of that dependency chain: the MFMA pipe is 20 % busy (profiles/round1_notes.md,
+// round2_notes.md).  Here a workgroup is persistent (one per CU, one wave per SIMD, 512 registers per lane) and keeps ITS
+// share of the weights -- both bf16 pieces of a 32-output-channel x K slab per wave, 288 registers at K = 576, most of them
+// pinned to AGPRs -- in registers as ready-made MFMA A operands for the whole launch.  Only the pixels stream: a tile's
+// frames are activated, split into bf16 pieces and written ONCE into a channel-innermost haloed image
+// [frame][(H + 2) x (W + 2) positions][CIN] in LDS (the halo is zeroed once per launch and never written again), and
+// every MFMA B operand is one ds_read_b128 from it (2/3 of a read per MFMA: MI355X_MICROARCH.md "Issued between MFMAs
+// by one wave per SIMD").
 //
 // Wave roles (4 waves): NCT output-channel tiles x NPG frames x KS halves of the input channels, NCT * NPG * KS = 4;
-// every wave owns all 64 pixels (two 32-pixel MFMA tiles) of one frame.  KS = 2 (K = 1152) meets in LDS once per tile.
+// every wave owns the 64 pixels of one frame and walks them as two UNITS of 32 (one MFMA column tile each).  While a
+// unit's 3 * KB MFMAs run, the wave's other instructions ride in their shadow, k-block by k-block: the previous unit's
+// epilogue rows (bias is the accumulator's start value; act'(x) and the skip gradient are requested a unit ahead), the
+// requests for the next tile's frames (unit 0) and their conversion into the other image (unit 1).  One LDS-only
+// barrier per tile.  KS = 2 (K = 1152) exchanges half of the rows through LDS after every unit.
+// Measured (profiles/round2_notes.md): paired 64 -> 64 layer 200 -> 93 us forward, 122 us backward-data.
 #pragma once
 
 namespace mtrssm {
@@ -30,6 +33,7 @@ __device__ unsigned long long* g_res_prof = nullptr;
   do {                                                                               \
     if (prof && it_no < 6) prof[2 + it_no * 8 + (i)] = __builtin_readcyclecounter(); \
   } while (0)
+#define MTRSSM_SGB(mask_, n_) __builtin_amdgcn_sched_group_barrier(mask_, n_, 0)
 
 // Image rows: one position, all CIN channels of one piece, padded by 16 bytes: the row pitch is an odd number of 16-byte
 // slots, so the 16 lanes one ds_read_b128 cycle serves (consecutive positions, the same channel slot) fall on 16 different
@@ -41,6 +45,24 @@ __host__ __device__ constexpr int res_row_bytes(int cin) { return cin * 2 + 16; 
 __host__ __device__ constexpr int res_wrow_bytes(int cin) { return 9 * cin * 2 + 16; }
 __host__ __device__ constexpr int res_group_rows(int cin) { return cin >= 128 ? 32 : 64; }
 
+// B-operand reads and their waits are inline asm.  The compiler's own s_waitcnt for these reads came out as lgkmcnt(0) every
+// third k-block, right behind the newest requests: the LDS latency sat in front of every ninth MFMA (46 instead of 32
+// cycles per MFMA measured).  LDS operations return in order, so "at most 4 outstanding" releases the fragment requested
+// two blocks ago whatever else (the staging writes) is in flight; res_wait ties the fragment registers to that wait.
+template <int IMGB>
+__device__ __forceinline__ void res_read_pair(bf16x8& hi, bf16x8& lo, unsigned addr, int cb) {
+  switch (cb) {
+    case 0: asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:%3" : "=&v"(hi), "=&v"(lo) : "v"(addr), "n"(IMGB)); break;
+    case 1: asm volatile("ds_read_b128 %0, %2 offset:32\n\tds_read_b128 %1, %2 offset:%3" : "=&v"(hi), "=&v"(lo) : "v"(addr), "n"(IMGB + 32)); break;
+    case 2: asm volatile("ds_read_b128 %0, %2 offset:64\n\tds_read_b128 %1, %2 offset:%3" : "=&v"(hi), "=&v"(lo) : "v"(addr), "n"(IMGB + 64)); break;
+    default: asm volatile("ds_read_b128 %0, %2 offset:96\n\tds_read_b128 %1, %2 offset:%3" : "=&v"(hi), "=&v"(lo) : "v"(addr), "n"(IMGB + 96)); break;
+  }
+}
+template <int N>
+__device__ __forceinline__ void res_wait(bf16x8& b0, bf16x8& b1) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(b0), "+v"(b1) : "n"(N));
+}
+
 template <int CIN, int NCT, int KS>
 __host__ __device__ constexpr size_t res_lds_bytes() {
   constexpr int NPG = 4 / (NCT * KS);
@@ -50,7 +72,7 @@ __host__ __device__ constexpr size_t res_lds_bytes() {
   return run > stage ? run : stage;
 }
 
-template <int CIN, int NCT, int KS>
+template <int CIN, int NCT, int KS, bool EPI>  // EPI: the epilogue has operands (act'(x) input and / or skip gradient)
 __global__ __launch_bounds__(kResThreads, 1) void conv3x3_resident_kernel(const GatherProblem pa, const GatherProblem pb) {
   static_assert(NCT * KS == 4 || NCT * KS == 2 || NCT * KS == 1, "4 waves");
   constexpr int NPG = 4 / (NCT * KS);  // frames per tile
@@ -73,13 +95,12 @@ __global__ __launch_bounds__(kResThreads, 1) void conv3x3_resident_kernel(const 
   float* __restrict__ out = P.out;
   const int wg = second ? (int)blockIdx.x - pa.nx : (int)blockIdx.x, nwg = P.nx;
   const int nframes = g.N;
-  const int ntiles = (nframes + NPG - 1) / NPG;
+  const int ntiles = nframes / NPG;  // host: N % NPG == 0
   if (wg >= ntiles) return;  // workgroup-uniform
 
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   unsigned char* patch = lds_raw;                                            // [2 buffers][2 pieces][IMG]
-  float* bias_lds = reinterpret_cast<float*>(lds_raw + (size_t)4 * IMG);     // [NCT * 32]
-  float* red = bias_lds + NCT * 32;                                          // KS == 2: [NCT][2][16][64]
+  float* red = reinterpret_cast<float*>(lds_raw + (size_t)4 * IMG);          // KS == 2: [NCT][2][8][64]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kl = lane >> 5, il = lane & 31;
   const int ct = KS == 2 ? (wave & 1) : (wave % NCT);
@@ -126,13 +147,30 @@ __global__ __launch_bounds__(kResThreads, 1) void conv3x3_resident_kernel(const 
       }
     }
   }
+  // Register classes: VALU operands must be architectural VGPRs, MFMA operands may be AGPRs.  Left to itself the allocator
+  // fills the VGPR half with these long-lived fragments first and then spills them to scratch when the loop's VALU values
+  // need room.  Pinning most of them to AGPRs (240 = 256 minus the accumulator) leaves the VGPR half to the loop.
+  constexpr int kPinned = (2 * KB < 60 ? 2 * KB : 60);
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+      if (kb * 2 + s2 < kPinned) asm volatile("" : "+a"(a[kb][s2]));
   if (prof) prof[56] = __builtin_readcyclecounter();
   // ---- zero both images once (the halo stays zero for the whole launch)
   for (int o = tid * 16; o < 4 * IMG; o += kResThreads * 16) *reinterpret_cast<u32x4*>(patch + o) = u32x4{0u, 0u, 0u, 0u};
   // this lane's 16 accumulator rows are output channels cbase + (r & 3) + 8 * (r >> 2) (host: Cout == 32 * NCT, no ragged
-  // channel tile); the bias waits in LDS for the epilogue
+  // channel tile); the bias is the accumulators' start value (KS == 2: in the first half of K only)
   const int cbase = ct * 32 + 4 * kl;
-  if (tid < NCT * 32) bias_lds[tid] = bias ? bias[tid] : 0.f;
+  float bv[16];
+  {
+    const float* bsafe = bias ? bias : src;  // any readable address: the value is dropped below
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float b = bsafe[cbase + (r & 3) + 8 * (r >> 2)];
+      bv[r] = (bias && kh == 0) ? b : 0.f;
+    }
+  }
   // planes of 64 pixels, W = 4, 8 or 16 wide (host); haloed rows are W + 2 positions
   const int pw = g.Wq + 2, wsh = g.Wq == 8 ? 3 : (g.Wq == 4 ? 2 : 4);
   const int tstep = g.TS > 0 ? RB : -RB;  // forward gather / flipped (backward-data) gather: bytes per position step
@@ -144,192 +182,218 @@ __global__ __launch_bounds__(kResThreads, 1) void conv3x3_resident_kernel(const 
     pos0[pt] = (pgi * kResPos + ((pixel >> wsh) + 1) * pw + (pixel & (g.Wq - 1)) + 1) * RB + (kh * (CW / 8) + kl) * 16;  // byte offset
   }
   const int spos = ((lane >> wsh) + 1) * pw + (lane & (g.Wq - 1)) + 1;  // staging: lane = pixel of the frame
+  // activation switches as lane-uniform selects (no branch inside the MFMA loop: a branch ends a scheduling region)
+  const bool act_elu = g.act == MTRSSM_ACT_ELU, act_relu = g.act == MTRSSM_ACT_RELU, pre = g.pre_act != 0;
+  auto act_fwd_sel = [&](float x) {  // pre-activation of a staged value
+    float e = __expf(x) - 1.f;
+    asm volatile("" : "+v"(e));  // computed unconditionally: the compiler would branch around the exponential
+    const float neg = act_elu ? e : (act_relu ? 0.f : x);
+    return (x > 0.f || !pre) ? x : neg;
+  };
+  auto act_grad_sel = [&](float x) {  // act'(x) from the layer input
+    float e = __expf(x);
+    asm volatile("" : "+v"(e));
+    const float neg = act_elu ? e : (act_relu ? 0.f : 1.f);
+    return x > 0.f ? 1.f : neg;
+  };
 
+  // ---- staging of a tile's frames: (frame, 8-channel octet) items per wave, lane = pixel
   float pv[NIT][8];
-  auto stage_load = [&](int tile) {
+  auto stage_load_part = [&](int tile, int part, int nparts) {  // loads [part * NIT * 8 / nparts, ...) of the tile's items
+    constexpr int TOT = NIT * 8;
+    const int per = TOT / nparts;
+    int opaque = 0;  // addresses are formed HERE: hoisted to the top of the tile they sit in registers for its whole length
+    asm volatile("" : "+s"(opaque));
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
+    for (int j = 0; j < TOT; ++j) {
+      if (j / per != part) continue;
+      const int it = j / 8, u = j % 8;
       const int q = wave * NIT + it, fi = q / OCT, o = q % OCT;
-      int f = tile * NPG + fi;
-      f = f < nframes ? f : nframes - 1;  // a frame past the end: any finite values, its outputs are never stored
-      const float* bp = src + ((size_t)f * CIN + o * 8) * 64 + lane;
-#pragma unroll
-      for (int u = 0; u < 8; ++u) pv[it][u] = bp[u * 64];
+      pv[it][u] = src[((size_t)(tile * NPG + fi + opaque) * CIN + o * 8 + u) * 64 + lane];
     }
   };
-  auto stage_store = [&](int buf) {
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int q = wave * NIT + it, fi = q / OCT, o = q % OCT;
-      float x[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) x[u] = pv[it][u];
-      if (g.pre_act) {  // host: act is Identity, ELU or ReLU (no libm call in this kernel)
-        if (g.act == MTRSSM_ACT_ELU) {
-#pragma unroll
-          for (int u = 0; u < 8; ++u) x[u] = elu_fast(x[u]);
-        } else if (g.act == MTRSSM_ACT_RELU) {
-#pragma unroll
-          for (int u = 0; u < 8; ++u) x[u] = x[u] > 0.f ? x[u] : 0.f;
-        }
-      }
-      u16x8 qv[2];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        unsigned short p[2];
-        split_bf16<2>(x[u], p);
-        qv[0][u] = p[0];
-        qv[1][u] = p[1];
-      }
-      unsigned char* dst = patch + (size_t)buf * 2 * IMG + (fi * kResPos + spos) * RB + o * 16;
-      *reinterpret_cast<u16x8*>(dst) = qv[0];
-      *reinterpret_cast<u16x8*>(dst + IMG) = qv[1];
-    }
+  auto stage_store_chunk = [&](int buf, int c) {  // chunk c: channels 2 * (c % 4), +1 of item c / 4 -> 4 bytes per piece
+    const int it = c / 4, u2 = c % 4;
+    const int q = wave * NIT + it, fi = q / OCT, o = q % OCT;
+    unsigned short p0[2], p1[2];
+    split_bf16<2>(act_fwd_sel(pv[it][2 * u2]), p0);
+    split_bf16<2>(act_fwd_sel(pv[it][2 * u2 + 1]), p1);
+    int opaque = 0;
+    asm volatile("" : "+s"(opaque));
+    unsigned char* dst = patch + (size_t)buf * 2 * IMG + (fi * kResPos + spos + opaque) * RB + o * 16 + u2 * 4;
+    *reinterpret_cast<unsigned*>(dst) = (unsigned)p0[0] | ((unsigned)p1[0] << 16);
+    *reinterpret_cast<unsigned*>(dst + IMG) = (unsigned)p0[1] | ((unsigned)p1[1] << 16);
   };
+  constexpr int NSC = NIT * 4;  // staging chunks per tile
 
   if (prof) prof[57] = __builtin_readcyclecounter();
-  stage_load(wg);
-  if (prof) prof[58] = __builtin_readcyclecounter();
+  stage_load_part(wg, 0, 1);
   __syncthreads();  // zero fill done before the interior is written
-  if (prof) prof[59] = __builtin_readcyclecounter();
-  stage_store(0);
+#pragma unroll
+  for (int c = 0; c < NSC; ++c) stage_store_chunk(0, c);
   __syncthreads();
-
   if (prof) prof[1] = __builtin_readcyclecounter();
-  struct Frag { bf16x8 b[2][2]; };
+
+  // ---- the pipeline.  A unit = (tile, pixel half h): 3 * KB MFMAs into the accumulator.  In their shadow (between MFMAs, in program
+  // order: the wave issues in order) run the epilogue of the PREVIOUS unit (the other accumulator), the requests for this
+  // unit's epilogue operands, and (h = 0) the requests / (h = 1) the conversion of the next tile's frames.  Every k-block is
+  // one scheduling region: its three MFMAs alternate with at most ~6 VALU instructions each.
+  constexpr int ROWS = KS == 2 ? 8 : 16;            // accumulator rows this wave finishes per unit (KS == 2: half of them)
+  constexpr int RPE = (EPI && KB >= 36) ? 1 : 2;    // rows per epilogue region
+  constexpr int NES = ROWS / RPE;                   // epilogue regions: k-blocks [1, 1 + NES)
+  constexpr int NLD = EPI ? 4 : 0;                  // operand-request regions: k-blocks [0, NLD) of the unit they belong to
+  constexpr int S0 = 1 + NES;                       // staging chunks: k-block 0 and [S0, KB) of unit h = 1
+  constexpr int CPS = KB >= 36 ? 1 : 2;             // staging chunks per region
+  static_assert((1 + (KB - S0)) * CPS >= NSC, "the staging chunks fit in one unit");
+  static_assert(S0 <= KB, "the epilogue fits in one unit");
+  // A VALU read of ANY accumulator register stalls until the MFMAs in flight have drained (measured: ~210 cycles per
+  // v_accvgpr_read in the loop, 3.3 us per tile), so a unit's sums leave the AGPRs once, right after its last MFMA, and the
+  // epilogue rows in the next unit's shadow work on that copy.
+  f32x16 acc;
+  float fin[ROWS];
+  // epilogue operands of unit h live in set h: requested in the first k-blocks of their unit, consumed in the next unit's
+  // epilogue rows a whole unit (> 2 us) later -- one set, requested after the previous rows were done, left ~1 us
+  float gvs[2][16], avs[2][16], part[8];  // KS == 2: part = the partner wave's half sums of the previous unit
+  // The first unit's epilogue slots have no previous unit: they store zeros where the SAME wave stores (tile wg, h = 1) one
+  // unit later (same address, program order).  Host: whole tiles only (N % NPG == 0), so every frame exists.
+  unsigned ob_prev = (unsigned)(wg * NPG + pgi) * (unsigned)(NCT * 32 * 64) + (unsigned)(cbase * 64 + il) + 32u;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) gvs[0][r] = gvs[1][r] = avs[0][r] = avs[1][r] = 0.f;
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) fin[r] = 0.f;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) part[r] = 0.f;
+  const float* gsrc = EPI ? (actgrad_in ? actgrad_in : add_in) : nullptr;  // host: EPI launches have at least one operand
+  const float* asrc = EPI ? (add_in ? add_in : actgrad_in) : nullptr;
+  const bool has_g = actgrad_in != nullptr, has_a = add_in != nullptr;
+  auto row_off = [](int r) { return (unsigned)(((r & 3) + 8 * (r >> 2)) * 64); };
+  // finished value of row j of the previous unit (accumulator pp), stored when its frame exists
+  auto epi_row = [&](int set, int j) {
+    float v = fin[j];
+    int r = j;
+    if (KS == 2) v += part[j];
+    if (EPI) {
+      float gm = act_grad_sel(gvs[set][r]);
+      asm volatile("" : "+v"(gm));
+      gm = has_g ? gm : 1.f;
+      const float am = has_a ? avs[set][r] : 0.f;
+      v = v * gm + am;
+    }
+    return v;
+  };
+
+  struct Frag { bf16x8 b[2]; };
   int it_no = 0;
   for (int tile = wg; tile < ntiles; tile += nwg, ++it_no) {
     const int buf = it_no & 1;
-    MTRSSM_RES_STAMP(0);
     const unsigned char* img = patch + (size_t)buf * 2 * IMG;
-    {
-      const int next = tile + nwg;
-      stage_load(next < ntiles ? next : tile);  // unconditional: no load inside a branch
-    }
-    // epilogue operands of this tile: requested now, consumed after the MFMA loop
-    const int frame = tile * NPG + pgi;
-    const bool fv = frame < nframes;
-    const unsigned obase = (unsigned)(fv ? frame : nframes - 1) * (unsigned)(NCT * 32 * 64);
-    constexpr int NE = KS == 2 ? 1 : 2;  // pixel tiles this wave finishes (KS == 2: tile kh, its partner the other one)
-    // Epilogue operands (act'(x) input, skip gradient): ONE pixel tile's worth of registers.  Tile 0's are requested in
-    // the middle of the MFMA loop (in the registers the staging has just freed); tile 1's lines are only touched there
-    // so that its real loads, issued after tile 0 is combined, hit in L2.
-    float gv[16], av[16];
-    unsigned ob[NE];
+    const int next = tile + nwg < ntiles ? tile + nwg : tile;
+    const unsigned obase = (unsigned)(tile * NPG + pgi) * (unsigned)(NCT * 32 * 64) + (unsigned)(cbase * 64 + il);
+    MTRSSM_RES_STAMP(0);
 #pragma unroll
-    for (int e = 0; e < NE; ++e) ob[e] = obase + (unsigned)(cbase * 64 + (KS == 2 ? kh : e) * 32 + il);
-    auto epi_load = [&](int e) {
-      if (actgrad_in) {
+    for (int h = 0; h < 2; ++h) {
+      const unsigned ob_cur = obase + (unsigned)(h * 32);
+      const unsigned ibase = (unsigned)(uintptr_t)img + (unsigned)pos0[h];  // LDS byte address (low half of the flat address)
+      auto read_frag = [&](Frag& f, int kb) {
+        const int t = kb / CB, cb = kb % CB;
+        const int toff = (t / 3 - 1) * trow + (t % 3 - 1) * tstep;  // scalar
+        res_read_pair<IMG>(f.b[0], f.b[1], ibase + (unsigned)toff, cb);
+      };
+      // fragments are requested two blocks ahead
+      Frag fr[3];
+      read_frag(fr[0], 0);
+      read_frag(fr[1], 1);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) gv[r] = actgrad_in[ob[e] + (unsigned)(((r & 3) + 8 * (r >> 2)) * 64)];
-      }
-      if (add_in) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) av[r] = add_in[ob[e] + (unsigned)(((r & 3) + 8 * (r >> 2)) * 64)];
-      }
-    };
-    // one load touches all of tile 1's lines: 32 channel rows x 128 bytes of each operand = 64 lines, one per lane; its
-    // value is never used, only kept (one register) until the loop is over so that the compiler counts the load
-    float touched = 0.f;
-    auto epi_touch = [&]() {
-      const float* base = (lane < 32 || !add_in) ? actgrad_in : add_in;
-      if (!base) base = add_in;
-      if (base) touched = base[obase + (unsigned)((ct * 32 + (lane & 31)) * 64 + 32)];
-    };
-    f32x16 acc[2];
-#pragma unroll
-    for (int pt = 0; pt < 2; ++pt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[pt][r] = 0.f;
-
-    auto read_frag = [&](Frag& f, int kb) {
-      const int t = kb / CB, cb = kb % CB;
-      const int toff = (t / 3 - 1) * trow + (t % 3 - 1) * tstep;  // scalar
-#pragma unroll
-      for (int pt = 0; pt < 2; ++pt) {
-        const unsigned char* ad = img + (pos0[pt] + toff) + cb * 32;
-        f.b[pt][0] = *reinterpret_cast<const bf16x8*>(ad);
-        f.b[pt][1] = *reinterpret_cast<const bf16x8*>(ad + IMG);
-      }
-    };
-    // The scheduler, left alone, sinks every ds_read_b128 of the unrolled loop in front of its MFMA (register pressure
-    // beats latency there: 58 instead of 32 cycles per MFMA measured); the barriers pin "next block's reads, then this
-    // block's MFMAs".
-    // Fragments are requested TWO blocks ahead: the compiler waits with lgkmcnt(0) (scalar loads share the counter), i.e.
-    // also for the newest reads, which by then are a whole block of MFMAs old.
-    Frag fr[3];
-    read_frag(fr[0], 0);
-    read_frag(fr[1], 1);
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-      Frag& cur = fr[kb % 3];
-      if (kb + 2 < KB) read_frag(fr[(kb + 2) % 3], kb + 2);
+      for (int r = 0; r < 16; ++r) acc[r] = bv[r];
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int pt = 0; pt < 2; ++pt) {
-        acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kb][0], cur.b[pt][1], acc[pt], 0, 0, 0);
-        acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kb][1], cur.b[pt][0], acc[pt], 0, 0, 0);
-        acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kb][0], cur.b[pt][0], acc[pt], 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (kb == KB / 2) {
-        MTRSSM_RES_STAMP(1);
-        stage_store(buf ^ 1);  // the next tile's image: conversions in the MFMAs' shadow
-        epi_load(0);
-        if (NE == 2) epi_touch();
-        MTRSSM_RES_STAMP(2);
-      }
-    }
-    MTRSSM_RES_STAMP(3);
-    f32x16 fin[NE];
-    if (KS == 2) {  // the two halves of K meet: each wave hands over the pixel tile it does not finish
-      float* mine = red + ((size_t)(ct * 2 + kh) * 16) * 64 + lane;
-      const float* theirs = red + ((size_t)(ct * 2 + (kh ^ 1)) * 16) * 64 + lane;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mine[r * 64] = kh == 0 ? acc[1][r] : acc[0][r];
-      lds_barrier();
-#pragma unroll
-      for (int r = 0; r < 16; ++r) fin[0][r] = (kh == 0 ? acc[0][r] : acc[1][r]) + theirs[r * 64];
-    } else {
-#pragma unroll
-      for (int e = 0; e < NE; ++e) fin[e] = acc[e];
-    }
-#pragma unroll
-    for (int e = 0; e < NE; ++e) {
-      if (e > 0) {
-        asm volatile("" ::"v"(touched));
-        epi_load(e);
-      }
-      float res[16];
-      if (actgrad_in) {  // act'(x) from the layer input x: one workgroup-uniform branch per tile, not per element
-        if (g.act == MTRSSM_ACT_ELU) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) gv[r] = gv[r] > 0.f ? 1.f : __expf(gv[r]);
-        } else if (g.act == MTRSSM_ACT_RELU) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) gv[r] = gv[r] > 0.f ? 1.f : 0.f;
+      for (int kb = 0; kb < KB; ++kb) {
+        Frag& cur = fr[kb % 3];
+        if (kb + 2 < KB) {
+          read_frag(fr[(kb + 2) % 3], kb + 2);
+          res_wait<4>(cur.b[0], cur.b[1]);
+        } else if (kb + 1 < KB) {
+          res_wait<2>(cur.b[0], cur.b[1]);
         } else {
+          res_wait<0>(cur.b[0], cur.b[1]);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kb][0], cur.b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kb][1], cur.b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kb][0], cur.b[0], acc, 0, 0, 0);
+        // ---- the shadow work of this k-block
+        if (kb >= 1 && kb < 1 + NES) {  // epilogue rows of the previous unit
+          float res[RPE];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) gv[r] = 1.f;
+          for (int i = 0; i < RPE; ++i) res[i] = epi_row(h ^ 1, (kb - 1) * RPE + i);
+#pragma unroll
+          for (int i = 0; i < RPE; ++i) {
+            const int j = (kb - 1) * RPE + i;
+            out[ob_prev + row_off(j) + (KS == 2 ? (unsigned)(kh * 16 * 64) : 0u)] = res[i];
+          }
+        }
+        if (EPI && kb < NLD) {  // this unit's epilogue operands, into set h
+          // one base pointer per operand and half of the rows: the row offsets stay inside the 12-bit immediate (computed
+          // as 32 separate 64-bit addresses they cost 64 registers for a whole tile)
+          constexpr int RPL = ROWS / 4;
+#pragma unroll
+          for (int i = 0; i < RPL; ++i) {
+            const int j = kb * RPL + i;
+            const unsigned ob2 = ob_cur + (KS == 2 ? (unsigned)(kh * 16 * 64) : 0u) + (j >= 8 ? 16u * 64u : 0u);
+            const float* gp = gsrc + ob2;
+            const float* ap = asrc + ob2;
+            asm volatile("" : "+v"(gp), "+v"(ap));
+            gvs[h][j] = gp[row_off(j & 7)];
+            avs[h][j] = ap[row_off(j & 7)];
+          }
+        }
+        if (h == 0 && kb >= NLD && kb < NLD + 4) stage_load_part(next, kb - NLD, 4);
+        if (h == 1) {
+          const int slot = kb == 0 ? 0 : (kb >= S0 ? 1 + (kb - S0) : NSC);
+#pragma unroll
+          for (int i = 0; i < CPS; ++i)
+            if (slot * CPS + i < NSC) stage_store_chunk(buf ^ 1, slot * CPS + i);
+        }
+        MTRSSM_SGB(0x008, 1);
+        MTRSSM_SGB(0x002, 6);
+        MTRSSM_SGB(0x008, 1);
+        MTRSSM_SGB(0x002, 6);
+        MTRSSM_SGB(0x008, 1);
+        MTRSSM_SGB(0x002, 6);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (h == 0) MTRSSM_RES_STAMP(1);
+      if (KS == 2) {  // the two halves of K meet: each wave hands over the rows it does not finish
+        float* mine = red + ((size_t)(ct * 2 + kh) * 8) * 64 + lane;
+        const float* theirs = red + ((size_t)(ct * 2 + (kh ^ 1)) * 8) * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mine[j * 64] = kh == 0 ? acc[8 + j] : acc[j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          fin[j] = kh == 0 ? acc[j] : acc[8 + j];
+          asm volatile("" : "+v"(fin[j]));  // architectural VGPRs: a store sourcing an AGPR stalls like the read does
+        }
+        lds_barrier();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) part[j] = theirs[j * 64];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          fin[j] = acc[j];
+          asm volatile("" : "+v"(fin[j]));  // architectural VGPRs: a store sourcing an AGPR stalls like the read does
         }
       }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = fin[e][r] + bias_lds[cbase + (r & 3) + 8 * (r >> 2)];
-        if (actgrad_in) v *= gv[r];
-        if (add_in) v += av[r];
-        res[r] = v;
-      }
-      if (fv) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) out[ob[e] + (unsigned)(((r & 3) + 8 * (r >> 2)) * 64)] = res[r];
-      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (h == 0) MTRSSM_RES_STAMP(2);
+      ob_prev = ob_cur;
     }
     MTRSSM_RES_STAMP(4);
     lds_barrier();  // the next image is complete; everyone is done reading this one (LDS only: a __syncthreads would also
                     // wait for this tile's stores and the next tile's frames in flight)
     MTRSSM_RES_STAMP(5);
   }
+  // ---- drain: the last unit's epilogue (accumulator 1)
+#pragma unroll
+  for (int j = 0; j < ROWS; ++j) out[ob_prev + row_off(j) + (KS == 2 ? (unsigned)(kh * 16 * 64) : 0u)] = epi_row(1, j);
 }
 
 }  // namespace mtrssm

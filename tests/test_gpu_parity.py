@@ -441,13 +441,14 @@ CONV_CASES = [
     (70, 16, 8, 8, 64, 1, 1, 0, True, False),   # ... more k-steps than one per workgroup slice boundary (280 k-steps)
     (6, 64, 8, 8, 128, 1, 1, 0, True, False),   # ... decoder residual 1x1 (64 -> 128): 4 x 2 tiles, 8 waves
     (3, 128, 4, 4, 100, 1, 1, 0, True, False),  # ... 4 x 4 tiles, 16 waves, ragged Cout
-    (5, 64, 8, 8, 64, 3, 1, 1, True, False),    # residual 3x3 on 8x8 planes: weight-resident gather (conv3x3_resident_kernel<64, 2, 1>), odd frame count
+    (6, 64, 8, 8, 64, 3, 1, 1, True, False),    # residual 3x3 on 8x8 planes: weight-resident gather (conv3x3_resident_kernel<64, 2, 1>)
     (7, 64, 8, 8, 128, 3, 1, 1, True, False),   # ... decoder residual 64 -> 128 (<64, 4, 1>); its backward-data is <128, 2, 2> (K split over wave pairs)
     (5, 128, 8, 8, 64, 3, 1, 1, False, False),  # ... 128 -> 64 forward (<128, 2, 2>), backward-data <64, 4, 1>, no activation
-    (9, 32, 8, 8, 64, 3, 1, 1, True, False),    # ... encoder 32 -> 64 (<32, 2, 1>)
+    (10, 32, 8, 8, 64, 3, 1, 1, True, False),   # ... encoder 32 -> 64 (<32, 2, 1>)
     (6, 64, 16, 4, 64, 3, 1, 1, True, False),   # ... 16x4 audio plane (18 x 6 haloed image); (3, 64, 16, 4, ...) above is the same shape
     (5, 64, 4, 16, 128, 3, 1, 1, True, False),  # ... 4x16 plane
-    (601, 64, 8, 8, 64, 3, 1, 1, True, False),  # ... more tiles than workgroups: the persistent loop, double-buffered images, ragged last tile
+    (1300, 64, 8, 8, 64, 3, 1, 1, True, False), # ... more tiles than workgroups (650 on 256): the persistent loop, double-buffered images
+    (7, 64, 8, 8, 64, 3, 1, 1, True, False),    # ... odd frame count: no whole tiles, the patch-staged kernel takes it
 ]
 
 

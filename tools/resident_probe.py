@@ -40,13 +40,11 @@ if os.environ.get("STAMPS"):
     torch.cuda.synchronize()
     assert fn(None) == 0
     st = prof.cpu().tolist()
-    print("prologue cycles:", st[1] - st[0], "zero fill", st[56] - st[0], "weights issued", st[57] - st[56], "stage loads issued", st[58] - st[57],
-          "barrier (all loads landed)", st[59] - st[58], "first image", st[1] - st[59])
+    print("prologue cycles:", st[1] - st[0], "weights", st[56] - st[0], "zero fill + bias", st[57] - st[56], "first image", st[1] - st[57])
     for k in range(6):
         r = st[2 + 8 * k: 2 + 8 * k + 6]
         if r[0]:
-            print("tile", k, "first half", r[1] - r[0], "stage+epi issue", r[2] - r[1], "second half", r[3] - r[2], "epilogue", r[4] - r[3],
-                  "barrier", r[5] - r[4], "total", r[5] - r[0])
+            print("tile", k, "unit 0 loop", r[1] - r[0], "copy out", r[2] - r[1], "unit 1", r[4] - r[2], "barrier", r[5] - r[4], "total", r[5] - r[0])
 if frames <= 64:
     want = F.conv2d(F.elu(x) if PRE else x, wt, b, 1, 1)
     want.backward(gout)
