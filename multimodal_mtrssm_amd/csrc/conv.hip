@@ -1030,6 +1030,7 @@ struct SplitPlan {
   int kind = 0;  // 0: not covered, 1: conv1x1_split_kernel, 2: conv_gather_split_kernel, 3: conv3x3_resident_kernel
   int tco = 0, ny = 0, nx = 0, sp = 0, pit = 0, tgs = 0, ngroups = 0;
   int res = 0;  // kind 3: CIN * 1000 + Cout (the instantiation)
+  int stream = 0;  // kind 1: CIN * 1000 + Cout when conv1x1_stream_kernel covers the shape (operands decide at launch)
   size_t lds = 0;
   bool same_kernel(const SplitPlan& o) const {
     if (kind == 3) return o.kind == 3 && res == o.res;
@@ -1085,6 +1086,10 @@ static SplitPlan plan_split(const MtrssmConvGeom* g, bool has_wq) {
       g->Ho == g->Hq && g->Wo == g->Wq && g->Cpad % 64 == 0) {  // 1x1 layers: 64 channels per step
     pl.kind = 1;
     pl.lds = (size_t)sp * (kTP + pl.tco) * 128;
+    const int key = g->C * 1000 + g->Cout;
+    if (sp == 2 && resident_enabled() && (key == 64064 || key == 128064 || key == 64128) && g->Cpad == g->C && g->CoutPad == g->Cout &&
+        (g->Hq * g->Wq) % 32 == 0 && g->act != MTRSSM_ACT_TANH && (long)g->N * g->C * g->Hq * g->Wq < (1L << 31))
+      pl.stream = key;
     return pl;
   }
   auto lds_of = [&](int t) { return (size_t)sp * ((size_t)pg.ps_raw * kRowB + (size_t)t * pl.tco * kRowB); };
@@ -1159,6 +1164,39 @@ static int launch_split(const SplitPlan& pl, size_t lds, const GatherProblem& pa
 #undef MTRSSM_RES_LAUNCH
     set_error("conv_gather_gemm: no resident kernel for this plan");
     return MTRSSM_EINVAL;
+  }
+  if (pl.kind == 1 && pl.stream != 0) {
+    // conv1x1_stream_kernel: forward (bias + skip) or backward-data (act'(h)) of the residual blocks' 1x1 conv; anything else
+    // (no operand, both operands) stays on conv1x1_split_kernel
+    auto dir = [](const GatherProblem& q) { return q.add_in && !q.actgrad_in ? 1 : (q.actgrad_in && !q.add_in && !q.bias ? 2 : 0); };
+    const int da = dir(pa), db = pb.nx > 0 ? dir(pb) : da;
+    const bool same_shape = pb.nx == 0 || (pb.g.C == pa.g.C && pb.g.Cout == pa.g.Cout);
+    if (da != 0 && da == db && same_shape) {
+      const long ta = (long)pa.g.N * (pa.g.Hq * pa.g.Wq / 32), tb = pb.nx > 0 ? (long)pb.g.N * (pb.g.Hq * pb.g.Wq / 32) : 0;
+      const long wa = (ta + 3) / 4, wb = (tb + 3) / 4;  // workgroups that would get at least one tile per wave
+      const int ncu = cu_count();
+      GatherProblem qa = pa, qb = pb;
+      if (tb == 0) {
+        qa.nx = (int)(wa < ncu ? wa : ncu);
+        qb.nx = 0;
+      } else {
+        long na = (ncu * ta + (ta + tb) / 2) / (ta + tb);
+        na = na < 1 ? 1 : (na > ncu - 1 ? ncu - 1 : na);
+        qa.nx = (int)(na < wa ? na : wa);
+        qb.nx = (int)(ncu - na < wb ? ncu - na : wb);
+      }
+      const dim3 sgrid((unsigned)(qa.nx + qb.nx));
+#define MTRSSM_STREAM_LAUNCH(CIN_, COUT_, FWD_)                                                                      \
+  {                                                                                                                   \
+    set_last_kernel("mtrssm::conv1x1_stream_kernel<" #CIN_ ", " #COUT_ ", " #FWD_ ">");                                \
+    hipLaunchKernelGGL((conv1x1_stream_kernel<CIN_, COUT_, FWD_>), sgrid, dim3(kResThreads), 0, stream, qa, qb);      \
+    return launched("conv_gather_gemm(1x1 stream)");                                                                  \
+  }
+      if (pl.stream == 64064) { if (da == 1) MTRSSM_STREAM_LAUNCH(64, 64, true) else MTRSSM_STREAM_LAUNCH(64, 64, false) }
+      if (pl.stream == 128064 && da == 1) MTRSSM_STREAM_LAUNCH(128, 64, true)
+      if (pl.stream == 64128 && da == 2) MTRSSM_STREAM_LAUNCH(64, 128, false)
+#undef MTRSSM_STREAM_LAUNCH
+    }
   }
   const dim3 grid((unsigned)(pa.nx + pb.nx), pl.ny);
   const int sp = pl.sp;

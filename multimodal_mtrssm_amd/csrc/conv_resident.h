@@ -396,4 +396,138 @@ __global__ __launch_bounds__(kResThreads, 1) void conv3x3_resident_kernel(const 
   for (int j = 0; j < ROWS; ++j) out[ob_prev + row_off(j) + (KS == 2 ? (unsigned)(kh * 16 * 64) : 0u)] = epi_row(1, j);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Streaming 1x1 kernel for the residual stacks' second conv (forward with bias + skip, backward-data with act'(h)).
+//
+// K = Cin is 64 or 128: 24..48 MFMAs per 32 pixels against 16..32 KB of HBM traffic -- a bandwidth problem
+// (conv1x1_split_kernel: 1.9 TB/s through two LDS images, two barriers per 128 pixels).  Here nothing meets in LDS and
+// no wave waits for another: lanes = 32 consecutive pixels of one plane (a 128-byte segment per channel), the lane's
+// half kl of every 16-channel k-block = 8 loads that ARE the MFMA B operand once activated and split, the whole weight
+// matrix sits in AGPRs as A operands (<= 128 registers), and a wave walks its own tiles with the next tile's pixels
+// and this tile's epilogue operand in flight under the conversions and MFMAs of the current one.  One wave per SIMD,
+// 96 KB of requests in flight per CU.
+// ------------------------------------------------------------------------------------------------
+template <int CIN, int COUT, bool FWD>  // FWD: out = acc + bias + add_in;  !FWD: out = acc * act'(actgrad_in)
+__global__ __launch_bounds__(kResThreads, 1) void conv1x1_stream_kernel(const GatherProblem pa, const GatherProblem pb) {
+  constexpr int CT = COUT / 32, CB = CIN / 16;
+  const bool second = blockIdx.x >= (unsigned)pa.nx;  // workgroup-uniform
+  const GatherProblem P = second ? pb : pa;
+  const MtrssmConvGeom g = P.g;
+  const float* __restrict__ src = P.src;
+  const unsigned short* __restrict__ wq = P.wq;
+  const float* __restrict__ bias = P.bias;
+  const float* __restrict__ opnd = FWD ? P.add_in : P.actgrad_in;  // host: the one operand this variant takes is present
+  float* __restrict__ out = P.out;
+  const int wg = second ? (int)blockIdx.x - pa.nx : (int)blockIdx.x, nwg = P.nx;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int kl = lane >> 5, il = lane & 31;
+  const int plane = g.Hq * g.Wq;           // host: plane % 32 == 0
+  const int tpf = plane >> 5;              // 32-pixel tiles per frame
+  const int ntiles = g.N * tpf;
+  const int nwv = nwg * 4;
+  int t = wg * 4 + wave;
+  if (t >= ntiles) return;  // wave-uniform; no barrier in this kernel
+
+  bf16x8 a[CT][CB][2];
+  {
+    const size_t piece = (size_t)g.CoutPad * g.Cpad;  // host: Cpad == CIN, CoutPad == COUT
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          a[ct][cb][s] = __builtin_bit_cast(
+              bf16x8, *reinterpret_cast<const u32x4*>(wq + s * piece + (size_t)(ct * 32 + il) * CIN + cb * 16 + 8 * kl));
+          asm volatile("" : "+a"(a[ct][cb][s]));  // AGPRs: the VGPR half belongs to the streams (conv3x3_resident_kernel)
+        }
+  }
+  float bv[CT][16];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bv[ct][r] = (FWD && bias) ? bias[ct * 32 + 4 * kl + (r & 3) + 8 * (r >> 2)] : 0.f;
+  const bool act_elu = g.act == MTRSSM_ACT_ELU, act_relu = g.act == MTRSSM_ACT_RELU, pre = g.pre_act != 0;
+
+  auto in_ptr = [&](int tile) {  // this lane's pixel of the tile, channel 8 * kl
+    const int n = tile / tpf, hw = (tile - n * tpf) * 32 + il;
+    return src + ((size_t)n * CIN + 8 * kl) * plane + hw;
+  };
+  auto io_off = [&](int tile) {  // element offset of this lane's pixel, output channel 4 * kl
+    const int n = tile / tpf, hw = (tile - n * tpf) * 32 + il;
+    return ((size_t)n * COUT + 4 * kl) * plane + hw;
+  };
+  float pv[CB][8], nx[CB][8];
+  {
+    const float* p = in_ptr(t);
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) pv[cb][u] = p[(size_t)(cb * 16 + u) * plane];
+  }
+  for (; t < ntiles; t += nwv) {
+    const int tn = t + nwv < ntiles ? t + nwv : t;
+    {  // the next tile's pixels
+      const float* p = in_ptr(tn);
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) nx[cb][u] = p[(size_t)(cb * 16 + u) * plane];
+    }
+    const size_t oo = io_off(t);
+    float op[CT][16];  // this tile's epilogue operand
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) op[ct][r] = opnd[oo + (size_t)(ct * 32 + (r & 3) + 8 * (r >> 2)) * plane];
+    f32x16 acc[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ct][r] = bv[ct][r];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+      u16x8 qh, ql;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float x = pv[cb][u];
+        float e = __expf(x) - 1.f;
+        const float neg = act_elu ? e : (act_relu ? 0.f : x);
+        const float y = (x > 0.f || !pre) ? x : neg;
+        unsigned short p2[2];
+        split_bf16<2>(y, p2);
+        qh[u] = p2[0];
+        ql[u] = p2[1];
+      }
+      const bf16x8 bh = __builtin_bit_cast(bf16x8, qh), bl = __builtin_bit_cast(bf16x8, ql);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ct][cb][0], bl, acc[ct], 0, 0, 0);
+        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ct][cb][1], bh, acc[ct], 0, 0, 0);
+        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ct][cb][0], bh, acc[ct], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[ct][r];
+        if (FWD) {
+          v += op[ct][r];
+        } else {
+          const float x = op[ct][r];
+          const float e = __expf(x);
+          const float neg = act_elu ? e : (act_relu ? 0.f : 1.f);
+          v *= x > 0.f ? 1.f : neg;
+        }
+        out[oo + (size_t)(ct * 32 + (r & 3) + 8 * (r >> 2)) * plane] = v;
+      }
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) pv[cb][u] = nx[cb][u];
+  }
+}
+
 }  // namespace mtrssm

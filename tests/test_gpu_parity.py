@@ -441,6 +441,7 @@ CONV_CASES = [
     (70, 16, 8, 8, 64, 1, 1, 0, True, False),   # ... more k-steps than one per workgroup slice boundary (280 k-steps)
     (6, 64, 8, 8, 128, 1, 1, 0, True, False),   # ... decoder residual 1x1 (64 -> 128): 4 x 2 tiles, 8 waves
     (3, 128, 4, 4, 100, 1, 1, 0, True, False),  # ... 4 x 4 tiles, 16 waves, ragged Cout
+    (6, 128, 8, 8, 64, 1, 1, 0, True, False),   # 1x1, 128 -> 64: its backward-data (64 -> 128 with act') runs conv1x1_stream_kernel<64, 128, false>; (7, 64, 8, 8, 64, 1, ...) above <64, 64, false>
     (6, 64, 8, 8, 64, 3, 1, 1, True, False),    # residual 3x3 on 8x8 planes: weight-resident gather (conv3x3_resident_kernel<64, 2, 1>)
     (7, 64, 8, 8, 128, 3, 1, 1, True, False),   # ... decoder residual 64 -> 128 (<64, 4, 1>); its backward-data is <128, 2, 2> (K split over wave pairs)
     (5, 128, 8, 8, 64, 3, 1, 1, False, False),  # ... 128 -> 64 forward (<128, 2, 2>), backward-data <64, 4, 1>, no activation
