@@ -396,14 +396,23 @@ def main() -> None:  # noqa: PLR0914, PLR0915
             if "conv" in name and "thin" not in name:
                 # algorithmic FLOPs (each multiply-add counted once) against the rate at which the MFMA pipe can deliver
                 # them in this operand format: fp32 MFMA 157.3 TFLOP/s; split kernels issue `products` bf16 MFMAs per
-                # algorithmic block, so their ceiling is the dense bf16 peak / products (bf16x2: 2500 / 3 = 833).
-                split = "split_kernel" in name
+                # algorithmic block, so their ceiling is the dense bf16 peak / products (bf16x2: 2500 / 3 = 833).  The roof
+                # that binds is the roofline model's: a kernel whose arithmetic intensity (algorithmic FLOPs per
+                # algorithmic byte) lies below the ridge peak / HBM rate is priced against HBM, above it against the MFMA.
+                split = any(tag in name for tag in ("split_kernel", "resident_kernel", "stream_kernel"))
                 products = MFMA_PRODUCTS[args.conv_mfma] if split else 1
                 peak = MFMA_BF16_PEAK_TFLOPS / products if split else MFMA_F32_PEAK_TFLOPS
                 achieved = row["flops"] / secs / 1e12
-                roof.update(bound="mfma", achieved=achieved, peak=peak, unit="TFLOP/s", frac=achieved / peak,
-                            mfma_products_per_block=products, frac_of_raw_bf16_peak=achieved / MFMA_BF16_PEAK_TFLOPS,
-                            hbm_frac=row["bytes"] / secs / 1e9 / HBM_PEAK_GBS)
+                gbs = row["bytes"] / secs / 1e9
+                intensity = row["flops"] / row["bytes"] if row["bytes"] else float("inf")
+                ridge = peak * 1e12 / (HBM_PEAK_GBS * 1e9)
+                if intensity >= ridge:
+                    roof.update(bound="mfma", achieved=achieved, peak=peak, unit="TFLOP/s", frac=achieved / peak)
+                else:
+                    roof.update(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS)
+                roof.update(mfma_products_per_block=products, mfma_frac=achieved / peak, hbm_frac=gbs / HBM_PEAK_GBS,
+                            flops_per_byte=intensity, ridge_flops_per_byte=ridge,
+                            frac_of_raw_bf16_peak=achieved / MFMA_BF16_PEAK_TFLOPS)
             else:
                 achieved = row["bytes"] / secs / 1e9
                 roof.update(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS)
@@ -413,7 +422,8 @@ def main() -> None:  # noqa: PLR0914, PLR0915
                         share_of_step=row["total_ms"] / n_steps / ms)
         roof["kernels"] = {k: {"launches_per_step": v["launches"] / 3, "avg_us": round(v["avg_ms"] * 1e3, 1),
                                "ms_per_step": round(v["total_ms"] / 3, 3),
-                               "tflops": round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 2) if v["total_ms"] else None}
+                               "tflops": round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 2) if v["total_ms"] else None,
+                               "gbs": round(v["bytes"] / (v["total_ms"] * 1e-3) / 1e9, 1) if v["total_ms"] else None}
                            for k, v in sorted(kernel_ms.items(), key=lambda kv: -kv[1]["total_ms"])}
         line = {
             "metric": {"mrssm": "seq-steps/s (BxT) MoPoE-MRSSM train step", "mmtrssm": "seq-steps/s (BxT) MoPoE-MMTRSSM train step",

@@ -13,12 +13,12 @@ Both take arbitrary leading batch dims (``[B,T,C,H,W]`` and ``[B,C,H,W]`` are bo
 ``mrssm/mopoe_mrssm/core.py:179-180,215-216,272-273``).  Frames are folded to one ``[B*T, C, H, W]`` batch so
 every layer is a single dense launch over all B*T frames.
 
-Every convolution runs on the hand-written fp32-MFMA implicit-GEMM kernels of ``csrc/conv.hip`` (``conv.py``):
-because each stack is "activation -> conv" throughout, the activation is fused into the consumer's operand
-staging (``pre_act``) and never materialised; bias is fused into the epilogue; the backward kernels fuse the
-multiplication by act'(x).  The Linear layers are plain library GEMMs (rocBLAS via ``F.linear``); the few
-remaining elementwise ops (final activation before ``flatten``, residual adds, ``tanh``) are torch elementwise
-kernels.  No MIOpen call is made anywhere (its first-run kernel JIT costs minutes on a fresh box).
+Every convolution runs on the hand-written MFMA implicit-GEMM kernels of ``csrc/conv.hip`` / ``conv_split.h`` /
+``conv_resident.h`` (``conv.py``): because each stack is "activation -> conv" throughout, the activation is fused into the
+consumer's operand staging (``pre_act``) and never materialised; bias is fused into the epilogue; the backward kernels fuse the
+multiplication by act'(x).  The Linear layers run on ``csrc/gemm.hip`` (``linear.linear``: fp32 MFMA with the activation of
+the operand, bias, and the gradients' epilogues fused).  No rocBLAS / MIOpen call is made anywhere (MIOpen's first-run kernel
+JIT costs minutes on a fresh box).
 The nn.Conv2d / nn.ConvTranspose2d / nn.Linear objects below are parameter containers only.
 """
 
