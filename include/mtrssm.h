@@ -517,6 +517,9 @@ typedef struct MtrssmGemm {
   int32_t a_rmajor, b_rmajor, act_a, act_b, act_out, act_z, accumulate, split_r;
   int32_t* tickets;   /* optional: >= n_tickets device ints (zeroed by the call).  Lets a reduction be split although the output */
   int32_t n_tickets;  /* has an epilogue (act' of a data gradient): the last slice to arrive at a 64 x 64 tile finishes it */
+  int32_t mfma_split; /* 0: fp32 MFMA (above); 2: every operand value as two bf16 pieces (16 significant bits, made while staging),
+                         three bf16 MFMA products per k-block, fp32 accumulation -- the conv kernels' default arithmetic, for the
+                         large Linear layers inside the conv stacks (cnn.Encoder head, cnn.Decoder stem) */
 } MtrssmGemm;
 int mtrssm_gemm(const MtrssmGemm* g, void* stream);
 

@@ -80,7 +80,7 @@ ConvGeom = _struct("MtrssmConvGeom", [(n, _i) for n in (
 
 Gemm = _struct("MtrssmGemm", _ptrs("A", "B", "C", "bias", "zgrad", "colsum") + [(n, _i) for n in (
     "M", "N", "R", "lda", "ldb", "ldc", "ldz", "a_rmajor", "b_rmajor", "act_a", "act_b", "act_out", "act_z", "accumulate", "split_r")]
-    + [("tickets", _p), ("n_tickets", _i)])
+    + [("tickets", _p), ("n_tickets", _i), ("mfma_split", _i)])
 
 # every symbol include/mtrssm.h declares (tests/test_capi.py checks the header against this list)
 SYMBOLS: dict[str, tuple[type | None, list[type]]] = {

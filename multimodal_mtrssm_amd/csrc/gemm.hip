@@ -272,6 +272,235 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
   if (want_colsum && tid < kTile && i0 + tid < g.M) atomicAdd(g.colsum + i0 + tid, csum);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Split-bf16 variant (MtrssmGemm.mfma_split = 2) for the large GEMMs inside the conv stacks (encoder head, decoder stem:
+// 3200 x 4096 x 256 and its gradients).  Same contract and epilogues; every fp32 operand value becomes two bf16 pieces while
+// it is staged (after the fused activation) and a k-block of 16 is three v_mfma_f32_32x32x16_bf16 (hi*lo + lo*hi + hi*hi,
+// fp32 accumulation): the arithmetic of the conv kernels' default mode (conv_split.h), 16 significant bits per operand.
+// Both operand layouts are staged as "8 consecutive r of one row" per thread (two float4 loads of an r-contiguous operand,
+// eight 4-byte loads -- coalesced across the rows of neighbouring lanes -- of an r-major one), so the LDS images are always
+// [row][32 r] bf16 with an 80-byte pitch (an odd number of 16-byte slots: conflict-free ds_read_b128 fragments) and a
+// k-step costs a wave 12 ds_read_b128 + 12 MFMAs instead of 32 ds_read_b32 + 16 fp32 MFMAs of 64 cycles.
+// Workgroup tile 128 x 64, four waves of 64 x 32 (two accumulators).
+// ------------------------------------------------------------------------------------------------
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u16x8 = __attribute__((ext_vector_type(8))) unsigned short;
+constexpr int kSM = 128, kSN = 64;
+constexpr int kSPitch = kStep * 2 + 16;
+constexpr int kSImgA = kSM * kSPitch, kSImgB = kSN * kSPitch;  // bytes of one piece
+constexpr int kSBuf = 2 * kSImgA + 2 * kSImgB;                 // one buffer: A hi, A lo, B hi, B lo
+
+struct SItem { float v[8]; };
+
+// item idx of an operand tile with TROWS rows: 8 consecutive r of one row, raw (clamped addresses; masked in store_item)
+template <bool RMAJOR, int TROWS>
+__device__ __forceinline__ void load_item(SItem& it, const float* __restrict__ P, int ld, int rows, int row0, int r0, int r_end, int idx,
+                                          bool vec) {
+  if (RMAJOR) {  // memory [r][row]
+    const int row = idx % TROWS, kg = idx / TROWS;
+    const int x = row0 + row < rows ? row0 + row : rows - 1;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int y = r0 + kg * 8 + u;
+      it.v[u] = P[(size_t)(y < r_end ? y : r_end - 1) * ld + x];
+    }
+  } else {  // memory [row][r]
+    const int row = idx >> 2, kg = idx & 3;
+    const float4 q0 = load_quad(P, ld, row0 + row, rows, r0 + kg * 8, r_end, vec);
+    const float4 q1 = load_quad(P, ld, row0 + row, rows, r0 + kg * 8 + 4, r_end, vec);
+    it.v[0] = q0.x; it.v[1] = q0.y; it.v[2] = q0.z; it.v[3] = q0.w;
+    it.v[4] = q1.x; it.v[5] = q1.y; it.v[6] = q1.z; it.v[7] = q1.w;
+  }
+}
+template <bool RMAJOR, int TROWS>
+__device__ __forceinline__ void store_item(const SItem& it, unsigned char* img, int img_bytes, int act, int rows, int row0, int r0, int r_end,
+                                           int idx) {
+  const int row = RMAJOR ? idx % TROWS : idx >> 2, kg = RMAJOR ? idx / TROWS : idx & 3;
+  const bool okrow = row0 + row < rows;
+  float x[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) x[u] = (okrow && r0 + kg * 8 + u < r_end) ? it.v[u] : 0.f;
+  // ONE uniform branch per item (per element it became a branch chain per value: 580 branches in the step, 2x slower than
+  // the fp32 kernel); act(0) = 0 for every supported activation
+  if (act == MTRSSM_ACT_ELU) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) x[u] = x[u] > 0.f ? x[u] : __expf(x[u]) - 1.f;
+  } else if (act == MTRSSM_ACT_RELU) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) x[u] = fmaxf(x[u], 0.f);
+  } else if (act == MTRSSM_ACT_TANH) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) x[u] = 1.f - 2.f / (__expf(2.f * x[u]) + 1.f);
+  }
+  u16x8 hi, lo;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const __bf16 h = (__bf16)x[u];
+    const __bf16 l = (__bf16)(x[u] - (float)h);
+    hi[u] = __builtin_bit_cast(unsigned short, h);
+    lo[u] = __builtin_bit_cast(unsigned short, l);
+  }
+  unsigned char* d = img + row * kSPitch + kg * 16;
+  *reinterpret_cast<u16x8*>(d) = hi;
+  *reinterpret_cast<u16x8*>(d + img_bytes) = lo;
+}
+
+template <bool AR, bool BR>
+__global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kSBuf];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1, il = lane & 31, kl = lane >> 5;
+  const int i0 = blockIdx.y * kSM, j0 = blockIdx.x * kSN;
+  const int steps = (g.R + kStep - 1) / kStep;
+  const int per = (steps + g.splits - 1) / g.splits;
+  const int s_lo = blockIdx.z * per, s_hi = min(steps, s_lo + per);
+  if (s_lo >= s_hi) return;
+  const int r_end = min(g.R, s_hi * kStep);
+  const bool vec_a = ((g.lda & 3) == 0) && (((uintptr_t)g.A & 15) == 0);
+  const bool vec_b = ((g.ldb & 3) == 0) && (((uintptr_t)g.B & 15) == 0);
+  const bool want_colsum = g.colsum && blockIdx.x == 0;
+  float csum = 0.f;
+  f32x16 acc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  // two register stages: the tiles of steps s + 1 and s + 2 are in flight while step s is multiplied out of LDS
+  SItem sa[2][2], sb[2];
+  auto issue = [&](int which, int s) __attribute__((always_inline)) {
+    if (s < s_hi) {
+      load_item<AR, kSM>(sa[which][0], g.A, g.lda, g.M, i0, s * kStep, r_end, tid, vec_a);
+      load_item<AR, kSM>(sa[which][1], g.A, g.lda, g.M, i0, s * kStep, r_end, tid + 256, vec_a);
+      load_item<BR, kSN>(sb[which], g.B, g.ldb, g.N, j0, s * kStep, r_end, tid, vec_b);
+    }
+  };
+  auto to_lds = [&](int which, int s, int buf) __attribute__((always_inline)) {
+    unsigned char* base = lds + buf * kSBuf;
+    store_item<AR, kSM>(sa[which][0], base, kSImgA, g.act_a, g.M, i0, s * kStep, r_end, tid);
+    store_item<AR, kSM>(sa[which][1], base, kSImgA, g.act_a, g.M, i0, s * kStep, r_end, tid + 256);
+    store_item<BR, kSN>(sb[which], base + 2 * kSImgA, kSImgB, g.act_b, g.N, j0, s * kStep, r_end, tid);
+  };
+  auto step = [&](int which, int s, int cur) __attribute__((always_inline)) {  // `which`: the register stage that holds step s + 1
+    if (s + 1 < s_hi) to_lds(which, s + 1, cur ^ 1);
+    issue(which, s + 3);
+    const unsigned char* ia = lds + cur * kSBuf + (wr * 64 + il) * kSPitch + kl * 16;
+    const unsigned char* ib = lds + cur * kSBuf + 2 * kSImgA + (wc * 32 + il) * kSPitch + kl * 16;
+    bf16x8 fa[2][2][2], fb[2][2];  // [k-block][row tile][piece], [k-block][piece]: all reads first, they pipeline under the MFMAs
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      fb[kb][0] = *reinterpret_cast<const bf16x8*>(ib + kb * 32);
+      fb[kb][1] = *reinterpret_cast<const bf16x8*>(ib + kb * 32 + kSImgB);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        fa[kb][t][0] = *reinterpret_cast<const bf16x8*>(ia + t * 32 * kSPitch + kb * 32);
+        fa[kb][t][1] = *reinterpret_cast<const bf16x8*>(ia + t * 32 * kSPitch + kb * 32 + kSImgA);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kb][t][0], fb[kb][1], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kb][t][1], fb[kb][0], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kb][t][0], fb[kb][0], acc[t], 0, 0, 0);
+      }
+    if (want_colsum && tid < kSM) {  // bias gradient: the staged A' row (hi + lo = the fp32 value to 2^-17)
+      const unsigned char* row = lds + cur * kSBuf + tid * kSPitch;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const u16x8 h = *reinterpret_cast<const u16x8*>(row + q * 16), l = *reinterpret_cast<const u16x8*>(row + q * 16 + kSImgA);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) csum += __uint_as_float((unsigned)h[u] << 16) + __uint_as_float((unsigned)l[u] << 16);
+      }
+    }
+    __syncthreads();
+  };
+  issue(0, s_lo);
+  to_lds(0, s_lo, 0);
+  issue(0, s_lo + 1);
+  issue(1, s_lo + 2);
+  __syncthreads();
+  for (int s = s_lo; s < s_hi; s += 2) {
+    step(0, s, 0);
+    if (s + 1 < s_hi) step(1, s + 1, 1);
+  }
+
+  // epilogue: as gemm_f32_kernel, once per 32 x 32 accumulator of the wave
+  const int j = j0 + wc * 32 + il;
+  const bool okj = j < g.N;
+  const int jc = okj ? j : g.N - 1;
+  const bool atomic = g.splits > 1;
+  const bool finalize = atomic && g.tickets != nullptr;
+  const bool colsum_now = want_colsum && tid < kSM && i0 + tid < g.M;
+  if (atomic) {
+    const float bias0 = (g.bias && !finalize && blockIdx.z == 0) ? g.bias[jc] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int ibase = i0 + wr * 64 + t * 32 + 4 * kl;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int i = ibase + (reg & 3) + 8 * (reg >> 2);
+        if (i < g.M && okj) atomicAdd(g.C + (size_t)i * g.ldc + j, acc[t][reg] + bias0);
+      }
+    }
+    if (!finalize) {
+      if (colsum_now) atomicAdd(g.colsum + i0 + tid, csum);
+      return;
+    }
+    __shared__ int last_flag;
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) last_flag = atomicAdd(g.tickets + blockIdx.y * gridDim.x + blockIdx.x, 1) == g.splits - 1;
+    __syncthreads();
+    if (!last_flag) {
+      if (colsum_now) atomicAdd(g.colsum + i0 + tid, csum);
+      return;
+    }
+    __threadfence();
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int ibase = i0 + wr * 64 + t * 32 + 4 * kl;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int i = ibase + (reg & 3) + 8 * (reg >> 2);
+        acc[t][reg] = __hip_atomic_load(g.C + (size_t)(i < g.M ? i : g.M - 1) * g.ldc + jc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+  const float bias = g.bias ? g.bias[jc] : 0.f;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int ibase = i0 + wr * 64 + t * 32 + 4 * kl;
+    float zv[16], cv[16];
+    if (g.zgrad) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int i = ibase + (reg & 3) + 8 * (reg >> 2);
+        zv[reg] = g.zgrad[(size_t)(i < g.M ? i : g.M - 1) * g.ldz + jc];
+      }
+    }
+    if (g.accumulate && !atomic) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int i = ibase + (reg & 3) + 8 * (reg >> 2);
+        cv[reg] = g.C[(size_t)(i < g.M ? i : g.M - 1) * g.ldc + jc];
+      }
+    }
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int i = ibase + (reg & 3) + 8 * (reg >> 2);
+      float v = acc[t][reg] + bias;
+      if (g.act_out) v = act_fwd(v, g.act_out);
+      if (g.zgrad) v *= act_grad_from_in(zv[reg], g.act_z);
+      if (g.accumulate && !atomic) v += cv[reg];
+      if (i < g.M && okj) g.C[(size_t)i * g.ldc + j] = v;
+    }
+  }
+  if (colsum_now) atomicAdd(g.colsum + i0 + tid, csum);
+}
+
 int gemm_launch(const MtrssmGemm* p, hipStream_t stream) {
   if (!p || !p->A || !p->B || !p->C || p->M <= 0 || p->N <= 0 || p->R <= 0) {
     set_error("gemm: null operand or non-positive extent");
@@ -293,7 +522,13 @@ int gemm_launch(const MtrssmGemm* p, hipStream_t stream) {
   g.M = p->M; g.N = p->N; g.R = p->R; g.lda = p->lda; g.ldb = p->ldb; g.ldc = p->ldc; g.ldz = p->ldz;
   g.a_rmajor = p->a_rmajor; g.b_rmajor = p->b_rmajor; g.act_a = p->act_a; g.act_b = p->act_b; g.act_out = p->act_out;
   g.act_z = p->act_z; g.accumulate = p->accumulate;
-  const int ti = (p->M + kTile - 1) / kTile, tj = (p->N + kTile - 1) / kTile;
+  if (p->mfma_split != 0 && p->mfma_split != 2) {
+    set_error("gemm: mfma_split must be 0 (fp32 MFMA) or 2 (two bf16 pieces), got %d", p->mfma_split);
+    return MTRSSM_EINVAL;
+  }
+  const bool split_mfma = p->mfma_split == 2;
+  const int tile_m = split_mfma ? kSM : kTile, tile_n = split_mfma ? kSN : kTile;
+  const int ti = (p->M + tile_m - 1) / tile_m, tj = (p->N + tile_n - 1) / tile_n;
   int splits = p->split_r;
   const int steps = (p->R + kStep - 1) / kStep;
   const bool plain_epilogue = !p->act_out && !p->zgrad;
@@ -328,7 +563,21 @@ int gemm_launch(const MtrssmGemm* p, hipStream_t stream) {
   g.tickets = finalize ? p->tickets : nullptr;
   g.splits = splits;
   const dim3 grid(tj, ti, splits);
-  if (p->a_rmajor && p->b_rmajor) {
+  if (split_mfma) {
+    if (p->a_rmajor && p->b_rmajor) {
+      set_last_kernel("mtrssm::gemm_split_kernel<true, true>");
+      hipLaunchKernelGGL((gemm_split_kernel<true, true>), grid, dim3(256), 0, stream, g);
+    } else if (!p->a_rmajor && p->b_rmajor) {
+      set_last_kernel("mtrssm::gemm_split_kernel<false, true>");
+      hipLaunchKernelGGL((gemm_split_kernel<false, true>), grid, dim3(256), 0, stream, g);
+    } else if (!p->a_rmajor && !p->b_rmajor) {
+      set_last_kernel("mtrssm::gemm_split_kernel<false, false>");
+      hipLaunchKernelGGL((gemm_split_kernel<false, false>), grid, dim3(256), 0, stream, g);
+    } else {
+      set_last_kernel("mtrssm::gemm_split_kernel<true, false>");
+      hipLaunchKernelGGL((gemm_split_kernel<true, false>), grid, dim3(256), 0, stream, g);
+    }
+  } else if (p->a_rmajor && p->b_rmajor) {
     set_last_kernel("mtrssm::gemm_f32_kernel<true, true>");
     hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, stream, g);
   } else if (!p->a_rmajor && p->b_rmajor) {

@@ -75,8 +75,18 @@ def _ld(t: Tensor) -> int:
     return int(t.stride(0)) if t.shape[0] > 1 else max(int(t.stride(0)), int(t.shape[1]))
 
 
+# MFMA operand format of the LARGE GEMMs (>= SPLIT_MIN_FLOPS: the Linear layers inside the conv stacks, cnn.Encoder.head /
+# cnn.Decoder.stem and their gradients): 0 = fp32 MFMA (default); 2 = two bf16 pieces per fp32 operand, the conv kernels'
+# default arithmetic (gemm_split_kernel).  The split kernel is tested and NOT faster (both kernels are
+# bound by the load round trip per k-step, not by the MFMA pipe), so it stays off.  Everything smaller -- the scan's
+# projections, init_proj, the prior head, the scan's weight gradients -- always runs the fp32 MFMA kernel.
+SPLIT_PIECES = 0
+SPLIT_MIN_FLOPS = 5.0e8
+
+
 def gemm(a: Tensor, b: Tensor, c: Tensor, *, a_rmajor: bool, b_rmajor: bool, bias: Tensor | None = None, zgrad: Tensor | None = None,  # noqa: PLR0913
-         colsum: Tensor | None = None, act_a: int = 0, act_b: int = 0, act_z: int = 0, accumulate: bool = False, split_r: int = 0) -> None:
+         colsum: Tensor | None = None, act_a: int = 0, act_b: int = 0, act_z: int = 0, accumulate: bool = False, split_r: int = 0,
+         mfma_split: int | None = None) -> None:
     """``c[i][j] (+)= (bias[j] + sum_r actA(a'(i,r)) actB(b'(j,r))) * act_z'(zgrad[i][j])`` (``include/mtrssm.h: MtrssmGemm``).
     ``a`` is ``[M, R]`` (or ``[R, M]`` when ``a_rmajor``), ``b`` is ``[N, R]`` (or ``[R, N]`` when ``b_rmajor``), ``c`` is ``[M, N]``."""
     m, r = (a.shape[1], a.shape[0]) if a_rmajor else (a.shape[0], a.shape[1])
@@ -96,6 +106,9 @@ def gemm(a: Tensor, b: Tensor, c: Tensor, *, a_rmajor: bool, b_rmajor: bool, bia
     g.a_rmajor, g.b_rmajor = int(a_rmajor), int(b_rmajor)
     g.act_a, g.act_b, g.act_out, g.act_z = int(act_a), int(act_b), 0, int(act_z)
     g.accumulate, g.split_r = int(accumulate), int(split_r)
+    if mfma_split is None:
+        mfma_split = SPLIT_PIECES if 2.0 * m * n * r >= SPLIT_MIN_FLOPS else 0
+    g.mfma_split = int(mfma_split)
     if zgrad is not None and not accumulate:  # a skinny data gradient may split its long reduction: last-arriver epilogue
         tk = _TICKETS.get(a.device)
         if tk is None:

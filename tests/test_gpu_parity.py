@@ -769,11 +769,13 @@ GEMM_CASES = [
 ]
 
 
+@pytest.mark.parametrize("pieces", [0, 2])
 @pytest.mark.parametrize(("m", "n", "r", "a_rm", "b_rm", "extras"), GEMM_CASES)
-def test_gemm_kernel(m: int, n: int, r: int, a_rm: bool, b_rm: bool, extras: str, lib_loaded: None) -> None:  # noqa: PLR0913
+def test_gemm_kernel(m: int, n: int, r: int, a_rm: bool, b_rm: bool, extras: str, pieces: int, lib_loaded: None) -> None:  # noqa: PLR0913
     """mtrssm_gemm against float64 matmul: every layout, ragged tiles, strided views, fused activations / bias / act' / column sums /
-    accumulation.  Tolerance 2e-6 of the result's scale (an fp32 fma chain over <= 4096 terms; the reference's fp32 nn.Linear
-    has the same)."""
+    accumulation, on the fp32 MFMA kernel (pieces = 0: tolerance 2e-6 of the result's scale -- an fp32 fma chain over <= 4096
+    terms; the reference's fp32 nn.Linear has the same) and on the split-bf16 kernel the large Linear layers of the conv stacks use
+    (pieces = 2: operands carry 16 significant bits, 3e-5 of the scale -- the conv kernels' default arithmetic)."""
     import torch.nn.functional as F  # noqa: N812
 
     from multimodal_mtrssm_amd.linear import gemm
@@ -807,15 +809,16 @@ def test_gemm_kernel(m: int, n: int, r: int, a_rm: bool, b_rm: bool, extras: str
     gemm(ag[:, pad:] if pad else ag, bg[:, pad:] if pad else bg, c[:, pad:] if pad else c, a_rmajor=a_rm, b_rmajor=b_rm,
          bias=None if bias is None else bias.to(DEV), zgrad=None if z is None else z.to(DEV), colsum=colsum,
          act_a=2 if "act_a" in extras else 0, act_b=2 if "act_b" in extras else 0, act_z=2 if z is not None else 0,
-         accumulate="acc" in extras)
+         accumulate="acc" in extras, mfma_split=pieces)
     got = c[:, pad:] if pad else c
     scale = float(want.abs().max())
-    np.testing.assert_allclose(_np(got), want.float().numpy(), rtol=1e-5, atol=2e-6 * scale)
+    rtol, tol = (1e-5, 2e-6) if pieces == 0 else (1e-4, 3e-5)
+    np.testing.assert_allclose(_np(got), want.float().numpy(), rtol=rtol, atol=tol * scale)
     if pad and "acc" not in extras:
         assert torch.isnan(c[:, :pad]).all()  # nothing outside the view was written
     if colsum is not None:
         want_cs = colsum0.double() + (a.t() if a_rm else a).double().sum(1)
-        np.testing.assert_allclose(_np(colsum), want_cs.float().numpy(), rtol=1e-5, atol=2e-6 * float(want_cs.abs().max()))
+        np.testing.assert_allclose(_np(colsum), want_cs.float().numpy(), rtol=rtol, atol=tol * float(want_cs.abs().max()))
 
 
 def test_linear_function_and_gradient_sink(lib_loaded: None) -> None:
@@ -966,10 +969,13 @@ def test_captured_train_step_matches_eager(name: str, lib_loaded: None) -> None:
         model = product_from_case(case, oracle, DEV)
         flat = FlatParameters(model, extra=8)
         dp = mt.FlatDataParallel(flat)
-        opt = mt.FlatAdamW(flat, lr=1e-3, clip_norm=10.0)
+        # a small learning rate: with 1e-3 eight steps of a model with discrete samples amplify the arrival order of the fp32
+        # atomics into flipped one-hots and the two trajectories part by 1e-3 (seen in full-suite runs, not in isolation)
+        opt = mt.FlatAdamW(flat, lr=1e-5, clip_norm=10.0)
         source = dp.noise_source(seed=11)
         shapes = model.noise_shapes(6, 9)
         losses = []
+        start = flat.param.clone()
         if mode == "eager":
             for _ in range(3 + 5):  # the capture's three warm-up steps are real optimizer steps too
                 noise = source.draw(shapes)
@@ -986,12 +992,14 @@ def test_captured_train_step_matches_eager(name: str, lib_loaded: None) -> None:
                 losses.append(float(cap.step()["loss"]))
             assert float(opt.state[1]) == 8.0 and opt.steps == 8
         scan.check_cluster_status()
+        moved = (flat.param - start).abs()
+        assert float(moved.max()) > 5e-5  # eight Adam steps of 1e-5 were applied (at most lr per step and element)
         results[mode] = (losses, flat.param.clone())
-    # same uniforms, same arithmetic; but eight optimizer steps of a model with discrete samples amplify the arrival order of the
-    # fp32 atomics (a flipped one-hot moves the loss by ~1e-4): the trajectories agree to a few 1e-4, not bit for bit
-    np.testing.assert_allclose(results["graph"][0], results["eager"][0], rtol=5e-4)
+    # same uniforms, same arithmetic up to the arrival order of the fp32 atomics; a skipped or doubled optimizer step would move
+    # parameters by 1e-5
+    np.testing.assert_allclose(results["graph"][0], results["eager"][0], rtol=1e-4)
     diff = (results["graph"][1] - results["eager"][1]).abs()
-    assert float(diff.max()) < 2e-3 and float(diff.mean()) < 2e-5, (float(diff.max()), float(diff.mean()))
+    assert float(diff.max()) < 4e-6 and float(diff.mean()) < 2e-7, (float(diff.max()), float(diff.mean()))
 
 
 def test_cpu_tensors_are_refused(lib_loaded: None) -> None:
