@@ -15,12 +15,13 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 
 import torch
 from torch import Tensor
 
 from multimodal_mtrssm_amd import _lib
-from multimodal_mtrssm_amd.linear import grad_target
+from multimodal_mtrssm_amd.linear import grad_target, grad_target_owner
 
 
 def _pad_to(n: int, m: int) -> int:
@@ -337,20 +338,28 @@ class _ConvGradSink:
     def __init__(self) -> None:
         self.entries: dict[tuple, tuple] = {}
         self.table: Tensor | None = None
+        self.retired: list[Tensor] = []  # superseded tables stay allocated: a captured graph may still read one (64 B per entry)
         self.pending = False
 
     def target(self, weight: Tensor | None, o: int, i: int, taps: int, opad: int, ipad: int) -> Tensor | None:
         """The packed accumulation buffer for ``weight`` ([o][i][kh][kw]-shaped parameter), or None when it has no flat home."""
         if weight is None or not weight.is_contiguous():
             return None
-        dst = grad_target(weight)
-        if dst is None:
+        found = grad_target_owner(weight)
+        if found is None:
             return None
-        key = (weight.data_ptr(), o, i, taps, opad, ipad)
+        dst, owner = found
+        # keyed by the DESTINATION (a live flat gradient buffer), never by the weight's address: a later model whose flat
+        # parameter buffer reuses a freed one's address must not inherit that model's entries (its gradients would land in
+        # the dead model's buffer).  Entries of collected owners are dropped.
+        key = (dst.data_ptr(), o, i, taps, opad, ipad)
         e = self.entries.get(key)
+        if e is not None and e[2]() is not owner:
+            e = None
         if e is None:
+            self.entries = {k: v for k, v in self.entries.items() if v[2]() is not None and k != key}
             packed = torch.zeros(opad, taps, ipad, device=weight.device, dtype=torch.float32)
-            e = self.entries[key] = (packed, dst)
+            e = self.entries[key] = (packed, dst, weakref.ref(owner))
             self.table = None
         if not self.pending:
             self.pending = True
@@ -359,12 +368,16 @@ class _ConvGradSink:
 
     def flush(self) -> None:
         self.pending = False
+        if any(v[2]() is None for v in self.entries.values()):
+            self.entries = {k: v for k, v in self.entries.items() if v[2]() is not None}
+            self.table = None
         if not self.entries:
             return
         dev = next(iter(self.entries.values()))[0].device
         if self.table is None:
-            rows = [[packed.data_ptr(), dst.data_ptr(), k[1], k[2], k[3], k[5], 0, 0] for k, (packed, dst) in self.entries.items()]
+            rows = [[packed.data_ptr(), dst.data_ptr(), k[1], k[2], k[3], k[5], 0, 0] for k, (packed, dst, _) in self.entries.items()]
             self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
+            self.retired.append(self.table)
         _lib.check(_lib.TIMERS.call("mtrssm_unpack_conv_grads", _lib.load().mtrssm_unpack_conv_grads, _lib.raw_ptr(self.table),
                                     len(self.entries), 8, _lib.stream_ptr(dev)), "mtrssm_unpack_conv_grads")
 

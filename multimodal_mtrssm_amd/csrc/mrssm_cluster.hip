@@ -347,8 +347,10 @@ __global__ __launch_bounds__(kCluThreads) void mrssm_fwd_cluster_kernel(const Mt
             if (io.sv_la) { io.sv_la[bt * S + s] = lds[Lla + s]; io.sv_lv[bt * S + s] = lds[Llv + s]; }
           }
         }
-        float kl = cat_block_fwd<true, true>(lds + Lmx, lds + Llp, K, C, lane, lds + Lu, io.u_prior ? lds + Lu + 64 : nullptr, lds + Ls,
-                                             io.post_stoch + bt * S, io.prior_stoch ? io.prior_stoch + bt * S : nullptr, writer);
+        float kl = C <= 8 ? cat_block_fwd_fast8(lds + Lmx, lds + Llp, K, C, lane, lds + Lu, io.u_prior ? lds + Lu + 64 : nullptr, lds + Ls,
+                                                io.post_stoch + bt * S, io.prior_stoch ? io.prior_stoch + bt * S : nullptr, writer)
+                          : cat_block_fwd<true, true>(lds + Lmx, lds + Llp, K, C, lane, lds + Lu, io.u_prior ? lds + Lu + 64 : nullptr, lds + Ls,
+                                                      io.post_stoch + bt * S, io.prior_stoch ? io.prior_stoch + bt * S : nullptr, writer);
         if (io.kl) {
           kl = wave_sum(kl);
           if (lane == 0 && writer) io.kl[bt] = kl;

@@ -46,15 +46,31 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-
 // (outputs are read by later launches; the cluster exchanges are polled sc1 granules).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Wave-wide reductions on the DPP data path (every lane gets the result; all 64 lanes must be active).  __shfl_xor goes
+// through the LDS crossbar (ds_bpermute_b32: ~60 cycles per step of a dependent chain of six); a DPP step is one VALU
+// instruction.  Steps: quad_perm swaps, row_half_mirror, row_mirror (16-lane rows complete), row_bcast15 into rows 1 and 3,
+// row_bcast31 into rows 2 and 3, lane 63 holds the result.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_move(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
-  return v;
+  v += dpp_move<0xB1, 0xF>(0.f, v);   // quad_perm [1, 0, 3, 2]
+  v += dpp_move<0x4E, 0xF>(0.f, v);   // quad_perm [2, 3, 0, 1]
+  v += dpp_move<0x141, 0xF>(0.f, v);  // row_half_mirror
+  v += dpp_move<0x140, 0xF>(0.f, v);  // row_mirror
+  v += dpp_move<0x142, 0xA>(0.f, v);  // row_bcast15 -> rows 1, 3
+  v += dpp_move<0x143, 0xC>(0.f, v);  // row_bcast31 -> rows 2, 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, kWave));
-  return v;
+  v = fmaxf(v, dpp_move<0xB1, 0xF>(v, v));
+  v = fmaxf(v, dpp_move<0x4E, 0xF>(v, v));
+  v = fmaxf(v, dpp_move<0x141, 0xF>(v, v));
+  v = fmaxf(v, dpp_move<0x140, 0xF>(v, v));
+  v = fmaxf(v, dpp_move<0x142, 0xA>(v, v));  // rows 0, 2 keep their own value (old = v)
+  v = fmaxf(v, dpp_move<0x143, 0xC>(v, v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -282,6 +298,68 @@ __device__ __forceinline__ float cat_block_fwd(const float* q_logits, const floa
         s_lds[k * C + c] = v;
         if (ok) prior_stoch_g[k * C + c] = v;
       }
+    }
+  }
+  return kl;
+}
+
+// The same block for the cluster scan's critical path (FAST arithmetic, POST, C <= 8): every exponential is evaluated once
+// (the generic form recomputes them for the statistics, the KL and the inverse CDF) and the divisions by the partition sums
+// are multiplications by one reciprocal (an IEEE division is ~10 instructions; 25 of them per categorical).
+__device__ __forceinline__ float cat_block_fwd_fast8(const float* q_logits, const float* p_logits, int K, int C, int lane,
+                                                     const float* u_post, const float* u_prior, float* s_lds, float* post_stoch_g,
+                                                     float* prior_stoch_g, bool ok) {
+  float kl = 0.f;
+  for (int k = lane; k < K; k += kWave) {
+    const float* ql = q_logits + k * C;
+    const float* pl = p_logits + k * C;
+    float q[8], p[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      q[c] = c < C ? ql[c] : -INFINITY;
+      p[c] = c < C ? pl[c] : -INFINITY;
+    }
+    float qm = q[0], pm = p[0];
+#pragma unroll
+    for (int c = 1; c < 8; ++c) { qm = fmaxf(qm, q[c]); pm = fmaxf(pm, p[c]); }
+    float eq[8], ep[8], qs = 0.f, ps = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      eq[c] = c < C ? __expf(q[c] - qm) : 0.f;
+      ep[c] = c < C ? __expf(p[c] - pm) : 0.f;
+      qs += eq[c];
+      ps += ep[c];
+    }
+    const float rq = __frcp_rn(qs), rp = __frcp_rn(ps);
+    const float lqs = __logf(qs), lps = __logf(ps);
+    float klk = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      if (c < C) klk += eq[c] * rq * (((q[c] - qm) - lqs) - ((p[c] - pm) - lps));
+    kl += klk;
+    const float u = u_post[k];
+    float acc = 0.f;
+    int idx = 0;
+#pragma unroll
+    for (int c = 0; c < 7; ++c)
+      if (c + 1 < C) { acc += eq[c] * rq; idx += (acc <= u) ? 1 : 0; }
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      if (c < C) {
+        const float v = c == idx ? 1.f : 0.f;
+        s_lds[k * C + c] = v;
+        if (ok) post_stoch_g[k * C + c] = v;
+      }
+    if (u_prior && prior_stoch_g && ok) {
+      const float up = u_prior[k];
+      float pacc = 0.f;
+      int pidx = 0;
+#pragma unroll
+      for (int c = 0; c < 7; ++c)
+        if (c + 1 < C) { pacc += ep[c] * rp; pidx += (pacc <= up) ? 1 : 0; }
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        if (c < C) prior_stoch_g[k * C + c] = c == pidx ? 1.f : 0.f;
     }
   }
   return kl;

@@ -40,9 +40,17 @@ def register_sink(flat) -> None:  # noqa: ANN001
 def grad_target(t: Tensor) -> Tensor | None:
     """The view of a flat gradient buffer that mirrors ``t`` (a parameter held by a ``FlatParameters``, or a strided view into
     one), or None.  Marks the parameter as touched: the caller is about to accumulate its gradient there."""
+    found = grad_target_owner(t)
+    return None if found is None else found[0]
+
+
+def grad_target_owner(t: Tensor):  # noqa: ANN201
+    """``(view, owning FlatParameters)`` for ``grad_target``'s lookup, or None."""
     if not SINK_ENABLED or not t.is_cuda or torch.is_grad_enabled():
         return None  # (backward runs with grad mode off unless create_graph: then the usual path is taken)
     addr = t.data_ptr()
+    if any(ref() is None for ref in _SINKS):
+        _SINKS[:] = [ref for ref in _SINKS if ref() is not None]
     for ref in _SINKS:
         flat = ref()
         if flat is None or flat.param.device != t.device:
@@ -57,7 +65,7 @@ def grad_target(t: Tensor) -> Tensor | None:
         if off + extent > flat.offsets[i] + p.numel():
             return None  # not contained in one parameter
         flat.mark_touched(i)
-        return flat.grad_full.as_strided(t.shape, t.stride(), off)
+        return flat.grad_full.as_strided(t.shape, t.stride(), off), flat
     return None
 
 
