@@ -46,9 +46,9 @@ __host__ __device__ constexpr int res_wrow_bytes(int cin) { return 9 * cin * 2 +
 __host__ __device__ constexpr int res_group_rows(int cin) { return cin >= 128 ? 32 : 64; }
 
 // B-operand reads and their waits are inline asm.  The compiler's own s_waitcnt for these reads came out as lgkmcnt(0) every
-// third k-block, right behind the newest requests: the LDS latency sat in front of every ninth MFMA (46 instead of 32
-// cycles per MFMA measured).  LDS operations return in order, so "at most 4 outstanding" releases the fragment requested
-// two blocks ago whatever else (the staging writes) is in flight; res_wait ties the fragment registers to that wait.
+// third k-block, right behind the newest requests.  LDS operations return in order, so "at most 4 outstanding" releases the
+// fragment requested two blocks ago whatever else (the staging writes) is in flight; res_wait ties the fragment registers
+// to that wait.  (Measured: no change of the unit time -- the schedule just no longer depends on the compiler's choice.)
 template <int IMGB>
 __device__ __forceinline__ void res_read_pair(bf16x8& hi, bf16x8& lo, unsigned addr, int cb) {
   switch (cb) {
@@ -246,9 +246,8 @@ __global__ __launch_bounds__(kResThreads, 1) void conv3x3_resident_kernel(const 
   constexpr int CPS = KB >= 36 ? 1 : 2;             // staging chunks per region
   static_assert((1 + (KB - S0)) * CPS >= NSC, "the staging chunks fit in one unit");
   static_assert(S0 <= KB, "the epilogue fits in one unit");
-  // A VALU read of ANY accumulator register stalls until the MFMAs in flight have drained (measured: ~210 cycles per
-  // v_accvgpr_read in the loop, 3.3 us per tile), so a unit's sums leave the AGPRs once, right after its last MFMA, and the
-  // epilogue rows in the next unit's shadow work on that copy.
+  // A unit's sums leave the AGPRs once, right after its last MFMA (180 cycles), and the epilogue rows in the next unit's
+  // shadow work on that copy in architectural VGPRs: no v_accvgpr_read and no AGPR-sourced store between the MFMAs.
   f32x16 acc;
   float fin[ROWS];
   // epilogue operands of unit h live in set h: requested in the first k-blocks of their unit, consumed in the next unit's
