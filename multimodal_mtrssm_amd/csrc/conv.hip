@@ -1044,6 +1044,14 @@ static bool resident_enabled() {
   return on;
 }
 
+// MTRSSM_PATCH_768=0: 641..768-position patches (the k=4 s=2 backward-data gathers, 648 positions) back on the fp32 patch
+// kernel.  Round 1 measured that kernel faster for them (283 us per modality); with audio + vision paired into one launch the
+// split kernel takes 182 us for both (round 2), so it is the default now.
+static bool patch_limit_768() {
+  static const bool on = [] { const char* e = getenv("MTRSSM_PATCH_768"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 static int cu_count() {
   static const int n = [] {
     int dev = 0, v = 0;
@@ -1100,8 +1108,7 @@ static SplitPlan plan_split(const MtrssmConvGeom* g, bool has_wq) {
   pl.ngroups = taps / tgs;
   pl.lds = lds_of(tgs);
   pl.pit = pg.ps_raw <= 384 ? 3 : 6;
-  // larger patches (the k=4 s=2 backward-data gathers, 648 positions) measured faster on the fp32 kernel
-  if (pl.lds <= 80 * 1024 && pg.ps_raw <= 640 && (long)pg.ipg * g->C * g->Hs * g->Ws < (1L << 31) &&
+  if (pl.lds <= 80 * 1024 && pg.ps_raw <= (patch_limit_768() ? 768 : 640) && (long)pg.ipg * g->C * g->Hs * g->Ws < (1L << 31) &&
       (long)sp * g->CoutPad * taps * g->Cpad < (1L << 31))
     pl.kind = 2;
   return pl;
