@@ -440,6 +440,16 @@ int mtrssm_unpack_conv_grads(const int64_t* table, int32_t count, int32_t blocks
  * source element. */
 int mtrssm_convt_k4s2_thin(int32_t N, int32_t C, int32_t Hs, int32_t Ws, int32_t Cout, const float* src, const float* w,
                            const float* bias, int32_t pre_act, int32_t act, float* out, void* stream);
+/* Conv2d backward-data / ConvTranspose2d forward with <= 8 output channels, all output parity classes in ONE pass (the general
+ * path, mtrssm_conv_gather_gemm, takes one launch per parity class of a strided layer; replaces the backward-data of the
+ * encoders' second conv, cnn.Encoder at mrssm core.py:179-180):
+ *   out[n, c, iy, ix] = (bias[c] + sum_{o, ky, kx} w[o][c][ky][kx] * pre(y)[n, o, (iy + pad - ky) / stride, (ix + pad - kx) / stride])
+ *                       * act'(actgrad_in[n, c, iy, ix]) + add_in[n, c, iy, ix]
+ * over the taps whose (iy + pad - ky), (ix + pad - kx) are non-negative multiples of the stride inside the source plane.
+ * y [N, O, Hs, Ws], w [O][Cout][KH][KW] contiguous (the Conv2d weight), out [N, Cout, Ho, Wo]; KH * KW * O <= 256; stride 2, even Ho and Wo. */
+int mtrssm_conv_tgather_thin(int32_t N, int32_t O, int32_t Hs, int32_t Ws, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
+                             int32_t Ho, int32_t Wo, const float* y, const float* w, const float* bias, int32_t pre_act, int32_t act,
+                             const float* actgrad_in, const float* add_in, float* out, void* stream);
 /* out[c] += sum_{n, i<HW} x[n, c, i]   (bias gradients; the caller zeroes out) */
 int mtrssm_channel_sum(const float* x, int32_t N, int32_t C, int32_t HW, float* out, void* stream);
 

@@ -295,6 +295,17 @@ def _conv_transposed_gather(y: Tensor, w: Tensor, bias: Tensor | None, stride: i
             int(pre_act), act, _lib.ptr(out), _lib.stream_ptr(y.device), flops=2.0 * n * ho * wo * c * 4 * o,
             nbytes=4.0 * (y.numel() + out.numel())), "mtrssm_convt_k4s2_thin")
         return out
+    if stride == 2 and c <= 8 and kh * kw * o <= 256 and ho % 2 == 0 and wo % 2 == 0 and TGATHER_THIN:  # noqa: PLR2004
+        # few output channels (backward-data of the encoders' second conv): all parity classes in one VALU pass
+        lib = _lib.load()
+        wc = w.contiguous()
+        taps_used = kh * kw / (stride * stride)
+        _lib.check(_lib.TIMERS.call(
+            "mtrssm_conv_tgather_thin", lib.mtrssm_conv_tgather_thin, n, o, hs, ws, c, kh, kw, stride, pad, ho, wo, _lib.ptr(y),
+            _lib.ptr(wc), _lib.ptr(bias), int(pre_act), act, _lib.ptr(actgrad_in), _lib.ptr(add_in), _lib.ptr(out),
+            _lib.stream_ptr(y.device), flops=2.0 * n * ho * wo * c * taps_used * o,
+            nbytes=4.0 * (y.numel() + out.numel() * (1 + (actgrad_in is not None) + (add_in is not None)))), "mtrssm_conv_tgather_thin")
+        return out
     for qy in range(min(stride, ho)):
         ky0 = (qy + pad) % stride
         for qx in range(min(stride, wo)):
@@ -313,6 +324,7 @@ def _conv_transposed_gather(y: Tensor, w: Tensor, bias: Tensor | None, stride: i
 # Accumulation targets of the weight-gradient kernels (fp32 atomics) must start at zero.  They are carved out of a zeroed
 # chunk -- one fill per chunk instead of one per tensor (the train step has ~90 such targets of a few KB each); a chunk is
 # never handed out twice and is freed by the allocator when the last view of it dies.
+TGATHER_THIN = os.environ.get("MTRSSM_TGATHER_THIN", "1") != "0"  # A/B switch of conv_tgather_thin_kernel
 _ZERO_CHUNK_FLOATS = 2 << 20
 _ZERO_CHUNKS: dict[tuple, list] = {}
 

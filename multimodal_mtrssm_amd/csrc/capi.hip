@@ -32,6 +32,8 @@ int conv_gather_pair_merges(const MtrssmConvGeom*, const MtrssmConvGeom*, bool);
 int conv_weight_grad_launch(const MtrssmConvGeom*, const float*, const float*, const float*, int, float*, float*, hipStream_t);
 int channel_sum_launch(const float*, int, int, int, float*, hipStream_t);
 int convt_k4s2_thin_launch(int, int, int, int, int, const float*, const float*, const float*, int, int, float*, hipStream_t);
+int conv_tgather_thin_launch(int, int, int, int, int, int, int, int, int, int, int, const float*, const float*, const float*, int, int, const float*,
+                             const float*, float*, hipStream_t);
 int nll_fwd_launch(const float*, const float*, int64_t, int64_t, int, float*, hipStream_t);
 int nll_bwd_launch(const float*, const float*, const float*, int64_t, int64_t, int, float*, hipStream_t);
 int sumsq_launch(const float*, int64_t, float*, hipStream_t);
@@ -147,6 +149,12 @@ MTRSSM_API int mtrssm_conv_weight_grad(const MtrssmConvGeom* g, const float* a, 
 }
 MTRSSM_API int mtrssm_channel_sum(const float* x, int32_t N, int32_t C, int32_t HW, float* out, void* stream) {
   return channel_sum_launch(x, N, C, HW, out, static_cast<hipStream_t>(stream));
+}
+MTRSSM_API int mtrssm_conv_tgather_thin(int32_t N, int32_t O, int32_t Hs, int32_t Ws, int32_t Cout, int32_t KH, int32_t KW, int32_t stride,
+                                        int32_t pad, int32_t Ho, int32_t Wo, const float* y, const float* w, const float* bias, int32_t pre_act,
+                                        int32_t act, const float* actgrad_in, const float* add_in, float* out, void* stream) {
+  return conv_tgather_thin_launch(N, O, Hs, Ws, Cout, KH, KW, stride, pad, Ho, Wo, y, w, bias, pre_act, act, actgrad_in, add_in, out,
+                                  static_cast<hipStream_t>(stream));
 }
 MTRSSM_API int mtrssm_convt_k4s2_thin(int32_t N, int32_t C, int32_t Hs, int32_t Ws, int32_t Cout, const float* src, const float* w,
                                       const float* bias, int32_t pre_act, int32_t act, float* out, void* stream) {

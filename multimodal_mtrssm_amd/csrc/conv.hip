@@ -745,6 +745,95 @@ __global__ __launch_bounds__(kConvThreads) void conv_gather_thin_kernel(
 // ------------------------------------------------------------------------------------------------
 constexpr int kCtTH = 8, kCtTW = 32, kCtPW = kCtTW + 2, kCtPS = (kCtTH + 2) * kCtPW + 1;
 
+// Transposed gather with <= 8 output channels (backward-data of the encoders' second conv: dX[N, 8, 32, 32] from
+// dY[N, 16, 16, 16], k = 3, s = 2, p = 1), ALL output parity classes in one pass: one thread per output pixel visits the taps
+// of its own parity.  The general path launches one sub-grid per parity class (4 launches, each re-reading the whole source
+// and storing every second pixel): 4 x 69 us per modality against one ~40 us pass here (HBM: source once, output once, fully
+// coalesced).
+//   out[n, c, iy, ix] = (bias[c] + sum_{o, ky, kx} w[o][c][ky][kx] pre(y)[n, o, (iy + p - ky) / s, (ix + p - kx) / s]) * act'(actgrad_in) + add_in
+template <int COT, int S>  // S: the stride as a constant
+__global__ __launch_bounds__(kConvThreads) void conv_tgather_thin_kernel(
+    const int N, const int O, const int Hs, const int Ws, const int Cc, const int KH, const int KW, const int P, const int Ho,
+    const int Wo, const float* __restrict__ y, const float* __restrict__ w, const float* __restrict__ bias, const int pre_act, const int act,
+    const float* __restrict__ actgrad_in, const float* __restrict__ add_in, float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float w_lds[kThinMaxK * COT];
+  const int tid = threadIdx.x;
+  const int taps = KH * KW;
+  for (int e = tid; e < taps * O * COT; e += kConvThreads) {
+    const int j = e % COT, k = e / COT;
+    const int oc = k % O, t = k / O;
+    w_lds[e] = j < Cc ? w[((size_t)oc * Cc + j) * taps + t] : 0.f;
+  }
+  __syncthreads();
+  // Pixels are enumerated parity class by parity class (host: Ho % S == 0, Wo % S == 0): the lanes of a wave share their taps
+  // (uniform loops, weights by broadcast LDS reads).  A first version with one thread per pixel in plane order ran every wave
+  // through all KH * KW taps at 25 % of its lanes: 291 us; the four per-class launches it replaces: 4 x 69 us.
+  const int Hq = Ho / S, Wq = Wo / S, PQ = Hq * Wq;
+  const long ptot = (long)N * S * S * PQ;
+  const long p = (long)blockIdx.x * kConvThreads + tid;
+  if (p >= ptot) return;
+  const int cls = (int)(p / PQ), r = (int)(p - (long)cls * PQ);
+  const int n = cls / (S * S), q = cls - n * (S * S);
+  const int qy = q / S, qx = q - qy * S;
+  const int jy = r / Wq, jx = r - jy * Wq;
+  const int iy = jy * S + qy, ix = jx * S + qx;
+  const int plane_s = Hs * Ws;
+  const float* yn = y + (size_t)n * O * plane_s;
+  float acc[COT];
+#pragma unroll
+  for (int j = 0; j < COT; ++j) acc[j] = (bias && j < Cc) ? bias[j] : 0.f;
+  for (int ky = (qy + P) % S; ky < KH; ky += S) {
+    const int sy = jy + (qy + P - ky) / S;  // exact: (qy + P - ky) is a multiple of S
+    if (sy < 0 || sy >= Hs) continue;
+    for (int kx = (qx + P) % S; kx < KW; kx += S) {
+      const int sx = jx + (qx + P - kx) / S;
+      if (sx < 0 || sx >= Ws) continue;
+      const float* wk = w_lds + (size_t)(ky * KW + kx) * O * COT;
+      const float* yp = yn + sy * Ws + sx;
+      for (int oc0 = 0; oc0 < O; oc0 += 8) {  // eight channels' loads in flight before the first is used
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = yp[(size_t)(oc0 + u < O ? oc0 + u : O - 1) * plane_s];
+        if (pre_act) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = act == MTRSSM_ACT_ELU ? elu_fast(v[u]) : act_fwd(v[u], act);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (oc0 + u < O) {
+#pragma unroll
+            for (int j = 0; j < COT; ++j) acc[j] = fmaf(v[u], wk[(oc0 + u) * COT + j], acc[j]);
+          }
+        }
+      }
+    }
+  }
+  const size_t plane_o = (size_t)Ho * Wo;
+  const size_t base = (size_t)n * Cc * plane_o + (size_t)iy * Wo + ix;
+  float gv[COT], av[COT];
+#pragma unroll
+  for (int j = 0; j < COT; ++j) {
+    const size_t o = base + (size_t)(j < Cc ? j : Cc - 1) * plane_o;
+    gv[j] = actgrad_in ? actgrad_in[o] : 0.f;
+    av[j] = add_in ? add_in[o] : 0.f;
+  }
+  if (actgrad_in) {
+    if (act == MTRSSM_ACT_ELU) {
+#pragma unroll
+      for (int j = 0; j < COT; ++j) gv[j] = gv[j] > 0.f ? 1.f : __expf(gv[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < COT; ++j) gv[j] = act_grad_from_in(gv[j], act);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < COT; ++j) {
+    float v = acc[j];
+    if (actgrad_in) v *= gv[j];
+    if (add_in) v += av[j];
+    if (j < Cc) out[base + (size_t)j * plane_o] = v;
+  }
+}
 template <int COT>
 __global__ __launch_bounds__(kConvThreads) void convt_k4s2_thin_kernel(
     const int N, const int C, const int Hs, const int Ws, const int Cout, const float* __restrict__ src,
@@ -1552,6 +1641,26 @@ int convt_k4s2_thin_launch(int N, int C, int Hs, int Ws, int Cout, const float* 
   else
     { set_last_kernel("mtrssm::convt_k4s2_thin_kernel<2>"); hipLaunchKernelGGL(convt_k4s2_thin_kernel<2>, grid, dim3(kConvThreads), lds, stream, N, C, Hs, Ws, Cout, src, w, bias, pre_act, act, out); }
   return launched("convt_k4s2_thin");
+}
+
+int conv_tgather_thin_launch(int N, int O, int Hs, int Ws, int Cc, int KH, int KW, int S, int P, int Ho, int Wo, const float* y, const float* w,
+                             const float* bias, int pre_act, int act, const float* actgrad_in, const float* add_in, float* out,
+                             hipStream_t stream) {
+  if (N <= 0 || O <= 0 || Hs <= 0 || Ws <= 0 || Cc <= 0 || Cc > 8 || KH <= 0 || KW <= 0 || S <= 0 || P < 0 || Ho <= 0 || Wo <= 0 || !y || !w ||
+      !out || KH * KW * O > kThinMaxK) {
+    set_error("conv_tgather_thin: bad argument (needs 1 <= Cout <= 8 and taps * channels <= %d)", kThinMaxK);
+    return MTRSSM_EINVAL;
+  }
+  if (act < MTRSSM_ACT_IDENTITY || act > MTRSSM_ACT_TANH) { set_error("conv_tgather_thin: unknown activation id %d", act); return MTRSSM_EINVAL; }
+  const long ptot = (long)N * Ho * Wo;
+  if (ptot >= (1L << 31) * (long)kConvThreads) { set_error("conv_tgather_thin: too many output pixels"); return MTRSSM_EINVAL; }
+  const dim3 grid((unsigned)((ptot + kConvThreads - 1) / kConvThreads));
+  if (S != 2 || Ho % 2 || Wo % 2) { set_error("conv_tgather_thin: stride 2 and even output planes only (stride %d, %d x %d)", S, Ho, Wo); return MTRSSM_EINVAL; }
+  if (Cc <= 2)
+    { set_last_kernel("mtrssm::conv_tgather_thin_kernel<2, 2>"); hipLaunchKernelGGL((conv_tgather_thin_kernel<2, 2>), grid, dim3(kConvThreads), 0, stream, N, O, Hs, Ws, Cc, KH, KW, P, Ho, Wo, y, w, bias, pre_act, act, actgrad_in, add_in, out); }
+  else
+    { set_last_kernel("mtrssm::conv_tgather_thin_kernel<8, 2>"); hipLaunchKernelGGL((conv_tgather_thin_kernel<8, 2>), grid, dim3(kConvThreads), 0, stream, N, O, Hs, Ws, Cc, KH, KW, P, Ho, Wo, y, w, bias, pre_act, act, actgrad_in, add_in, out); }
+  return launched("conv_tgather_thin");
 }
 
 int channel_sum_launch(const float* x, int N, int C, int HW, float* out, hipStream_t stream) {
