@@ -88,8 +88,8 @@ class FlatDataParallel:
         if len(keys) > self.flat.extra:
             msg = f"at most {self.flat.extra} scalars fit in the gradient buffer's tail"
             raise ValueError(msg)
-        for i, k in enumerate(keys):
-            self.flat.tail[i].copy_(scalars[k].detach().reshape(()))  # type: ignore[index]
+        if keys:  # one stack + one copy instead of a copy per scalar
+            self.flat.tail[: len(keys)].copy_(torch.stack([scalars[k].detach().reshape(()) for k in keys]))  # type: ignore[index]
         return keys
 
     @torch.no_grad()
@@ -103,4 +103,7 @@ class FlatDataParallel:
         """All-reduce gradients (SUM, left un-normalised) and average ``scalars`` in the same call."""
         keys = self.stage_scalars(scalars)
         self.reduce()
-        return {k: self.flat.tail[i] / self.world for i, k in enumerate(keys)}
+        if not keys:
+            return {}
+        mean = self.flat.tail[: len(keys)] / self.world  # one launch for all scalars
+        return {k: mean[i] for i, k in enumerate(keys)}
