@@ -790,16 +790,16 @@ __global__ __launch_bounds__(kConvThreads) void conv_tgather_thin_kernel(
       if (sx < 0 || sx >= Ws) continue;
       const float* wk = w_lds + (size_t)(ky * KW + kx) * O * COT;
       const float* yp = yn + sy * Ws + sx;
-      for (int oc0 = 0; oc0 < O; oc0 += 8) {  // eight channels' loads in flight before the first is used
-        float v[8];
+      for (int oc0 = 0; oc0 < O; oc0 += 16) {  // sixteen channels' loads in flight before the first is used
+        float v[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = yp[(size_t)(oc0 + u < O ? oc0 + u : O - 1) * plane_s];
+        for (int u = 0; u < 16; ++u) v[u] = yp[(size_t)(oc0 + u < O ? oc0 + u : O - 1) * plane_s];
         if (pre_act) {
 #pragma unroll
-          for (int u = 0; u < 8; ++u) v[u] = act == MTRSSM_ACT_ELU ? elu_fast(v[u]) : act_fwd(v[u], act);
+          for (int u = 0; u < 16; ++u) v[u] = act == MTRSSM_ACT_ELU ? elu_fast(v[u]) : act_fwd(v[u], act);
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 16; ++u) {
           if (oc0 + u < O) {
 #pragma unroll
             for (int j = 0; j < COT; ++j) acc[j] = fmaf(v[u], wk[(oc0 + u) * COT + j], acc[j]);
