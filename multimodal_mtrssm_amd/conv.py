@@ -136,7 +136,7 @@ def invalidate_packs() -> None:
     _PLAN.invalidate()
 
 
-def pack_weight(w: Tensor) -> tuple[Tensor, Tensor | None]:
+def pack_weight(w: Tensor, sub: int = 0) -> tuple[Tensor, Tensor | None]:
     """``w[O][I][kh][kw]`` (any strided view) -> zero-padded fp32 ``wp[OPad][kh*kw][IPad]`` (channel fastest) and, in a
     bf16 MFMA mode, its bf16 pieces ``wq[pieces][OPad][kh*kw][IPad]`` (``mtrssm_pack_conv_weight``).
 
@@ -148,8 +148,8 @@ def pack_weight(w: Tensor) -> tuple[Tensor, Tensor | None]:
     if PACK_PLAN and w.is_cuda and kh * kw > 0 and torch.cuda.current_stream(w.device).cuda_stream == _PLAN.stream:
         return _PLAN.get(w)
     slot = len(_DEFER) if _DEFER is not None else 0  # deferred (paired) launches: one buffer per pending job
-    key = (o, i, kh, kw, _MFMA_SPLIT, slot, w.device, torch.cuda.current_stream(w.device).cuda_stream if w.is_cuda else 0)
-    bufs = _PACK_BUFFERS.get(key)
+    key = (o, i, kh, kw, _MFMA_SPLIT, slot, sub, w.device, torch.cuda.current_stream(w.device).cuda_stream if w.is_cuda else 0)
+    bufs = _PACK_BUFFERS.get(key)  # (`sub`: same-shaped weights packed for ONE pending launch, e.g. the four parity sub-kernels)
     if bufs is None:
         bufs = _PACK_BUFFERS[key] = _pack_buffers(w)
     if kh * kw > 0:
@@ -214,7 +214,32 @@ def _job_args(job: tuple) -> tuple:
             _lib.ptr(add_in), _lib.ptr(out))
 
 
+def _quad_args(job: tuple) -> tuple:
+    _, geoms, y, wqs, bias, out = job
+    arr = (C.c_void_p * 4)(*[_lib.raw_ptr(wq) for wq in wqs])
+    job_keepalive = arr  # noqa: F841 (ctypes array lives until the call returns: it is an argument below)
+    return (geoms, _lib.ptr(y), arr, _lib.ptr(bias), _lib.ptr(out))
+
+
+def _quad_work(job: tuple) -> tuple[float, float]:
+    g = job[1][0]
+    pixels = g.N * g.Ho * g.Wo
+    return 2.0 * pixels * g.Cout * 4 * g.C, 4.0 * (g.N * g.C * g.Hs * g.Ws + pixels * g.Cout)
+
+
+def _launch_quad(ja: tuple, jb: tuple | None) -> None:
+    lib = _lib.load()
+    fa, ba = _quad_work(ja)
+    fb, bb = _quad_work(jb) if jb is not None else (0.0, 0.0)
+    args_b = _quad_args(jb) if jb is not None else (None, None, None, None, None)
+    _lib.check(_lib.TIMERS.call("mtrssm_convt_quad", lib.mtrssm_convt_quad, *_quad_args(ja), *args_b, _lib.stream_ptr(ja[2].device),
+                                flops=fa + fb, nbytes=ba + bb), "mtrssm_convt_quad")
+
+
 def _launch_gather(job: tuple) -> None:
+    if job[0] == "quad":
+        _launch_quad(job, None)
+        return
     lib = _lib.load()
     flops, nbytes = _job_work(job)
     _lib.check(_lib.TIMERS.call("mtrssm_conv_gather_gemm", lib.mtrssm_conv_gather_gemm, *_job_args(job),
@@ -240,6 +265,14 @@ def paired(fn_a, fn_b):  # noqa: ANN001, ANN201
         return ra, rb
     lib = _lib.load()
     for ja, jb in zip(jobs[:na], jobs[na:], strict=True):
+        qa, qb = ja[0] == "quad", jb[0] == "quad"
+        if qa or qb:
+            if qa and qb and lib.mtrssm_convt_quad_supported(ja[1]) == lib.mtrssm_convt_quad_supported(jb[1]):
+                _launch_quad(ja, jb)
+            else:
+                _launch_gather(ja)
+                _launch_gather(jb)
+            continue
         if not lib.mtrssm_conv_gather_pair_merges(C.byref(ja[0]), C.byref(jb[0]), int(ja[4] is not None and jb[4] is not None)):
             _launch_gather(ja)  # thin / fp32-kernel layers: nothing to merge
             _launch_gather(jb)
@@ -295,6 +328,27 @@ def _conv_transposed_gather(y: Tensor, w: Tensor, bias: Tensor | None, stride: i
             int(pre_act), act, _lib.ptr(out), _lib.stream_ptr(y.device), flops=2.0 * n * ho * wo * c * 4 * o,
             nbytes=4.0 * (y.numel() + out.numel())), "mtrssm_convt_k4s2_thin")
         return out
+    if (stride == 2 and kh == 4 and kw == 4 and pad == 1 and (ho, wo) == (2 * hs, 2 * ws) and actgrad_in is None and add_in is None
+            and _MFMA_SPLIT == 2 and CONVT_QUAD and (o, c, hs * ws) in ((64, 32, 64), (32, 16, 256))):  # noqa: PLR2004
+        # the decoders' ConvTranspose layers: all four parity classes in one pass over the source (convt_quad_resident_kernel)
+        geoms = (_lib.ConvGeom * 4)()
+        wqs = []
+        for q in range(4):
+            qy, qx = q >> 1, q & 1
+            ky0, kx0 = (qy + pad) % stride, (qx + pad) % stride
+            wsub = w[:, :, ky0::stride, kx0::stride].permute(1, 0, 2, 3)  # [c][o][2][2]
+            wp, wq = pack_weight(wsub, sub=q)
+            geoms[q] = _geom(N=n, C=o, Hs=hs, Ws=ws, C2=0, Cpad=wp.shape[2], KH=2, KW=2, SS=1, TS=-1,
+                             OFFY=(qy + pad - ky0) // stride, OFFX=(qx + pad - kx0) // stride, Hq=hs, Wq=ws, OS=stride, QY=qy, QX=qx,
+                             Ho=ho, Wo=wo, Cout=c, CoutPad=wp.shape[0], pre_act=int(pre_act), act=act)
+            wqs.append(wq)
+        if _lib.load().mtrssm_convt_quad_supported(geoms):
+            job = ("quad", geoms, y, wqs, bias, out)
+            if _DEFER is not None:
+                _DEFER.append(job)
+            else:
+                _launch_gather(job)
+            return out
     if stride == 2 and c <= 8 and kh * kw * o <= 256 and ho % 2 == 0 and wo % 2 == 0 and TGATHER_THIN:  # noqa: PLR2004
         # few output channels (backward-data of the encoders' second conv): all parity classes in one VALU pass
         lib = _lib.load()
@@ -325,6 +379,7 @@ def _conv_transposed_gather(y: Tensor, w: Tensor, bias: Tensor | None, stride: i
 # chunk -- one fill per chunk instead of one per tensor (the train step has ~90 such targets of a few KB each); a chunk is
 # never handed out twice and is freed by the allocator when the last view of it dies.
 TGATHER_THIN = os.environ.get("MTRSSM_TGATHER_THIN", "1") != "0"  # A/B switch of conv_tgather_thin_kernel
+CONVT_QUAD = os.environ.get("MTRSSM_CONVT_QUAD", "1") != "0"  # A/B switch of convt_quad_resident_kernel
 _ZERO_CHUNK_FLOATS = 2 << 20
 _ZERO_CHUNKS: dict[tuple, list] = {}
 

@@ -1663,6 +1663,76 @@ int conv_tgather_thin_launch(int N, int O, int Hs, int Ws, int Cc, int KH, int K
   return launched("conv_tgather_thin");
 }
 
+// All four output parity classes of a k = 4, s = 2, p = 1 ConvTranspose2d forward in one pass (conv_resident.h:
+// convt_quad_resident_kernel); optionally two tensors (audio + vision) in one launch.  Returns MTRSSM_EINVAL when the layer is
+// outside the kernel's shapes: ask conv_convt_quad_supported first.
+static int quad_key(const MtrssmConvGeom* g4) {
+  if (!g4) return 0;
+  const MtrssmConvGeom& g0 = g4[0];
+  for (int q = 0; q < 4; ++q) {
+    const MtrssmConvGeom& g = g4[q];
+    if (g.KH != 2 || g.KW != 2 || g.TS != -1 || g.SS != 1 || g.OS != 2 || g.C2 != 0 || g.mfma_split != 2 || g.QY != (q >> 1) || g.QX != (q & 1) ||
+        g.C != g0.C || g.Cout != g0.Cout || g.Hs != g0.Hs || g.Ws != g0.Ws || g.N != g0.N || g.Ho != 2 * g.Hs || g.Wo != 2 * g.Ws ||
+        g.Hq != g.Hs || g.Wq != g.Ws || g.Cpad != g.C || g.CoutPad != 32 || g.act == MTRSSM_ACT_TANH || g.OFFY < 0 || g.OFFY > 1 ||
+        g.OFFX < 0 || g.OFFX > 1)
+      return 0;
+  }
+  if (g0.Ws & (g0.Ws - 1)) return 0;
+  if ((long)g0.N * g0.Cout * g0.Ho * g0.Wo >= (1L << 31) || (long)g0.N * g0.C * g0.Hs * g0.Ws >= (1L << 31)) return 0;
+  const int plane = g0.Hs * g0.Ws;
+  if (g0.C == 64 && g0.Cout == 32 && plane == 64) return 1;
+  if (g0.C == 32 && g0.Cout == 16 && plane == 256) return 2;
+  return 0;
+}
+
+int conv_convt_quad_supported(const MtrssmConvGeom* g4) { return resident_enabled() ? quad_key(g4) : 0; }
+
+int conv_convt_quad_launch(const MtrssmConvGeom* ga4, const float* srca, const unsigned short* const* wqa4, const float* biasa, float* outa,
+                           const MtrssmConvGeom* gb4, const float* srcb, const unsigned short* const* wqb4, const float* biasb, float* outb,
+                           hipStream_t stream) {
+  const int key = quad_key(ga4);
+  if (!key || !srca || !wqa4 || !outa || (gb4 && (quad_key(gb4) != key || !srcb || !wqb4 || !outb))) {
+    set_error("convt_quad: layer outside the kernel's shapes (k4 s2 p1, 64 -> 32 on 64-pixel planes or 32 -> 16 on 256-pixel planes, two bf16 pieces)");
+    return MTRSSM_EINVAL;
+  }
+  QuadProblem qa{}, qb{};
+  for (int q = 0; q < 4; ++q) {
+    qa.g[q] = ga4[q]; qa.wq[q] = wqa4[q];
+    if (!wqa4[q]) { set_error("convt_quad: null packed weights"); return MTRSSM_EINVAL; }
+    if (gb4) { qb.g[q] = gb4[q]; qb.wq[q] = wqb4[q]; if (!wqb4[q]) { set_error("convt_quad: null packed weights"); return MTRSSM_EINVAL; } }
+  }
+  qa.src = srca; qa.bias = biasa; qa.out = outa;
+  qb.src = srcb; qb.bias = biasb; qb.out = outb;
+  const long ta = ga4[0].N, tb = gb4 ? gb4[0].N : 0;
+  const int ncu = cu_count();
+  if (tb == 0) {
+    qa.nx = (int)(ta < ncu ? ta : ncu);
+    qb.nx = 0;
+  } else {
+    long na = (ncu * ta + (ta + tb) / 2) / (ta + tb);
+    na = na < 1 ? 1 : (na > ncu - 1 ? ncu - 1 : na);
+    qa.nx = (int)(na < ta ? na : ta);
+    qb.nx = (int)(ncu - na < tb ? ncu - na : tb);
+  }
+  const dim3 grid((unsigned)(qa.nx + qb.nx));
+#define MTRSSM_QUAD_LAUNCH(CIN_, COUT_, PLANE_)                                                                      \
+  {                                                                                                                   \
+    static bool attr_done = false;                                                                                    \
+    const size_t ql = quad_lds_bytes<CIN_, PLANE_>();                                                                 \
+    if (!attr_done) {                                                                                                 \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convt_quad_resident_kernel<CIN_, COUT_, PLANE_>),       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ql);                                 \
+      attr_done = true;                                                                                               \
+    }                                                                                                                 \
+    set_last_kernel("mtrssm::convt_quad_resident_kernel<" #CIN_ ", " #COUT_ ", " #PLANE_ ">");                          \
+    hipLaunchKernelGGL((convt_quad_resident_kernel<CIN_, COUT_, PLANE_>), grid, dim3(kResThreads), ql, stream, qa, qb); \
+    return launched("convt_quad");                                                                                    \
+  }
+  if (key == 1) MTRSSM_QUAD_LAUNCH(64, 32, 64)
+  MTRSSM_QUAD_LAUNCH(32, 16, 256)
+#undef MTRSSM_QUAD_LAUNCH
+}
+
 int channel_sum_launch(const float* x, int N, int C, int HW, float* out, hipStream_t stream) {
   if (!x || !out || N <= 0 || C <= 0 || HW <= 0) { set_error("channel_sum: bad argument"); return MTRSSM_EINVAL; }
   const long total = (long)N * HW;

@@ -397,6 +397,211 @@ __global__ __launch_bounds__(kResThreads, 1) void conv3x3_resident_kernel(const 
 
 
 // ------------------------------------------------------------------------------------------------
+// ConvTranspose2d k = 4, s = 2, p = 1 forward of the decoders (64 -> 32 on 64-pixel planes, 32 -> 16 on 256-pixel planes), ALL
+// FOUR output parity classes in one pass over the source.
+//
+// The general path runs one gather launch per parity class (conv.py: _conv_transposed_gather): every class re-reads the whole
+// source and writes a quarter of the output -- four ~100-us launches per layer for traffic worth ~60 us.  Here the
+// structure of conv3x3_resident_kernel is reused with the four WAVES of a workgroup as the four parity classes: a frame's
+// source is staged once into the haloed channel-innermost image, wave q keeps the 2 x 2-tap sub-kernel of class q (both bf16
+// pieces, 32 output-channel rows x 4 taps x CIN) in registers and walks the frame's PLANE / 32 units of its class's output
+// sub-grid, storing to rows / columns 2 j + q of the output plane.  The previous unit's rows are stored, the next frame is
+// requested and converted between the MFMAs as there.
+// ------------------------------------------------------------------------------------------------
+struct QuadProblem {
+  MtrssmConvGeom g[4];          // the parity classes' geometries (KH = KW = 2, TS = -1, OS = 2, QY / QX, OFFY / OFFX), same source
+  const unsigned short* wq[4];  // their packed sub-kernels [pieces][CoutPad = 32][4 taps][Cpad = CIN]
+  const float* src;
+  const float* bias;
+  float* out;
+  int nx;                       // workgroups of the launch that work on this tensor
+};
+
+template <int CIN, int PLANE>
+__host__ __device__ constexpr size_t quad_lds_bytes() {
+  return (size_t)4 * (PLANE == 64 ? 108 : 340) * res_row_bytes(CIN);  // haloed positions: 10x10 / 18x6, 18x18 / 34x10
+}
+
+template <int CIN, int COUT, int PLANE>
+__global__ __launch_bounds__(kResThreads, 1) void convt_quad_resident_kernel(const QuadProblem qa, const QuadProblem qb) {
+  constexpr int CB = CIN / 16, KB = 4 * CB;
+  constexpr int RB = res_row_bytes(CIN);
+  constexpr int NPOS = PLANE == 64 ? 108 : 340;
+  constexpr int IMG = NPOS * RB;           // one piece of one buffer (one frame)
+  constexpr int OCT = CIN / 8;
+  constexpr int UN = PLANE / 32;           // 32-pixel units per frame and parity class
+  constexpr int NIT = OCT * (PLANE / 64) / 4;  // staging items (8 channels x 64 pixels) per wave
+  constexpr int NSC = NIT * 4;             // staging chunks (2 channels of an item)
+  constexpr int ROWS = COUT / 2;           // accumulator rows that hold output channels (16 of 16, or 8 when COUT = 16)
+  constexpr int RPE = 2, NES = ROWS / RPE; // epilogue rows per k-block, k-blocks [1, 1 + NES)
+  constexpr int SPU = KB - NES;            // staging slots per unit: k-block 0 and [1 + NES, KB)
+  static_assert(UN >= 2 && 1 + NES <= KB && (UN / 2) * SPU >= NSC && NIT >= 1, "schedule");
+  const bool second = blockIdx.x >= (unsigned)qa.nx;  // workgroup-uniform
+  const QuadProblem& Q = second ? qb : qa;
+  const int wg = second ? (int)blockIdx.x - qa.nx : (int)blockIdx.x, nwg = Q.nx;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kl = lane >> 5, il = lane & 31;
+  const MtrssmConvGeom g = Q.g[wave];  // this wave's parity class
+  const unsigned short* __restrict__ wq = Q.wq[wave];
+  const float* __restrict__ src = Q.src;
+  const float* __restrict__ bias = Q.bias;
+  float* __restrict__ out = Q.out;
+  const int ntiles = g.N;  // one frame per tile
+  if (wg >= ntiles) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  unsigned char* patch = lds_raw;  // [2 buffers][2 pieces][IMG]
+
+  bf16x8 a[KB][2];
+  {
+    const size_t piece = (size_t)g.CoutPad * 4 * g.Cpad;  // host: CoutPad == 32, Cpad == CIN
+    const unsigned short* wrow = wq + (size_t)il * 4 * CIN + 8 * kl;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const int t = kb / CB, cb = kb % CB;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        a[kb][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wrow + s * piece + t * CIN + cb * 16));
+        asm volatile("" : "+a"(a[kb][s]));
+      }
+    }
+  }
+  for (int o = tid * 16; o < 4 * IMG; o += kResThreads * 16) *reinterpret_cast<u32x4*>(patch + o) = u32x4{0u, 0u, 0u, 0u};
+  const int cbase = 4 * kl;
+  float bv[16];
+  {
+    const float* bsafe = bias ? bias : src;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = cbase + (r & 3) + 8 * (r >> 2);
+      const float b = bsafe[co < COUT ? co : 0];
+      bv[r] = (bias && co < COUT) ? b : 0.f;
+    }
+  }
+  const int Ws = g.Ws, pw = Ws + 2, wsh = 31 - __builtin_clz(Ws);  // host: Ws a power of two, Hs * Ws == PLANE
+  const int plane_o = g.Ho * g.Wo;
+  const bool act_elu = g.act == MTRSSM_ACT_ELU, act_relu = g.act == MTRSSM_ACT_RELU, pre = g.pre_act != 0;
+  auto act_fwd_sel = [&](float x) {
+    float e = __expf(x) - 1.f;
+    asm volatile("" : "+v"(e));
+    const float neg = act_elu ? e : (act_relu ? 0.f : x);
+    return (x > 0.f || !pre) ? x : neg;
+  };
+  float pv[NIT][8];
+  auto stage_load_part = [&](int tile, int part, int nparts) {
+    constexpr int TOT = NIT * 8;
+    const int per = TOT / nparts;
+#pragma unroll
+    for (int j = 0; j < TOT; ++j) {
+      if (j / per != part) continue;
+      const int it = j / 8, u = j % 8;
+      const int q = wave * NIT + it, o = q % OCT, blk = q / OCT;
+      pv[it][u] = src[((size_t)tile * CIN + o * 8 + u) * PLANE + blk * 64 + lane];
+    }
+  };
+  auto stage_store_chunk = [&](int buf, int c) {
+    const int it = c / 4, u2 = c % 4;
+    const int q = wave * NIT + it, o = q % OCT, blk = q / OCT;
+    const int p = blk * 64 + lane;
+    const int spos = ((p >> wsh) + 1) * pw + (p & (Ws - 1)) + 1;
+    unsigned short p0[2], p1[2];
+    split_bf16<2>(act_fwd_sel(pv[it][2 * u2]), p0);
+    split_bf16<2>(act_fwd_sel(pv[it][2 * u2 + 1]), p1);
+    unsigned char* dst = patch + (size_t)buf * 2 * IMG + spos * RB + o * 16 + u2 * 4;
+    *reinterpret_cast<unsigned*>(dst) = (unsigned)p0[0] | ((unsigned)p1[0] << 16);
+    *reinterpret_cast<unsigned*>(dst + IMG) = (unsigned)p0[1] | ((unsigned)p1[1] << 16);
+  };
+  stage_load_part(wg, 0, 1);
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < NSC; ++c) stage_store_chunk(0, c);
+  __syncthreads();
+
+  // this lane's output pixel of unit u: sub-grid pixel j = 32 u + il -> (jy, jx); source position of tap (0, 0); output offset
+  auto unit_pos = [&](int u) {
+    const int j = u * 32 + il, jy = j >> wsh, jx = j & (Ws - 1);
+    return ((jy + g.OFFY + 1) * pw + (jx + g.OFFX + 1)) * RB + kl * 16;
+  };
+  auto unit_out = [&](int tile, int u) {
+    const int j = u * 32 + il, jy = j >> wsh, jx = j & (Ws - 1);
+    return (unsigned)tile * (unsigned)(COUT * plane_o) + (unsigned)(cbase * plane_o) + (unsigned)((jy * 2 + g.QY) * g.Wo + jx * 2 + g.QX);
+  };
+  f32x16 acc;
+  float fin[ROWS];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) fin[r] = 0.f;
+  // (the first unit's epilogue slots store zeros where the same wave stores unit 1 of its first frame one unit later)
+  unsigned ob_prev = unit_out(wg, 1);
+  struct Frag { bf16x8 b[2]; };
+  int it_no = 0;
+  for (int tile = wg; tile < ntiles; tile += nwg, ++it_no) {
+    const int buf = it_no & 1;
+    const unsigned char* img = patch + (size_t)buf * 2 * IMG;
+    const int next = tile + nwg < ntiles ? tile + nwg : tile;
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const unsigned ob_cur = unit_out(tile, u);
+      const unsigned ibase = (unsigned)(uintptr_t)img + (unsigned)unit_pos(u);
+      auto read_frag = [&](Frag& f, int kb) {
+        const int t = kb / CB, cb = kb % CB;
+        const int toff = -((t / 2) * pw + (t % 2)) * RB;  // TS = -1: tap (ty, tx) reads (jy - ty + OFFY, jx - tx + OFFX)
+        res_read_pair<IMG>(f.b[0], f.b[1], ibase + (unsigned)toff, cb);
+      };
+      Frag fr[3];
+      read_frag(fr[0], 0);
+      read_frag(fr[1], 1);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = bv[r];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        Frag& cur = fr[kb % 3];
+        if (kb + 2 < KB) {
+          read_frag(fr[(kb + 2) % 3], kb + 2);
+          res_wait<4>(cur.b[0], cur.b[1]);
+        } else if (kb + 1 < KB) {
+          res_wait<2>(cur.b[0], cur.b[1]);
+        } else {
+          res_wait<0>(cur.b[0], cur.b[1]);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kb][0], cur.b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kb][1], cur.b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kb][0], cur.b[0], acc, 0, 0, 0);
+        if (kb >= 1 && kb < 1 + NES) {  // rows of the previous unit
+#pragma unroll
+          for (int i = 0; i < RPE; ++i) {
+            const int j = (kb - 1) * RPE + i;
+            out[ob_prev + (unsigned)(((j & 3) + 8 * (j >> 2)) * plane_o)] = fin[j];
+          }
+        }
+        if (u == 0 && kb < 4) stage_load_part(next, kb, 4);
+        if (u >= UN / 2) {
+          const int local = kb == 0 ? 0 : (kb >= 1 + NES ? 1 + (kb - 1 - NES) : SPU);
+          const int slot = (u - UN / 2) * SPU + local;
+          if (local < SPU && slot < NSC) stage_store_chunk(buf ^ 1, slot);
+        }
+        MTRSSM_SGB(0x008, 1);
+        MTRSSM_SGB(0x002, 6);
+        MTRSSM_SGB(0x008, 1);
+        MTRSSM_SGB(0x002, 6);
+        MTRSSM_SGB(0x008, 1);
+        MTRSSM_SGB(0x002, 6);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int j = 0; j < ROWS; ++j) {
+        fin[j] = acc[j];
+        asm volatile("" : "+v"(fin[j]));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      ob_prev = ob_cur;
+    }
+    lds_barrier();
+  }
+#pragma unroll
+  for (int j = 0; j < ROWS; ++j) out[ob_prev + (unsigned)(((j & 3) + 8 * (j >> 2)) * plane_o)] = fin[j];
+}
+
+// ------------------------------------------------------------------------------------------------
 // Streaming 1x1 kernel for the residual stacks' second conv (forward with bias + skip, backward-data with act'(h)).
 //
 // K = Cin is 64 or 128: 24..48 MFMAs per 32 pixels against 16..32 KB of HBM traffic -- a bandwidth problem
