@@ -995,11 +995,12 @@ def test_captured_train_step_matches_eager(name: str, lib_loaded: None) -> None:
         moved = (flat.param - start).abs()
         assert float(moved.max()) > 5e-5  # eight Adam steps of 1e-5 were applied (at most lr per step and element)
         results[mode] = (losses, flat.param.clone())
-    # same uniforms, same arithmetic up to the arrival order of the fp32 atomics; a skipped or doubled optimizer step would move
-    # parameters by 1e-5
+    # same uniforms, same arithmetic up to the arrival order of the fp32 atomics.  A skipped or doubled optimizer step would move
+    # EVERY parameter by ~1e-5 (the mean catches it); single elements whose gradient is rounding noise may take Adam's +-lr step in
+    # opposite directions in the two runs (seen: one element off by 7.7e-6 after eight steps), hence the loose maximum.
     np.testing.assert_allclose(results["graph"][0], results["eager"][0], rtol=1e-4)
     diff = (results["graph"][1] - results["eager"][1]).abs()
-    assert float(diff.max()) < 4e-6 and float(diff.mean()) < 2e-7, (float(diff.max()), float(diff.mean()))
+    assert float(diff.max()) < 2e-4 and float(diff.mean()) < 2e-7, (float(diff.max()), float(diff.mean()))
 
 
 def test_cpu_tensors_are_refused(lib_loaded: None) -> None:
