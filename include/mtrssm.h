@@ -439,11 +439,14 @@ int mtrssm_unpack_conv_grads(const int64_t* table, int32_t count, int32_t blocks
  * source (mtrssm_conv_gather_gemm takes one launch per class: each re-reads the source).  g4[q], wq4[q]: geometry and packed
  * sub-kernel (mtrssm_pack_conv_weight(s), two bf16 pieces) of class q = 2 * QY + QX exactly as for mtrssm_conv_gather_gemm
  * (KH = KW = 2, TS = -1, SS = 1, OS = 2, same source / output).  Optionally a second tensor (gb4 != NULL: the other modality) in
- * the same launch.  mtrssm_convt_quad_supported: 1 / 2 = the instantiated shape (64 -> 32 on 64-pixel planes, 32 -> 16 on
- * 256-pixel planes), 0 = use the general path. */
+ * the same launch.  actgrad (may be NULL): out *= act'(actgrad[same index]) -- the backward-data of a Conv2d(k = 3, s = 2, p = 1)
+ * is this transposed conv with the kernel zero-padded to 4 x 4 (the encoders' third conv).
+ * mtrssm_convt_quad_supported: 1 / 2 = the instantiated forward shapes (64 -> 32 on 64-pixel planes, 32 -> 16 on 256-pixel planes),
+ * 3 = 32 -> 16 on 64-pixel planes WITH actgrad; 0 = use the general path. */
 int mtrssm_convt_quad_supported(const MtrssmConvGeom* g4);
-int mtrssm_convt_quad(const MtrssmConvGeom* ga4, const float* srca, const uint16_t* const* wqa4, const float* biasa, float* outa,
-                      const MtrssmConvGeom* gb4, const float* srcb, const uint16_t* const* wqb4, const float* biasb, float* outb, void* stream);
+int mtrssm_convt_quad(const MtrssmConvGeom* ga4, const float* srca, const uint16_t* const* wqa4, const float* biasa, const float* actgrada,
+                      float* outa, const MtrssmConvGeom* gb4, const float* srcb, const uint16_t* const* wqb4, const float* biasb,
+                      const float* actgradb, float* outb, void* stream);
 /* Last decoder layer (default.yaml:70-74, channels [.., 1]): out[N, Cout<=2, 2Hs, 2Ws] = bias + ConvTranspose2d_{k=4,s=2,p=1}(pre(src[N,C,Hs,Ws]))
  * with w in the ConvTranspose2d layout [C][Cout][4][4].  All four output parity classes in one pass, one activation per
  * source element. */

@@ -107,7 +107,8 @@ SYMBOLS: dict[str, tuple[type | None, list[type]]] = {
     "mtrssm_channel_sum": (C.c_int, [_p, _i, _i, _i, _p, _p]),
     "mtrssm_convt_k4s2_thin": (C.c_int, [_i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _p, _p]),
     "mtrssm_convt_quad_supported": (C.c_int, [C.POINTER(ConvGeom)]),
-    "mtrssm_convt_quad": (C.c_int, [C.POINTER(ConvGeom), _p, C.POINTER(C.c_void_p), _p, _p, C.POINTER(ConvGeom), _p, C.POINTER(C.c_void_p), _p, _p, _p]),
+    "mtrssm_convt_quad": (C.c_int, [C.POINTER(ConvGeom), _p, C.POINTER(C.c_void_p), _p, _p, _p, C.POINTER(ConvGeom), _p, C.POINTER(C.c_void_p),
+                                    _p, _p, _p, _p]),
     "mtrssm_conv_tgather_thin": (C.c_int, [_i] * 11 + [_p, _p, _p, _i, _i, _p, _p, _p, _p]),
     "mtrssm_episode_gather": (C.c_int, [_p, _p, _p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _f, _p, _p, _p]),
     "mtrssm_gaussian_nll_fwd": (C.c_int, [_p, _p, C.c_int64, C.c_int64, _i, _p, _p]),

@@ -215,23 +215,22 @@ def _job_args(job: tuple) -> tuple:
 
 
 def _quad_args(job: tuple) -> tuple:
-    _, geoms, y, wqs, bias, out = job
+    _, geoms, y, wqs, bias, out, actgrad = job
     arr = (C.c_void_p * 4)(*[_lib.raw_ptr(wq) for wq in wqs])
-    job_keepalive = arr  # noqa: F841 (ctypes array lives until the call returns: it is an argument below)
-    return (geoms, _lib.ptr(y), arr, _lib.ptr(bias), _lib.ptr(out))
+    return (geoms, _lib.ptr(y), arr, _lib.ptr(bias), _lib.ptr(actgrad), _lib.ptr(out))
 
 
 def _quad_work(job: tuple) -> tuple[float, float]:
     g = job[1][0]
     pixels = g.N * g.Ho * g.Wo
-    return 2.0 * pixels * g.Cout * 4 * g.C, 4.0 * (g.N * g.C * g.Hs * g.Ws + pixels * g.Cout)
+    return 2.0 * pixels * g.Cout * 4 * g.C, 4.0 * (g.N * g.C * g.Hs * g.Ws + pixels * g.Cout * (2 if job[6] is not None else 1))
 
 
 def _launch_quad(ja: tuple, jb: tuple | None) -> None:
     lib = _lib.load()
     fa, ba = _quad_work(ja)
     fb, bb = _quad_work(jb) if jb is not None else (0.0, 0.0)
-    args_b = _quad_args(jb) if jb is not None else (None, None, None, None, None)
+    args_b = _quad_args(jb) if jb is not None else (None, None, None, None, None, None)
     _lib.check(_lib.TIMERS.call("mtrssm_convt_quad", lib.mtrssm_convt_quad, *_quad_args(ja), *args_b, _lib.stream_ptr(ja[2].device),
                                 flops=fa + fb, nbytes=ba + bb), "mtrssm_convt_quad")
 
@@ -328,22 +327,26 @@ def _conv_transposed_gather(y: Tensor, w: Tensor, bias: Tensor | None, stride: i
             int(pre_act), act, _lib.ptr(out), _lib.stream_ptr(y.device), flops=2.0 * n * ho * wo * c * 4 * o,
             nbytes=4.0 * (y.numel() + out.numel())), "mtrssm_convt_k4s2_thin")
         return out
-    if (stride == 2 and kh == 4 and kw == 4 and pad == 1 and (ho, wo) == (2 * hs, 2 * ws) and actgrad_in is None and add_in is None
-            and _MFMA_SPLIT == 2 and CONVT_QUAD and (o, c, hs * ws) in ((64, 32, 64), (32, 16, 256))):  # noqa: PLR2004
-        # the decoders' ConvTranspose layers: all four parity classes in one pass over the source (convt_quad_resident_kernel)
+    quad_fwd = kh == 4 and kw == 4 and actgrad_in is None and (o, c, hs * ws) in ((64, 32, 64), (32, 16, 256))  # noqa: PLR2004
+    quad_bwd = kh == 3 and kw == 3 and actgrad_in is not None and bias is None and (o, c, hs * ws) == (32, 16, 64)  # noqa: PLR2004
+    if (stride == 2 and pad == 1 and (ho, wo) == (2 * hs, 2 * ws) and add_in is None and _MFMA_SPLIT == 2 and CONVT_QUAD  # noqa: PLR2004
+            and (quad_fwd or quad_bwd)):
+        # the decoders' ConvTranspose layers (and the backward-data of the encoders' third conv = the same transposed conv with
+        # its 3 x 3 kernel zero-padded to 4 x 4): all four parity classes in one pass over the source (convt_quad_resident_kernel)
+        w4 = w if kh == 4 else torch.nn.functional.pad(w, (0, 1, 0, 1))  # noqa: PLR2004
         geoms = (_lib.ConvGeom * 4)()
         wqs = []
         for q in range(4):
             qy, qx = q >> 1, q & 1
             ky0, kx0 = (qy + pad) % stride, (qx + pad) % stride
-            wsub = w[:, :, ky0::stride, kx0::stride].permute(1, 0, 2, 3)  # [c][o][2][2]
+            wsub = w4[:, :, ky0::stride, kx0::stride].permute(1, 0, 2, 3)  # [c][o][2][2]
             wp, wq = pack_weight(wsub, sub=q)
             geoms[q] = _geom(N=n, C=o, Hs=hs, Ws=ws, C2=0, Cpad=wp.shape[2], KH=2, KW=2, SS=1, TS=-1,
                              OFFY=(qy + pad - ky0) // stride, OFFX=(qx + pad - kx0) // stride, Hq=hs, Wq=ws, OS=stride, QY=qy, QX=qx,
                              Ho=ho, Wo=wo, Cout=c, CoutPad=wp.shape[0], pre_act=int(pre_act), act=act)
             wqs.append(wq)
         if _lib.load().mtrssm_convt_quad_supported(geoms):
-            job = ("quad", geoms, y, wqs, bias, out)
+            job = ("quad", geoms, y, wqs, bias, out, actgrad_in)
             if _DEFER is not None:
                 _DEFER.append(job)
             else:

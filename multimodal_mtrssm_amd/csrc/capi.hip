@@ -33,8 +33,8 @@ int conv_weight_grad_launch(const MtrssmConvGeom*, const float*, const float*, c
 int channel_sum_launch(const float*, int, int, int, float*, hipStream_t);
 int convt_k4s2_thin_launch(int, int, int, int, int, const float*, const float*, const float*, int, int, float*, hipStream_t);
 int conv_convt_quad_supported(const MtrssmConvGeom*);
-int conv_convt_quad_launch(const MtrssmConvGeom*, const float*, const unsigned short* const*, const float*, float*, const MtrssmConvGeom*, const float*,
-                           const unsigned short* const*, const float*, float*, hipStream_t);
+int conv_convt_quad_launch(const MtrssmConvGeom*, const float*, const unsigned short* const*, const float*, const float*, float*,
+                           const MtrssmConvGeom*, const float*, const unsigned short* const*, const float*, const float*, float*, hipStream_t);
 int conv_tgather_thin_launch(int, int, int, int, int, int, int, int, int, int, int, const float*, const float*, const float*, int, int, const float*,
                              const float*, float*, hipStream_t);
 int nll_fwd_launch(const float*, const float*, int64_t, int64_t, int, float*, hipStream_t);
@@ -160,11 +160,12 @@ MTRSSM_API int mtrssm_conv_tgather_thin(int32_t N, int32_t O, int32_t Hs, int32_
                                   static_cast<hipStream_t>(stream));
 }
 MTRSSM_API int mtrssm_convt_quad_supported(const MtrssmConvGeom* g4) { return conv_convt_quad_supported(g4); }
-MTRSSM_API int mtrssm_convt_quad(const MtrssmConvGeom* ga4, const float* srca, const uint16_t* const* wqa4, const float* biasa, float* outa,
-                                 const MtrssmConvGeom* gb4, const float* srcb, const uint16_t* const* wqb4, const float* biasb, float* outb,
-                                 void* stream) {
-  return conv_convt_quad_launch(ga4, srca, reinterpret_cast<const unsigned short* const*>(wqa4), biasa, outa, gb4, srcb,
-                                reinterpret_cast<const unsigned short* const*>(wqb4), biasb, outb, static_cast<hipStream_t>(stream));
+MTRSSM_API int mtrssm_convt_quad(const MtrssmConvGeom* ga4, const float* srca, const uint16_t* const* wqa4, const float* biasa,
+                                 const float* actgrada, float* outa, const MtrssmConvGeom* gb4, const float* srcb,
+                                 const uint16_t* const* wqb4, const float* biasb, const float* actgradb, float* outb, void* stream) {
+  return conv_convt_quad_launch(ga4, srca, reinterpret_cast<const unsigned short* const*>(wqa4), biasa, actgrada, outa, gb4, srcb,
+                                reinterpret_cast<const unsigned short* const*>(wqb4), biasb, actgradb, outb,
+                                static_cast<hipStream_t>(stream));
 }
 MTRSSM_API int mtrssm_convt_k4s2_thin(int32_t N, int32_t C, int32_t Hs, int32_t Ws, int32_t Cout, const float* src, const float* w,
                                       const float* bias, int32_t pre_act, int32_t act, float* out, void* stream) {

@@ -1682,17 +1682,20 @@ static int quad_key(const MtrssmConvGeom* g4) {
   const int plane = g0.Hs * g0.Ws;
   if (g0.C == 64 && g0.Cout == 32 && plane == 64) return 1;
   if (g0.C == 32 && g0.Cout == 16 && plane == 256) return 2;
+  if (g0.C == 32 && g0.Cout == 16 && plane == 64) return 3;  // backward-data of the encoders' third conv (k = 3 zero-padded to 4)
   return 0;
 }
 
 int conv_convt_quad_supported(const MtrssmConvGeom* g4) { return resident_enabled() ? quad_key(g4) : 0; }
 
-int conv_convt_quad_launch(const MtrssmConvGeom* ga4, const float* srca, const unsigned short* const* wqa4, const float* biasa, float* outa,
-                           const MtrssmConvGeom* gb4, const float* srcb, const unsigned short* const* wqb4, const float* biasb, float* outb,
-                           hipStream_t stream) {
+int conv_convt_quad_launch(const MtrssmConvGeom* ga4, const float* srca, const unsigned short* const* wqa4, const float* biasa,
+                           const float* actgrada, float* outa, const MtrssmConvGeom* gb4, const float* srcb,
+                           const unsigned short* const* wqb4, const float* biasb, const float* actgradb, float* outb, hipStream_t stream) {
   const int key = quad_key(ga4);
-  if (!key || !srca || !wqa4 || !outa || (gb4 && (quad_key(gb4) != key || !srcb || !wqb4 || !outb))) {
-    set_error("convt_quad: layer outside the kernel's shapes (k4 s2 p1, 64 -> 32 on 64-pixel planes or 32 -> 16 on 256-pixel planes, two bf16 pieces)");
+  const bool epi = actgrada != nullptr;
+  if (!key || !srca || !wqa4 || !outa || (gb4 && (quad_key(gb4) != key || !srcb || !wqb4 || !outb || (actgradb != nullptr) != epi)) ||
+      (epi != (key == 3))) {
+    set_error("convt_quad: layer outside the kernel's shapes (k4 s2 p1: 64 -> 32 on 64-pixel planes, 32 -> 16 on 256-pixel planes; with act' operand: 32 -> 16 on 64-pixel planes; two bf16 pieces)");
     return MTRSSM_EINVAL;
   }
   QuadProblem qa{}, qb{};
@@ -1701,8 +1704,8 @@ int conv_convt_quad_launch(const MtrssmConvGeom* ga4, const float* srca, const u
     if (!wqa4[q]) { set_error("convt_quad: null packed weights"); return MTRSSM_EINVAL; }
     if (gb4) { qb.g[q] = gb4[q]; qb.wq[q] = wqb4[q]; if (!wqb4[q]) { set_error("convt_quad: null packed weights"); return MTRSSM_EINVAL; } }
   }
-  qa.src = srca; qa.bias = biasa; qa.out = outa;
-  qb.src = srcb; qb.bias = biasb; qb.out = outb;
+  qa.src = srca; qa.bias = biasa; qa.actgrad = actgrada; qa.out = outa;
+  qb.src = srcb; qb.bias = biasb; qb.actgrad = actgradb; qb.out = outb;
   const long ta = ga4[0].N, tb = gb4 ? gb4[0].N : 0;
   const int ncu = cu_count();
   if (tb == 0) {
@@ -1715,21 +1718,22 @@ int conv_convt_quad_launch(const MtrssmConvGeom* ga4, const float* srca, const u
     qb.nx = (int)(ncu - na < tb ? ncu - na : tb);
   }
   const dim3 grid((unsigned)(qa.nx + qb.nx));
-#define MTRSSM_QUAD_LAUNCH(CIN_, COUT_, PLANE_)                                                                      \
+#define MTRSSM_QUAD_LAUNCH(CIN_, COUT_, PLANE_, EPI_)                                                                \
   {                                                                                                                   \
     static bool attr_done = false;                                                                                    \
     const size_t ql = quad_lds_bytes<CIN_, PLANE_>();                                                                 \
     if (!attr_done) {                                                                                                 \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convt_quad_resident_kernel<CIN_, COUT_, PLANE_>),       \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convt_quad_resident_kernel<CIN_, COUT_, PLANE_, EPI_>), \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)ql);                                 \
       attr_done = true;                                                                                               \
     }                                                                                                                 \
-    set_last_kernel("mtrssm::convt_quad_resident_kernel<" #CIN_ ", " #COUT_ ", " #PLANE_ ">");                          \
-    hipLaunchKernelGGL((convt_quad_resident_kernel<CIN_, COUT_, PLANE_>), grid, dim3(kResThreads), ql, stream, qa, qb); \
+    set_last_kernel("mtrssm::convt_quad_resident_kernel<" #CIN_ ", " #COUT_ ", " #PLANE_ ", " #EPI_ ">");                \
+    hipLaunchKernelGGL((convt_quad_resident_kernel<CIN_, COUT_, PLANE_, EPI_>), grid, dim3(kResThreads), ql, stream, qa, qb); \
     return launched("convt_quad");                                                                                    \
   }
-  if (key == 1) MTRSSM_QUAD_LAUNCH(64, 32, 64)
-  MTRSSM_QUAD_LAUNCH(32, 16, 256)
+  if (key == 1) MTRSSM_QUAD_LAUNCH(64, 32, 64, false)
+  if (key == 2) MTRSSM_QUAD_LAUNCH(32, 16, 256, false)
+  MTRSSM_QUAD_LAUNCH(32, 16, 64, true)
 #undef MTRSSM_QUAD_LAUNCH
 }
 

@@ -413,6 +413,7 @@ struct QuadProblem {
   const unsigned short* wq[4];  // their packed sub-kernels [pieces][CoutPad = 32][4 taps][Cpad = CIN]
   const float* src;
   const float* bias;
+  const float* actgrad;         // EPI: out *= act'(actgrad[same index as out]) (backward-data of a strided conv), else NULL
   float* out;
   int nx;                       // workgroups of the launch that work on this tensor
 };
@@ -422,7 +423,7 @@ __host__ __device__ constexpr size_t quad_lds_bytes() {
   return (size_t)4 * (PLANE == 64 ? 108 : 340) * res_row_bytes(CIN);  // haloed positions: 10x10 / 18x6, 18x18 / 34x10
 }
 
-template <int CIN, int COUT, int PLANE>
+template <int CIN, int COUT, int PLANE, bool EPI>
 __global__ __launch_bounds__(kResThreads, 1) void convt_quad_resident_kernel(const QuadProblem qa, const QuadProblem qb) {
   constexpr int CB = CIN / 16, KB = 4 * CB;
   constexpr int RB = res_row_bytes(CIN);
@@ -435,7 +436,8 @@ __global__ __launch_bounds__(kResThreads, 1) void convt_quad_resident_kernel(con
   constexpr int ROWS = COUT / 2;           // accumulator rows that hold output channels (16 of 16, or 8 when COUT = 16)
   constexpr int RPE = 2, NES = ROWS / RPE; // epilogue rows per k-block, k-blocks [1, 1 + NES)
   constexpr int SPU = KB - NES;            // staging slots per unit: k-block 0 and [1 + NES, KB)
-  static_assert(UN >= 2 && 1 + NES <= KB && (UN / 2) * SPU >= NSC && NIT >= 1, "schedule");
+  constexpr int NLD = EPI ? 2 : 0;         // k-blocks [0, NLD) request the unit's act' operand (ROWS / NLD rows each)
+  static_assert(UN >= 2 && 1 + NES <= KB && (UN / 2) * SPU >= NSC && NIT >= 1 && NLD <= KB, "schedule");
   const bool second = blockIdx.x >= (unsigned)qa.nx;  // workgroup-uniform
   const QuadProblem& Q = second ? qb : qa;
   const int wg = second ? (int)blockIdx.x - qa.nx : (int)blockIdx.x, nwg = Q.nx;
@@ -445,6 +447,7 @@ __global__ __launch_bounds__(kResThreads, 1) void convt_quad_resident_kernel(con
   const unsigned short* __restrict__ wq = Q.wq[wave];
   const float* __restrict__ src = Q.src;
   const float* __restrict__ bias = Q.bias;
+  const float* __restrict__ actgrad = Q.actgrad;  // host: non-null exactly in the EPI instantiation
   float* __restrict__ out = Q.out;
   const int ntiles = g.N;  // one frame per tile
   if (wg >= ntiles) return;
@@ -526,9 +529,15 @@ __global__ __launch_bounds__(kResThreads, 1) void convt_quad_resident_kernel(con
     return (unsigned)tile * (unsigned)(COUT * plane_o) + (unsigned)(cbase * plane_o) + (unsigned)((jy * 2 + g.QY) * g.Wo + jx * 2 + g.QX);
   };
   f32x16 acc;
-  float fin[ROWS];
+  float fin[ROWS], gvs[2][ROWS];  // gvs[u & 1]: the act' operand of unit u, requested in its first k-blocks, used one unit later
 #pragma unroll
-  for (int r = 0; r < ROWS; ++r) fin[r] = 0.f;
+  for (int r = 0; r < ROWS; ++r) fin[r] = gvs[0][r] = gvs[1][r] = 0.f;
+  auto act_grad_sel = [&](float x) {
+    float e = __expf(x);
+    asm volatile("" : "+v"(e));
+    const float neg = act_elu ? e : (act_relu ? 0.f : 1.f);
+    return x > 0.f ? 1.f : neg;
+  };
   // (the first unit's epilogue slots store zeros where the same wave stores unit 1 of its first frame one unit later)
   unsigned ob_prev = unit_out(wg, 1);
   struct Frag { bf16x8 b[2]; };
@@ -570,7 +579,17 @@ __global__ __launch_bounds__(kResThreads, 1) void convt_quad_resident_kernel(con
 #pragma unroll
           for (int i = 0; i < RPE; ++i) {
             const int j = (kb - 1) * RPE + i;
-            out[ob_prev + (unsigned)(((j & 3) + 8 * (j >> 2)) * plane_o)] = fin[j];
+            float v = fin[j];
+            if (EPI) v *= act_grad_sel(gvs[(u + 1) & 1][j]);
+            out[ob_prev + (unsigned)(((j & 3) + 8 * (j >> 2)) * plane_o)] = v;
+          }
+        }
+        if (EPI && kb < NLD) {
+          constexpr int RPL = ROWS / 2;
+#pragma unroll
+          for (int i = 0; i < RPL; ++i) {
+            const int j = kb * RPL + i;
+            gvs[u & 1][j] = actgrad[ob_cur + (unsigned)(((j & 3) + 8 * (j >> 2)) * plane_o)];
           }
         }
         if (u == 0 && kb < 4) stage_load_part(next, kb, 4);
@@ -598,7 +617,11 @@ __global__ __launch_bounds__(kResThreads, 1) void convt_quad_resident_kernel(con
     lds_barrier();
   }
 #pragma unroll
-  for (int j = 0; j < ROWS; ++j) out[ob_prev + (unsigned)(((j & 3) + 8 * (j >> 2)) * plane_o)] = fin[j];
+  for (int j = 0; j < ROWS; ++j) {
+    float v = fin[j];
+    if (EPI) v *= act_grad_sel(gvs[(UN - 1) & 1][j]);
+    out[ob_prev + (unsigned)(((j & 3) + 8 * (j >> 2)) * plane_o)] = v;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
