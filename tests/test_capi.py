@@ -76,6 +76,16 @@ def test_invalid_arguments_are_rejected_without_a_launch() -> None:
     assert lib.mtrssm_adamw_prepare(None, 10, None, None, 0.9, 0.999, None) == -1
     assert lib.mtrssm_clear(None, 16, None) == -1
     assert lib.mtrssm_adamw_apply(None, None, None, None, None, 10, None, None, 1.0, 1.0, 0.9, 0.999, 1e-8, 1e-2, None) == -1
+    # round-2 entries: argument errors are reported before anything is launched
+    assert lib.mtrssm_conv_tgather_thin(1, 16, 8, 8, 9, 3, 3, 2, 1, 16, 16, None, None, None, 0, 0, None, None, None, None) == -1  # Cout > 8
+    assert b"tgather" in lib.mtrssm_last_error()
+    geoms = (_lib.ConvGeom * 4)()  # all-zero geometries: no instantiated shape
+    assert lib.mtrssm_convt_quad_supported(geoms) == 0
+    assert lib.mtrssm_convt_quad(geoms, None, None, None, None, None, None, None, None, None, None, None, None) == -1
+    assert b"convt_quad" in lib.mtrssm_last_error()
+    g = _lib.Gemm()
+    g.mfma_split = 1  # only 0 (fp32 MFMA) and 2 (two bf16 pieces) exist
+    assert lib.mtrssm_gemm(C.byref(g), None) == -1
 
 
 def test_missing_library_fails_loudly(monkeypatch: pytest.MonkeyPatch, tmp_path: Path) -> None:
