@@ -611,6 +611,48 @@ def test_paired_stacks_of_different_shape_fall_back(lib_loaded: None) -> None:
     np.testing.assert_allclose(_np(pb), _np(rb), rtol=1e-6, atol=1e-6)
 
 
+def test_one_pass_parity_class_kernels_match_the_per_class_launches(lib_loaded: None) -> None:
+    """convt_quad_resident_kernel (all four output parity classes of a k = 4, s = 2 ConvTranspose2d in one pass, single and
+    paired, and -- with the act' operand -- the backward-data of a k = 3, s = 2 Conv2d) and conv_tgather_thin_kernel (the thin
+    transposed gather) against the general path they replace (one gather launch per parity class): the same products, summed
+    in another order."""
+    from multimodal_mtrssm_amd import conv
+
+    gen = torch.Generator(device="cpu").manual_seed(23)
+
+    def rnd(*shape: int, scale: float = 1.0) -> torch.Tensor:
+        return (torch.randn(*shape, generator=gen) * scale).to(DEV).requires_grad_(True)
+
+    def run() -> list[torch.Tensor]:
+        gen.manual_seed(23)
+        outs = []
+        # decoder shapes: 64 -> 32 on 8x8 (vision) and 16x4 (audio) planes, paired; 32 -> 16 on 16x16, single
+        xa, xv = rnd(6, 64, 16, 4), rnd(6, 64, 8, 8)
+        wa, wv, ba, bv = rnd(64, 32, 4, 4, scale=0.05), rnd(64, 32, 4, 4, scale=0.05), rnd(32, scale=0.1), rnd(32, scale=0.1)
+        ya, yv = conv.conv_transpose2d_pair((xa, wa, ba, 2, 1, 0, True, 2), (xv, wv, bv, 2, 1, 0, True, 2))
+        x2, w2, b2 = rnd(5, 32, 16, 16), rnd(32, 16, 4, 4, scale=0.05), rnd(16, scale=0.1)
+        y2 = conv.conv_transpose2d(x2, w2, b2, stride=2, padding=1, output_padding=0, pre_act=True, act=2)
+        # encoder shapes: the backward-data of 16 -> 32 (k3 s2, quad kernel with act') and of 8 -> 16 (thin transposed gather)
+        x3, w3, b3 = rnd(4, 16, 16, 16), rnd(32, 16, 3, 3, scale=0.1), rnd(32, scale=0.1)
+        y3 = conv.conv2d(x3, w3, b3, stride=2, padding=1, pre_act=True, act=2)
+        x4, w4, b4 = rnd(4, 8, 32, 32), rnd(16, 8, 3, 3, scale=0.1), rnd(16, scale=0.1)
+        y4 = conv.conv2d(x4, w4, b4, stride=2, padding=1, pre_act=True, act=2)
+        (ya.square().sum() + yv.sin().sum() + y2.square().sum() + y3.sin().sum() + y4.square().sum()).backward()
+        torch.cuda.synchronize()
+        outs += [ya.detach(), yv.detach(), y2.detach(), xa.grad, xv.grad, x2.grad, x3.grad, x4.grad]
+        return outs
+
+    res = {}
+    for one_pass in (False, True):
+        conv.CONVT_QUAD = conv.TGATHER_THIN = one_pass
+        try:
+            res[one_pass] = run()
+        finally:
+            conv.CONVT_QUAD = conv.TGATHER_THIN = True
+    for i, (a, b) in enumerate(zip(res[True], res[False], strict=True)):
+        np.testing.assert_allclose(_np(a), _np(b), rtol=2e-5, atol=2e-6 * float(b.abs().max()), err_msg=str(i))
+
+
 def test_paired_launches_change_nothing(lib_loaded: None) -> None:
     """conv.paired (the audio and the vision stack's equal layers in one launch, the default) against one launch per
     layer: the gathers are the same arithmetic per output tile, so forward values are bit-identical; gradients are equal
