@@ -365,7 +365,7 @@ __global__ __launch_bounds__(kConvThreads, 3) void conv_gather_split_kernel(cons
   int grp = 0, c0 = 0;
   for (int step = 0; step < nsteps; ++step) {
     const int tap0 = grp * tg;
-    if (step > 0) __syncthreads();  // every wave is done with the previous step's LDS images
+    if (step > 0) lds_barrier();  // every wave is done with the previous step's LDS images
     store_w();
     {  // next step's weights (L2-resident): in flight under the patch conversion and this step's MFMAs
       int ngrp = grp + 1, nc0 = c0;
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(kConvThreads, 3) void conv_gather_split_kernel(cons
       // the NEXT chunk's patch (HBM): a whole chunk of steps ahead of its conversion, in the same registers
       if (c0 + kKC < g.Cpad) load_patch(c0 + kKC);
     }
-    __syncthreads();
+    lds_barrier();
     int ty = tap0 / g.KW, tx = tap0 - ty * g.KW;
     auto next_tapoff = [&]() {
       const int o = g.TS > 0 ? ty * pg.pw + tx : (g.KH - 1 - ty) * pg.pw + (g.KW - 1 - tx);
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(kConvThreads, 3) void conv1x1_split_kernel(const Ga
       const int slot = q & 7, row = (q >> 3) & (TCO - 1), s = q / (8 * TCO);
       wv[i] = *reinterpret_cast<const u32x4*>(wq + s * wq_plane + (size_t)(co0 + row) * g.Cpad + c0 + slot * 8);
     }
-    if (c0 > 0) __syncthreads();  // everyone is done with the previous step's images
+    if (c0 > 0) lds_barrier();  // everyone is done with the previous step's images
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
       float x[8];
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(kConvThreads, 3) void conv1x1_split_kernel(const Ga
       const int slot = q & 7, row = (q >> 3) & (TCO - 1), s = q / (8 * TCO);
       *reinterpret_cast<u32x4*>(w_lds + s * TCO * 128 + swz128(row, slot)) = wv[i];
     }
-    __syncthreads();
+    lds_barrier();
     // ---- four k-blocks of 16 channels
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
@@ -733,7 +733,7 @@ __global__ __launch_bounds__(2 * kConvThreads, 2) void conv_weight_grad_split_ke
           conv_p(cur, A + (size_t)SPLIT * a_bytes);
           conv_a(cur, grp + 1, A);
         }
-        __syncthreads();
+        lds_barrier();
       }
     } else {
       // nbuf == 1 (images too big to double-buffer: the k=4 s=2 decoder layers in three pieces): stage, barrier, the
@@ -751,8 +751,8 @@ __global__ __launch_bounds__(2 * kConvThreads, 2) void conv_weight_grad_split_ke
           }
           conv_a(R, grp + 1, A);  // its loads have landed under the patch work
         }
-        __syncthreads();
-        if (nbuf == 1 && grp + 1 < iend) __syncthreads();  // the consumers are done with the only buffer
+        lds_barrier();
+        if (nbuf == 1 && grp + 1 < iend) lds_barrier();  // the consumers are done with the only buffer
       }
     }
     if (dbias != nullptr) {  // thread (row, o8): the 8 octet lanes of a row are consecutive lanes
@@ -808,7 +808,7 @@ __global__ __launch_bounds__(2 * kConvThreads, 2) void conv_weight_grad_split_ke
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[s][j][r] = 0.f;
 
-  __syncthreads();  // first group staged
+  lds_barrier();  // first group staged
   int cur = 0;
   for (long grp = gbeg; grp < gend; ++grp) {
     const unsigned char* A = lds_raw + (size_t)cur * buf_bytes;
@@ -850,9 +850,9 @@ __global__ __launch_bounds__(2 * kConvThreads, 2) void conv_weight_grad_split_ke
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     if (nbuf == 2) cur ^= 1;
-    else if (grp + 1 < gend) __syncthreads();  // single buffer: wait for the next group to be staged
+    else if (grp + 1 < gend) lds_barrier();  // single buffer: wait for the next group to be staged
   }
 
 #pragma unroll

@@ -133,12 +133,33 @@ __device__ __forceinline__ void store_tile(const Stage& st, float* img, int act,
   }
 }
 
+// full tiles (FAST instantiation): nothing to mask
+template <bool RMAJOR>
+__device__ __forceinline__ void store_tile_full(const Stage& st, float* img, int act) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int f = tid + 256 * j;
+    const float4 q = act4(st.v[j], act);
+    if (RMAJOR) {
+      *reinterpret_cast<float4*>(img + (f >> 4) * kLdT + 4 * (f & 15)) = q;
+    } else {
+      float* d = img + (f >> 3) * kLdRow + 4 * (f & 7);
+      d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w;
+    }
+  }
+}
+
 template <bool RMAJOR>
 __device__ __forceinline__ float image_at(const float* img, int row, int r) {
   return RMAJOR ? img[r * kLdT + row] : img[row * kLdRow + r];
 }
 
-template <bool AR, bool BR>
+// FAST: every tile of the launch is full (M, N multiples of 64, every reduction slice a whole number of 32-steps) and both
+// operands take 16-byte loads: per-thread pointers advance by one k-step per request and nothing is clamped or masked.  Per
+// k-step the general form spent ~3000 cycles of address arithmetic, clamps, masks and their waits around 1100 cycles of
+// MFMAs (stamped, one workgroup per CU) -- the MFMA pipe idled 3/4 of the time on the 3200 x 4096 x 256 head GEMMs.
+template <bool AR, bool BR, bool FAST>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float lds[2][2][kImage];  // [buffer][operand][image]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -163,15 +184,46 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
   // multiplied out of LDS, so a global load has two whole steps to land; with one stage the ~1.5 us load latency, not the
   // 0.43 us of MFMAs, set the step time on grids of < 1 workgroup per SIMD (measured: 13-16 TFLOP/s).
   Stage sa[2], sb[2];
+  // FAST: this thread's two quads of each operand at the NEXT step to request (requests come in step order)
+  const float4* pa[2];
+  const float4* pb[2];
+  size_t bump_a = 0, bump_b = 0;  // float4s per k-step
+  if (FAST) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int f = tid + 256 * j;
+      pa[j] = reinterpret_cast<const float4*>(AR ? g.A + (size_t)(s_lo * kStep + (f >> 4)) * g.lda + i0 + 4 * (f & 15)
+                                                 : g.A + (size_t)(i0 + (f >> 3)) * g.lda + s_lo * kStep + 4 * (f & 7));
+      pb[j] = reinterpret_cast<const float4*>(BR ? g.B + (size_t)(s_lo * kStep + (f >> 4)) * g.ldb + j0 + 4 * (f & 15)
+                                                 : g.B + (size_t)(j0 + (f >> 3)) * g.ldb + s_lo * kStep + 4 * (f & 7));
+    }
+    bump_a = AR ? (size_t)kStep * g.lda / 4 : kStep / 4;
+    bump_b = BR ? (size_t)kStep * g.ldb / 4 : kStep / 4;
+  }
   auto issue = [&](int which, int s) {
     if (s < s_hi) {
-      load_tile<AR>(sa[which], g.A, g.lda, g.M, i0, s * kStep, r_end, vec_a);
-      load_tile<BR>(sb[which], g.B, g.ldb, g.N, j0, s * kStep, r_end, vec_b);
+      if (FAST) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          sa[which].v[j] = *pa[j];
+          sb[which].v[j] = *pb[j];
+          pa[j] += bump_a;
+          pb[j] += bump_b;
+        }
+      } else {
+        load_tile<AR>(sa[which], g.A, g.lda, g.M, i0, s * kStep, r_end, vec_a);
+        load_tile<BR>(sb[which], g.B, g.ldb, g.N, j0, s * kStep, r_end, vec_b);
+      }
     }
   };
   auto to_lds = [&](int which, int s, int buf) {
-    store_tile<AR>(sa[which], lds[buf][0], g.act_a, g.M, i0, s * kStep, r_end);
-    store_tile<BR>(sb[which], lds[buf][1], g.act_b, g.N, j0, s * kStep, r_end);
+    if (FAST) {
+      store_tile_full<AR>(sa[which], lds[buf][0], g.act_a);
+      store_tile_full<BR>(sb[which], lds[buf][1], g.act_b);
+    } else {
+      store_tile<AR>(sa[which], lds[buf][0], g.act_a, g.M, i0, s * kStep, r_end);
+      store_tile<BR>(sb[which], lds[buf][1], g.act_b, g.N, j0, s * kStep, r_end);
+    }
   };
   const int ar = wr * 32 + (lane & 31), bc = wc * 32 + (lane & 31), kh = lane >> 5;
   auto step = [&](int which, int s, int cur) {  // `which`: the register stage that holds step s + 1
@@ -192,13 +244,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
 #pragma unroll 8
       for (int k = 0; k < kStep; ++k) csum += image_at<AR>(ia, tid, k);
     }
-    __syncthreads();
+    lds_barrier();  // LDS only: a __syncthreads also drains vmcnt, i.e. waits for the prefetched tiles at every k-step
   };
   issue(0, s_lo);
   to_lds(0, s_lo, 0);
   issue(0, s_lo + 1);
   issue(1, s_lo + 2);
-  __syncthreads();
+  lds_barrier();  // LDS only: a __syncthreads also drains vmcnt, i.e. waits for the prefetched tiles at every k-step
   for (int s = s_lo; s < s_hi; s += 2) {
     step(0, s, 0);
     if (s + 1 < s_hi) step(1, s + 1, 1);
@@ -415,13 +467,13 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs g) {
         for (int u = 0; u < 8; ++u) csum += __uint_as_float((unsigned)h[u] << 16) + __uint_as_float((unsigned)l[u] << 16);
       }
     }
-    __syncthreads();
+    lds_barrier();  // LDS only: a __syncthreads also drains vmcnt, i.e. waits for the prefetched tiles at every k-step
   };
   issue(0, s_lo);
   to_lds(0, s_lo, 0);
   issue(0, s_lo + 1);
   issue(1, s_lo + 2);
-  __syncthreads();
+  lds_barrier();  // LDS only: a __syncthreads also drains vmcnt, i.e. waits for the prefetched tiles at every k-step
   for (int s = s_lo; s < s_hi; s += 2) {
     step(0, s, 0);
     if (s + 1 < s_hi) step(1, s + 1, 1);
@@ -577,18 +629,21 @@ int gemm_launch(const MtrssmGemm* p, hipStream_t stream) {
       set_last_kernel("mtrssm::gemm_split_kernel<true, false>");
       hipLaunchKernelGGL((gemm_split_kernel<true, false>), grid, dim3(256), 0, stream, g);
     }
-  } else if (p->a_rmajor && p->b_rmajor) {
-    set_last_kernel("mtrssm::gemm_f32_kernel<true, true>");
-    hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, stream, g);
-  } else if (!p->a_rmajor && p->b_rmajor) {
-    set_last_kernel("mtrssm::gemm_f32_kernel<false, true>");
-    hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, stream, g);
-  } else if (!p->a_rmajor && !p->b_rmajor) {
-    set_last_kernel("mtrssm::gemm_f32_kernel<false, false>");
-    hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, stream, g);
   } else {
-    set_last_kernel("mtrssm::gemm_f32_kernel<true, false>");
-    hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, stream, g);
+    const int per_slice = (steps + splits - 1) / splits;
+    const bool fast = p->M % kTile == 0 && p->N % kTile == 0 && p->R % kStep == 0 && steps % splits == 0 && per_slice >= 1 &&
+                      (p->lda & 3) == 0 && (p->ldb & 3) == 0 && ((uintptr_t)p->A & 15) == 0 && ((uintptr_t)p->B & 15) == 0;
+#define MTRSSM_GEMM_LAUNCH(AR_, BR_)                                                                                  \
+  {                                                                                                                   \
+    set_last_kernel("mtrssm::gemm_f32_kernel<" #AR_ ", " #BR_ ">");                                                    \
+    if (fast) hipLaunchKernelGGL((gemm_f32_kernel<AR_, BR_, true>), grid, dim3(256), 0, stream, g);                   \
+    else hipLaunchKernelGGL((gemm_f32_kernel<AR_, BR_, false>), grid, dim3(256), 0, stream, g);                       \
+  }
+    if (p->a_rmajor && p->b_rmajor) MTRSSM_GEMM_LAUNCH(true, true)
+    else if (!p->a_rmajor && p->b_rmajor) MTRSSM_GEMM_LAUNCH(false, true)
+    else if (!p->a_rmajor && !p->b_rmajor) MTRSSM_GEMM_LAUNCH(false, false)
+    else MTRSSM_GEMM_LAUNCH(true, false)
+#undef MTRSSM_GEMM_LAUNCH
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
