@@ -328,7 +328,12 @@ def _conv_transposed_gather(y: Tensor, w: Tensor, bias: Tensor | None, stride: i
             nbytes=4.0 * (y.numel() + out.numel())), "mtrssm_convt_k4s2_thin")
         return out
     quad_fwd = kh == 4 and kw == 4 and actgrad_in is None and (o, c, hs * ws) in ((64, 32, 64), (32, 16, 256))  # noqa: PLR2004
-    quad_bwd = kh == 3 and kw == 3 and actgrad_in is not None and bias is None and (o, c, hs * ws) == (32, 16, 64)  # noqa: PLR2004
+    # The same kernel takes the backward-data of a Conv2d(k = 3, s = 2, p = 1) with its kernel zero-padded to 4 x 4 (the encoders'
+    # third conv: 4 x 60 -> 88 us).  OFF by default: the padded weight is a new tensor every step, which the step's pack plan
+    # cannot learn (it rebuilt its table -- a host-to-device copy -- every step, which also breaks graph capture) and the extra
+    # pad / pack launches ate the gain.  Needs a pack descriptor with "valid taps" instead of a padded copy.
+    quad_bwd = (CONVT_QUAD_BWD and kh == 3 and kw == 3 and actgrad_in is not None and bias is None  # noqa: PLR2004
+                and (o, c, hs * ws) == (32, 16, 64))
     if (stride == 2 and pad == 1 and (ho, wo) == (2 * hs, 2 * ws) and add_in is None and _MFMA_SPLIT == 2 and CONVT_QUAD  # noqa: PLR2004
             and (quad_fwd or quad_bwd)):
         # the decoders' ConvTranspose layers (and the backward-data of the encoders' third conv = the same transposed conv with
@@ -383,6 +388,7 @@ def _conv_transposed_gather(y: Tensor, w: Tensor, bias: Tensor | None, stride: i
 # never handed out twice and is freed by the allocator when the last view of it dies.
 TGATHER_THIN = os.environ.get("MTRSSM_TGATHER_THIN", "1") != "0"  # A/B switch of conv_tgather_thin_kernel
 CONVT_QUAD = os.environ.get("MTRSSM_CONVT_QUAD", "1") != "0"  # A/B switch of convt_quad_resident_kernel
+CONVT_QUAD_BWD = os.environ.get("MTRSSM_CONVT_QUAD_BWD", "0") == "1"  # its use for a k=3 s=2 conv's backward-data (see there)
 _ZERO_CHUNK_FLOATS = 2 << 20
 _ZERO_CHUNKS: dict[tuple, list] = {}
 

@@ -644,11 +644,12 @@ def test_one_pass_parity_class_kernels_match_the_per_class_launches(lib_loaded: 
 
     res = {}
     for one_pass in (False, True):
-        conv.CONVT_QUAD = conv.TGATHER_THIN = one_pass
+        conv.CONVT_QUAD = conv.TGATHER_THIN = conv.CONVT_QUAD_BWD = one_pass  # (the backward-data use is off by default)
         try:
             res[one_pass] = run()
         finally:
             conv.CONVT_QUAD = conv.TGATHER_THIN = True
+            conv.CONVT_QUAD_BWD = False
     for i, (a, b) in enumerate(zip(res[True], res[False], strict=True)):
         np.testing.assert_allclose(_np(a), _np(b), rtol=2e-5, atol=2e-6 * float(b.abs().max()), err_msg=str(i))
 
