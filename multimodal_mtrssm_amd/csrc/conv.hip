@@ -23,6 +23,10 @@
 //
 // The weight-gradient kernel is the transposed problem: dWp[co][tap][c] += sum_pixels A[co][pix] G[pix][c],
 // reduction over all N*H*W pixels split across workgroups, partial tiles combined with fp32 atomics.
+#include <mutex>
+#include <unordered_map>
+#include <utility>
+
 #include "scan_common.h"
 
 namespace mtrssm {
@@ -652,6 +656,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_gather_gemm_patch_kernel(
 }  // namespace mtrssm
 #include "conv_split.h"
 #include "conv_resident.h"
+#include "conv_wgrad_resident.h"
 namespace mtrssm {
 
 // ------------------------------------------------------------------------------------------------
@@ -1457,6 +1462,39 @@ int conv_gather_gemm_pair_launch(const MtrssmConvGeom* ga, const float* srca, co
 int channel_sum_launch(const float* x, int N, int C, int HW, float* out, hipStream_t stream);
 
 // MTRSSM_NO_DIRECT_WGRAD=1: the patch-staged kernels for every layer (A/B runs of the register-direct 3x3 kernel)
+// MTRSSM_WGRAD_RESIDENT=0: the register-direct 3x3 kernel instead of the staged-input one (A/B runs)
+static bool wgrad_resident_enabled() {
+  static const bool on = [] { const char* e = getenv("MTRSSM_WGRAD_RESIDENT"); return !(e && e[0] == '0'); }();
+  return on;
+}
+// MTRSSM_WGRAD_RESIDENT_C32=1: also the 32-channel input layer (measured slower there than the register-direct kernel: 104 vs 97 us)
+static bool wgrad_resident_c32() {
+  static const bool on = [] { const char* e = getenv("MTRSSM_WGRAD_RESIDENT_C32"); return e && e[0] == '1'; }();
+  return on;
+}
+// MTRSSM_WGRAD_PARTIALS=0: the staged-input kernel adds its tiles to dwp by atomics instead of storing partial sets
+static bool wgrad_partials_enabled() {
+  static const bool on = [] { const char* e = getenv("MTRSSM_WGRAD_PARTIALS"); return !(e && e[0] == '0'); }();
+  return on;
+}
+// Scratch for the partial tile sets of conv3x3_wgrad_resident_kernel: one buffer per stream (launches of a stream reuse it
+// in order), grown on demand, kept for the life of the process (~38 MB at the bench shapes).  NULL when it cannot be
+// provided -- the stream is being captured and the buffer is not there yet, or the allocation fails -- and the caller
+// falls back to atomics.
+static float* wgrad_scratch(hipStream_t stream, size_t bytes) {
+  static std::mutex mu;
+  static std::unordered_map<hipStream_t, std::pair<float*, size_t>> tab;
+  std::lock_guard<std::mutex> lk(mu);
+  auto& e = tab[stream];
+  if (e.second >= bytes) return e.first;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
+  float* p = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&p), bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  if (e.first) (void)hipFree(e.first);  // waits for the device: queued launches that read the old buffer are done
+  e = {p, bytes};
+  return p;
+}
 static bool no_direct_wgrad() {
   static const bool off = getenv("MTRSSM_NO_DIRECT_WGRAD") != nullptr;
   return off;
@@ -1488,6 +1526,49 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
     else if (sp == 2) hipLaunchKernelGGL((conv1x1_weight_grad_split_kernel<2>), grid, block, 0, stream, *g, a, src, pre_act_a, dwp, dbias, tiles_ci, per);
     else hipLaunchKernelGGL((conv1x1_weight_grad_split_kernel<1>), grid, block, 0, stream, *g, a, src, pre_act_a, dwp, dbias, tiles_ci, per);
     return launched("conv_weight_grad(1x1 split)");
+  }
+  if ((g->mfma_split == 1 || g->mfma_split == 2) && g->KH == 3 && g->KW == 3 && g->SS == 1 && g->TS == 1 && g->OFFY == -1 && g->OFFX == -1 &&
+      g->C2 == 0 && g->Hs == g->Hq && g->Ws == g->Wq && (g->Wq == 8 || g->Wq == 4) && g->Hq * g->Wq == 64 && (g->C == 64 || (g->C == 32 && wgrad_resident_c32())) &&
+      g->Cout % 64 == 0 && g->Cout <= 65535 * 64 && g->Cpad >= g->C && !pre_act_a &&
+      (g->act == MTRSSM_ACT_IDENTITY || g->act == MTRSSM_ACT_ELU || g->act == MTRSSM_ACT_RELU) && !((uintptr_t)a & 15) &&
+      !((uintptr_t)src & 15) && !((uintptr_t)dwp & 15) && wgrad_resident_enabled() && !no_direct_wgrad()) {
+    // 3x3 layers of the residual stacks on 64-pixel planes: both operands staged once per frame (conv_wgrad_resident.h)
+    const int cogroups = g->Cout / 64;
+    int wgs = (g->C == 64 ? cu_count() : 2 * cu_count()) / cogroups;  // one wave per SIMD over the chip
+    if (wgs < 1) wgs = 1;
+    if (wgs > g->N) wgs = g->N;
+    const int per = (g->N + wgs - 1) / wgs;
+    const dim3 grid((unsigned)((g->N + per - 1) / per), cogroups);
+    const size_t set_floats = (size_t)wgres_set_floats(g->C);
+    float* const part = wgrad_partials_enabled() ? wgrad_scratch(stream, (size_t)grid.x * cogroups * set_floats * sizeof(float)) : nullptr;
+#define MTRSSM_WGRES_LAUNCH(SP_, C_, W_)                                                                                         \
+  {                                                                                                                             \
+    static bool attr_done = false; /* once per instantiation: never while another stream may be running the kernel */       \
+    constexpr int lds_b = wgres_lds_bytes<SP_, C_, W_>();                                                                       \
+    if (!attr_done) {                                                                                                           \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_resident_kernel<SP_, C_, W_>),                       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);                                             \
+      attr_done = true;                                                                                                         \
+    }                                                                                                                           \
+    set_last_kernel("mtrssm::conv3x3_wgrad_resident_kernel<" #SP_ ", " #C_ ", " #W_ ">");                                        \
+    hipLaunchKernelGGL((conv3x3_wgrad_resident_kernel<SP_, C_, W_>), grid, dim3(64 * 2 * (C_ / 32)), lds_b, stream, *g, a, src,  \
+                       dwp, part, dbias, per);                                                                                  \
+  }
+    const int sp = g->mfma_split;
+    if (g->C == 64) {
+      if (g->Wq == 8) { if (sp == 2) MTRSSM_WGRES_LAUNCH(2, 64, 8) else MTRSSM_WGRES_LAUNCH(1, 64, 8) }
+      else { if (sp == 2) MTRSSM_WGRES_LAUNCH(2, 64, 4) else MTRSSM_WGRES_LAUNCH(1, 64, 4) }
+    } else {
+      if (g->Wq == 8) { if (sp == 2) MTRSSM_WGRES_LAUNCH(2, 32, 8) else MTRSSM_WGRES_LAUNCH(1, 32, 8) }
+      else { if (sp == 2) MTRSSM_WGRES_LAUNCH(2, 32, 4) else MTRSSM_WGRES_LAUNCH(1, 32, 4) }
+    }
+#undef MTRSSM_WGRES_LAUNCH
+    if (part) {
+      const dim3 rgrid((unsigned)(set_floats / 4 / 16), cogroups);
+      if (g->C == 64) hipLaunchKernelGGL(wgrad_reduce_partials_kernel<64>, rgrid, dim3(256), 0, stream, reinterpret_cast<const float4*>(part), (int)grid.x, g->Cpad, dwp);
+      else hipLaunchKernelGGL(wgrad_reduce_partials_kernel<32>, rgrid, dim3(256), 0, stream, reinterpret_cast<const float4*>(part), (int)grid.x, g->Cpad, dwp);
+    }
+    return launched("conv_weight_grad(3x3 resident)");
   }
   if (g->mfma_split >= 1 && g->KH == 3 && g->KW == 3 && g->SS == 1 && g->TS == 1 && g->OFFY == -1 && g->OFFX == -1 && g->C2 == 0 &&
       g->Hs == g->Hq && g->Ws == g->Wq && (g->Wq == 8 || g->Wq == 4) && (g->Hq * g->Wq) % 16 == 0 && g->C <= 64 && g->C >= 8 &&

@@ -1,0 +1,352 @@
+// Weight gradient of the 3x3 / stride 1 / pad 1 layers of the residual stacks on 64-pixel planes (8x8 vision, 16x4 audio)
+// with BOTH operands staged once per frame (included by conv.hip after conv_split.h).
+//
+//   dW[co][ty][tx][ci] = sum over frames n and pixels (y, x) of  a[n][co][y][x] * act(src)[n][ci][y + ty - 1][x + tx - 1]
+//
+// The register-direct kernel (conv_split.h: conv3x3_weight_grad_split_kernel) lets every lane load, activate and split its
+// own operands: each src element is fetched 2 (co tiles) x 3 (window rows) times by 16-byte loads that touch 32 cache lines
+// per instruction and is converted as often, each `a` element twice -- the kernel is VALU-bound (about 75 % of its issue
+// slots are conversions), and its 9.4 M fp32 atomics alone take ~60 us.  Here a workgroup owns a run of frames and
+//   * loads every frame of `src` and of `a` ONCE, coalesced (consecutive lanes = consecutive 16 bytes), activates / splits
+//     it once and writes it to LDS: `a` as a plain [co][pixel] bf16 image, src as THREE column-shifted copies (tx = 0, 1,
+//     2; zero where the shift leaves the row) of a channel-major image with a zero halo row between consecutive planes:
+//     the B operand of tap (ty, tx) is then one aligned 16-byte read of copy tx at row offset ty -- no selects, no per-tap
+//     conversion;
+//   * double-buffers those images: frame n + 1 is converted (VALU + ds_write_b64) while the MFMAs of frame n run, its
+//     raw values requested a whole frame ahead, so no HBM latency is exposed;
+//   * gives each wave nine accumulator tiles chosen so that it reads five taps instead of nine: the two waves of a ci tile
+//     hold {co tile 0: taps 0-4, co tile 1: taps 0-3} and {co tile 1: taps 4-8, co tile 0: taps 5-8};
+//   * writes its partial tiles with plain 16-byte stores, in accumulator order, to a scratch slice of its own (`part`),
+//     summed and scattered into dwp by wgrad_reduce_partials_kernel right behind it in the stream: no atomics, run-to-run
+//     deterministic.  With part == NULL (no scratch: first call inside a stream capture, or MTRSSM_WGRAD_PARTIALS=0) the
+//     tiles leave by fp32 atomics in the dwp layout [co][tap][Cpad], as in the other kernels.
+// One barrier per frame.
+//
+// LDS images: src piece / copy [C][H + 1 rows][W] bf16 -- row 0 of every plane is the zero halo, shared with the plane
+// above (the copy ends with one more zero row); `a` piece [64][64 pixels + 8].  Both pitches are an odd number of 16-byte
+// (W = 4: 8-byte, reads are two ds_read_b64 halves) slots, so the 32 channels one read covers fall on different banks.
+#pragma once
+
+namespace mtrssm {
+
+template <int W>
+__host__ __device__ constexpr int wgres_pitch() { return (64 / W + 1) * 2 * W; }  // 144 (W = 8), 136 (W = 4)
+constexpr int kWgresAPitch = 144;  // bytes per co row of the `a` image: 64 bf16 + 16
+template <int SPLIT, int C, int W>
+__host__ __device__ constexpr int wgres_xbuf_bytes() { return SPLIT * 3 * C * wgres_pitch<W>() + 16; }
+template <int SPLIT>
+__host__ __device__ constexpr int wgres_abuf_bytes() { return SPLIT * 64 * kWgresAPitch; }
+template <int SPLIT, int C, int W>
+__host__ __device__ constexpr int wgres_lds_bytes() { return 2 * (wgres_xbuf_bytes<SPLIT, C, W>() + wgres_abuf_bytes<SPLIT>()); }
+// floats of one workgroup's partial tile set: its waves' nine 32x32 tiles
+__host__ __device__ constexpr int wgres_set_floats(int c) { return 2 * (c / 32) * 9 * 1024; }
+
+using wg_bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using wg_f32x2 = __attribute__((ext_vector_type(2))) float;
+using wg_f32x4 = __attribute__((ext_vector_type(4))) float;  // a register quadruple inline asm can name (float4 is a struct)
+// two values -> packed bf16 pieces (round to nearest even, as split_bf16): d[s] = piece s of (f0 low half, f1 high half)
+template <int SPLIT>
+__device__ __forceinline__ void wg_split_pair(const float f0, const float f1, unsigned (&d)[SPLIT]) {
+  d[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(wg_f32x2{f0, f1}, wg_bf16x2));
+  if constexpr (SPLIT >= 2) {
+    const float r0 = f0 - __builtin_bit_cast(float, d[0] << 16), r1 = f1 - __builtin_bit_cast(float, d[0] & 0xffff0000u);  // exact
+    d[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(wg_f32x2{r0, r1}, wg_bf16x2));
+  }
+}
+
+template <int SPLIT, int C, int W>
+__global__ __launch_bounds__(64 * 2 * (C / 32), 1) void conv3x3_wgrad_resident_kernel(
+    const MtrssmConvGeom g, const float* __restrict__ a, const float* __restrict__ src, float* __restrict__ dwp,
+    float* __restrict__ part, float* __restrict__ dbias, const int frames_per_wg) {
+  static_assert(SPLIT == 1 || SPLIT == 2, "one or two bf16 pieces");
+  constexpr int NW = 2 * (C / 32), NT = 64 * NW;
+  constexpr int RB = 2 * W;  // bytes per image row
+  constexpr int PITCH = wgres_pitch<W>(), COPYB = C * PITCH, XBUFB = wgres_xbuf_bytes<SPLIT, C, W>();
+  constexpr int APIECEB = 64 * kWgresAPitch, ABUFB = wgres_abuf_bytes<SPLIT>();
+  constexpr int XI = 4, AI = 1024 / NT;  // float4 items per thread and frame: src (C * 16 = 4 NT), a (64 co * 16)
+  extern __shared__ __attribute__((aligned(16))) unsigned char wgres_lds[];
+  unsigned char* const lds = wgres_lds;           // [src image 0][src image 1][a image 0][a image 1]
+  unsigned char* const lds_a = wgres_lds + 2 * XBUFB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int il = lane & 31, kl = lane >> 5;
+  const int tci = wave >> 1, half = wave & 1;
+  const int n0 = blockIdx.x * frames_per_wg;
+  const int n1 = n0 + frames_per_wg < g.N ? n0 + frames_per_wg : g.N;
+  if (n0 >= n1) return;  // whole workgroup
+  const int nlast = n1 - 1;
+  const int cob = blockIdx.y * 64;
+  // development aid (tools/wgrad_probe.py): cycle stamps of workgroup 0 and of the middle workgroup
+  unsigned long long* const prof = (tid == 0 && blockIdx.y == 0 && g_res_prof) ? (blockIdx.x == 0 ? g_res_prof + 32 : (blockIdx.x == gridDim.x / 2 ? g_res_prof + 40 : nullptr)) : nullptr;
+  if (prof) prof[0] = __builtin_readcyclecounter();
+
+  // activation switches as lane-uniform selects (no branch inside the MFMA loop: a branch ends a scheduling region)
+  const bool act_elu = g.act == MTRSSM_ACT_ELU, act_relu = g.act == MTRSSM_ACT_RELU, pre = g.pre_act != 0;
+  auto act_sel = [&](float x) __attribute__((always_inline)) {
+    float e = __expf(x) - 1.f;
+    asm volatile("" : "+v"(e));  // computed unconditionally: the compiler would branch around the exponential
+    const float neg = act_elu ? e : (act_relu ? 0.f : x);
+    return (x > 0.f || !pre) ? x : neg;
+  };
+
+  // ---- zero everything once: the halo rows are never written again
+  for (int o = tid * 16; o < wgres_lds_bytes<SPLIT, C, W>(); o += NT * 16) *reinterpret_cast<uint4*>(lds + o) = make_uint4(0u, 0u, 0u, 0u);
+
+  // ---- staging: item j of a thread = float4 number tid + NT * j of the frame (of the workgroup's 64 co of it for `a`):
+  // 4 consecutive pixels of channel (tid >> 4) + j * NT / 16
+  const float4* const xsrc = reinterpret_cast<const float4*>(src) + tid;
+  const float4* const asrc = reinterpret_cast<const float4*>(a + (size_t)cob * 64) + tid;
+  const size_t xfr = (size_t)C * 16, afr = (size_t)g.Cout * 16;  // float4 per frame
+  const int xi = tid & 15;
+  const int xrow = (xi * 4) / W, xcol = (xi * 4) % W;
+  const unsigned wofs = (unsigned)((tid >> 4) * PITCH + (xrow + 1) * RB + xcol * 2);
+  const unsigned wofs_a = (unsigned)((tid >> 4) * kWgresAPitch + xi * 8);
+  const bool first_in_row = xcol == 0, last_in_row = xcol + 4 == W;
+  auto stage_x = [&](const float4 v, const int j, const unsigned bufoff) __attribute__((always_inline)) {
+    unsigned d0[SPLIT], d1[SPLIT];
+    wg_split_pair<SPLIT>(act_sel(v.x), act_sel(v.y), d0);
+    wg_split_pair<SPLIT>(act_sel(v.z), act_sel(v.w), d1);
+#pragma unroll
+    for (int p = 0; p < SPLIT; ++p) {
+      unsigned prev = 0u, next = 0u;  // the neighbouring items' pixels next to this one, zero past the row ends
+      if (W == 8) {
+        // lanes 2k / 2k + 1 hold the two halves of one row: quad_perm [0,0,2,2] hands the even lane's value to the odd
+        // one, [1,1,3,3] the odd lane's to the even one
+        prev = (unsigned)__builtin_amdgcn_update_dpp(0, (int)d1[p], 0xA0, 0xF, 0xF, false);
+        next = (unsigned)__builtin_amdgcn_update_dpp(0, (int)d0[p], 0xF5, 0xF, 0xF, false);
+        prev = first_in_row ? 0u : prev;
+        next = last_in_row ? 0u : next;
+      }
+      const unsigned mid = __builtin_amdgcn_alignbit(d1[p], d0[p], 16);  // pixels 1, 2
+      const uint2 c0 = make_uint2(__builtin_amdgcn_alignbit(d0[p], prev, 16), mid);   // S0[x] = X[x - 1]
+      const uint2 c1 = make_uint2(d0[p], d1[p]);
+      const uint2 c2 = make_uint2(mid, __builtin_amdgcn_alignbit(next, d1[p], 16));   // S2[x] = X[x + 1]
+      unsigned char* const wp = lds + bufoff + wofs + (unsigned)(j * (NT / 16) * PITCH) + (unsigned)(p * 3 * COPYB);
+      *reinterpret_cast<uint2*>(wp) = c0;
+      *reinterpret_cast<uint2*>(wp + COPYB) = c1;
+      *reinterpret_cast<uint2*>(wp + 2 * COPYB) = c2;
+    }
+  };
+  float bsum[AI];  // bias gradient: this thread's share of channel (tid >> 4) + j * NT / 16
+#pragma unroll
+  for (int j = 0; j < AI; ++j) bsum[j] = 0.f;
+  auto stage_a = [&](const float4 v, const int j, const unsigned bufoff, const float keep) __attribute__((always_inline)) {
+    bsum[j] += keep * ((v.x + v.y) + (v.z + v.w));
+    unsigned d0[SPLIT], d1[SPLIT];
+    wg_split_pair<SPLIT>(v.x, v.y, d0);
+    wg_split_pair<SPLIT>(v.z, v.w, d1);
+#pragma unroll
+    for (int p = 0; p < SPLIT; ++p)
+      *reinterpret_cast<uint2*>(lds_a + bufoff + wofs_a + (unsigned)(j * (NT / 16) * kWgresAPitch) + (unsigned)(p * APIECEB)) = make_uint2(d0[p], d1[p]);
+  };
+
+  // ---- the wave's tiles: nine accumulators = (coA, b[0..4]) and (coB, b[0..3]); b[k] = tap (half ? 8 - k : k)
+  const int coA = half, coB = half ^ 1;  // 32-channel tile of the co group
+  unsigned tapoff[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int tap = half ? 8 - k : k;
+    tapoff[k] = (unsigned)((tap % 3) * COPYB + (tap / 3) * RB);
+  }
+  const unsigned lane_b = (unsigned)((tci * 32 + il) * PITCH + kl * 16);
+  const unsigned lane_a0 = (unsigned)((coA * 32 + il) * kWgresAPitch + kl * 16), lane_a1 = (unsigned)((coB * 32 + il) * kWgresAPitch + kl * 16);
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  u32x4 qa[2][2][SPLIT];  // [set][co tile][piece]
+  u32x4 qb[2][5][SPLIT];  // [set][tap slot][piece]
+  auto operands = [&](const int q, const int set, const unsigned xoff, const unsigned aoff) __attribute__((always_inline)) {
+#pragma unroll
+    for (int p = 0; p < SPLIT; ++p) {
+      qa[set][0][p] = *reinterpret_cast<const u32x4*>(lds_a + aoff + lane_a0 + (unsigned)(p * APIECEB + q * 32));
+      qa[set][1][p] = *reinterpret_cast<const u32x4*>(lds_a + aoff + lane_a1 + (unsigned)(p * APIECEB + q * 32));
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+#pragma unroll
+      for (int p = 0; p < SPLIT; ++p) {
+        const unsigned char* rp = lds + xoff + lane_b + tapoff[k] + (unsigned)(p * 3 * COPYB + q * 32);
+        if (W == 8) {
+          qb[set][k][p] = *reinterpret_cast<const u32x4*>(rp);
+        } else {  // 8-byte aligned: two halves
+          const uint2 lo = *reinterpret_cast<const uint2*>(rp), hi = *reinterpret_cast<const uint2*>(rp + 8);
+          qb[set][k][p] = u32x4{lo.x, lo.y, hi.x, hi.y};
+        }
+      }
+  };
+  auto mfmas = [&](const int set) __attribute__((always_inline)) {
+    // product-major: consecutive MFMAs go to different accumulator tiles, so none waits for its predecessor
+#pragma unroll
+    for (int ord = SPLIT - 1; ord >= 0; --ord)
+#pragma unroll
+      for (int sa = 0; sa <= ord; ++sa)
+#pragma unroll
+        for (int j = 0; j < 9; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, qa[set][j < 5 ? 0 : 1][sa]),
+                                                           __builtin_bit_cast(bf16x8, qb[set][j < 5 ? j : j - 5][ord - sa]), acc[j], 0, 0, 0);
+  };
+
+  // ---- raw frames: two register sets.  Set s is requested early in a frame and staged under the NEXT one, so every use
+  // is at least three k-steps behind its request, and the requests of a frame follow its first staged item: whatever
+  // counter value the compiler waits for there, nothing younger than a frame is in flight.
+  // The requests are inline asm: the compiler sinks its own loads to their uses, a frame later (and then waits for them
+  // there).  As volatile asm they keep their place among the LDS operations; raw_wait is the matching counter wait.
+  constexpr int NI = XI + AI;
+  wg_f32x4 raw[2][NI];  // [set][x items, a items]
+  auto raw_load = [&](const int rs, const int n) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      const float4* const ptr = it < XI ? xsrc + (size_t)n * xfr + NT * it : asrc + (size_t)n * afr + NT * (it - XI);
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(raw[rs][it]) : "v"(ptr));
+    }
+  };
+  auto raw_wait = [&](const int rs) __attribute__((always_inline)) {  // every request so far has landed
+    if constexpr (NI == 8) {
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[rs][0]), "+v"(raw[rs][1]), "+v"(raw[rs][2]), "+v"(raw[rs][3]), "+v"(raw[rs][4]), "+v"(raw[rs][5]), "+v"(raw[rs][6]), "+v"(raw[rs][7]));
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[rs][0]), "+v"(raw[rs][1]), "+v"(raw[rs][2]), "+v"(raw[rs][3]), "+v"(raw[rs][4]), "+v"(raw[rs][5]), "+v"(raw[rs][6]), "+v"(raw[rs][7]), "+v"(raw[rs][8]), "+v"(raw[rs][9]), "+v"(raw[rs][10]), "+v"(raw[rs][11]));
+    }
+  };
+  auto stage = [&](const int rs, const int it, const unsigned xo, const unsigned ao, const float keep) __attribute__((always_inline)) {
+    const float4 v = make_float4(raw[rs][it].x, raw[rs][it].y, raw[rs][it].z, raw[rs][it].w);
+    if (it < XI) stage_x(v, it, xo); else stage_a(v, it - XI, ao, keep);
+  };
+  // staging order within a frame: x0 a0 x1 a1 x2 a2 x3 a3 [a4 ...]; item number of the k-th staged one
+  auto item_of = [](const int k) __attribute__((always_inline)) { return k < 8 ? ((k & 1) ? XI + (k >> 1) : (k >> 1)) : XI + k - 4; };
+
+  // ---- prologue: frame n0 staged into images 0, frame n0 + 1 requested into set 1
+  raw_load(0, n0);
+  raw_wait(0);
+  raw_load(1, n0 + 1 < nlast ? n0 + 1 : nlast);
+  lds_barrier();  // the zeroes are in place
+#pragma unroll
+  for (int k = 0; k < NI; ++k) stage(0, k, 0u, 0u, 1.f);
+  lds_barrier();  // images 0 complete
+  operands(0, 0, 0u, 0u);
+  if (prof) prof[1] = __builtin_readcyclecounter();
+
+  // One frame: par = parity of the frame within the workgroup's run (a literal at the call sites: image offsets and raw
+  // sets are compile-time).  Images par hold frame n; raw set par ^ 1 holds frame n + 1, staged into images par ^ 1 under
+  // k-steps 0-2; raw set par is free and receives frame n + 2.
+  auto frame = [&](const int n, const int par) __attribute__((always_inline)) {
+    const unsigned xoff = par ? (unsigned)XBUFB : 0u, xoth = (unsigned)XBUFB - xoff;
+    const unsigned aoff = par ? (unsigned)ABUFB : 0u, aoth = (unsigned)ABUFB - aoff;
+    const float keep = n + 1 < n1 ? 1.f : 0.f;  // the frame staged under the last one is a duplicate: keep it out of the bias sum
+    const int nn2 = n + 2 < nlast ? n + 2 : nlast;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int set = q & 1;
+      // operands of the NEXT k-step first: their LDS latency passes under this step's MFMAs
+      if (q < 3) {
+        operands(q + 1, set ^ 1, xoff, aoff);
+      } else {
+        lds_barrier();  // every wave has read these images and written the other ones
+        operands(0, set ^ 1, xoth, aoth);
+      }
+      mfmas(set);
+      if (q < 3) {
+#pragma unroll
+        for (int k = q * NI / 3; k < (q + 1) * NI / 3; ++k) {
+          if (k == 0) raw_wait(par ^ 1);  // requested a frame ago, nothing younger in flight
+          stage(par ^ 1, item_of(k), xoth, aoth, keep);
+          if (k == 0) raw_load(par, nn2);
+        }
+      }
+    }
+  };
+#pragma unroll 1
+  for (int n = n0; n < n1; n += 2) {
+    frame(n, 0);
+    if (n + 1 < n1) frame(n + 1, 1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped requests of the last frame
+  if (prof) prof[2] = __builtin_readcyclecounter();
+
+  if (part) {
+    // accumulator order: float4 number ((wave * 9 + j) * 4 + r / 4) * 64 + lane of this workgroup's set -- every store
+    // instruction writes 1 KiB in a row (wgrad_reduce_partials_kernel maps it back to dwp)
+    float4* const ps = reinterpret_cast<float4*>(part) + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NW * 9 * 4 * 64) + (size_t)wave * (9 * 4 * 64) + lane;
+#pragma unroll
+    for (int j = 0; j < 9; ++j)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) ps[(j * 4 + gq) * 64] = make_float4(acc[j][4 * gq], acc[j][4 * gq + 1], acc[j][4 * gq + 2], acc[j][4 * gq + 3]);
+  } else {
+    const int ci = tci * 32 + il;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+      const int k = j < 5 ? j : j - 5;
+      const int tap = half ? 8 - k : k;
+      const int cot = cob + (j < 5 ? coA : coB) * 32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = cot + (r & 3) + 8 * (r >> 2) + 4 * kl;
+        atomicAdd(&dwp[((size_t)row * 9 + tap) * g.Cpad + ci], acc[j][r]);
+      }
+    }
+  }
+  if (dbias != nullptr) {
+#pragma unroll
+    for (int j = 0; j < AI; ++j) {  // the 16 lanes of a DPP row share a channel
+      float v = bsum[j];
+      v += dpp_move<0xB1, 0xF>(0.f, v);   // quad_perm [1, 0, 3, 2]
+      v += dpp_move<0x4E, 0xF>(0.f, v);   // quad_perm [2, 3, 0, 1]
+      v += dpp_move<0x141, 0xF>(0.f, v);  // row_half_mirror
+      v += dpp_move<0x140, 0xF>(0.f, v);  // row_mirror
+      if (xi == 0) atomicAdd(&dbias[cob + (tid >> 4) + j * (NT / 16)], v);
+    }
+  }
+  if (prof) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    prof[3] = __builtin_readcyclecounter();
+  }
+}
+
+// Sum of the S partial tile sets of every co group (part [cogroups][S][set floats], accumulator order) into dwp.  Thread =
+// one float4 of the set (rows r .. r + 3 of one accumulator column) x one of 16 slices of S, the slices met in LDS; 16
+// lanes read 256-byte runs.  dwp is read-modified-written without atomics: launches that accumulate into one dwp chunk
+// are ordered by their stream.
+template <int C>
+__global__ __launch_bounds__(256) void wgrad_reduce_partials_kernel(const float4* __restrict__ part, const int S, const int cpad,
+                                                                    float* __restrict__ dwp) {
+  constexpr int SET4 = wgres_set_floats(C) / 4;
+  __shared__ float4 red[16][16];
+  const int li = threadIdx.x & 15, sg = threadIdx.x >> 4;
+  const int f = blockIdx.x * 16 + li;  // host: grid.x * 16 == SET4
+  const float4* const p = part + (size_t)blockIdx.y * S * SET4 + f;
+  float4 acc4[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) acc4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  int s = sg;
+  for (; s + 48 < S; s += 64) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float4 v = p[(size_t)(s + 16 * u) * SET4];
+      acc4[u].x += v.x; acc4[u].y += v.y; acc4[u].z += v.z; acc4[u].w += v.w;
+    }
+  }
+  for (; s < S; s += 16) {
+    const float4 v = p[(size_t)s * SET4];
+    acc4[0].x += v.x; acc4[0].y += v.y; acc4[0].z += v.z; acc4[0].w += v.w;
+  }
+  red[sg][li] = make_float4((acc4[0].x + acc4[1].x) + (acc4[2].x + acc4[3].x), (acc4[0].y + acc4[1].y) + (acc4[2].y + acc4[3].y),
+                            (acc4[0].z + acc4[1].z) + (acc4[2].z + acc4[3].z), (acc4[0].w + acc4[1].w) + (acc4[2].w + acc4[3].w));
+  __syncthreads();
+  if (sg == 0) {
+    float4 t = red[0][li];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) { t.x += red[k][li].x; t.y += red[k][li].y; t.z += red[k][li].z; t.w += red[k][li].w; }
+    // f = ((wave * 9 + j) * 4 + gq) * 64 + lane  ->  rows cot + 8 gq + 4 kl + {0..3}, tap, ci (the kernel's tile assignment)
+    const int lane = f & 63, gq = (f >> 6) & 3, wj = f >> 8, j = wj % 9, wave = wj / 9;
+    const int il = lane & 31, kl = lane >> 5, tci = wave >> 1, half = wave & 1;
+    const int k = j < 5 ? j : j - 5, tap = half ? 8 - k : k;
+    const int row = blockIdx.y * 64 + (j < 5 ? half : half ^ 1) * 32 + 8 * gq + 4 * kl;
+    float* const o = dwp + ((size_t)row * 9 + tap) * cpad + tci * 32 + il;
+    const size_t rs = (size_t)9 * cpad;
+    o[0] += t.x; o[rs] += t.y; o[2 * rs] += t.z; o[3 * rs] += t.w;
+  }
+}
+
+}  // namespace mtrssm

@@ -450,6 +450,9 @@ CONV_CASES = [
     (5, 64, 4, 16, 128, 3, 1, 1, True, False),  # ... 4x16 plane
     (1300, 64, 8, 8, 64, 3, 1, 1, True, False), # ... more tiles than workgroups (650 on 256): the persistent loop, double-buffered images
     (7, 64, 8, 8, 64, 3, 1, 1, True, False),    # ... odd frame count: no whole tiles, the patch-staged kernel takes it
+    (1, 64, 8, 8, 64, 3, 1, 1, True, False),    # staged-operand weight gradient (conv3x3_wgrad_resident_kernel): ONE frame, one workgroup
+    (700, 64, 16, 4, 128, 3, 1, 1, True, False),  # ... three frames per workgroup (odd run), two co groups, 16x4 plane; 1300 above: six / five
+    (5, 64, 8, 8, 64, 3, 1, 1, False, False),   # ... no activation
 ]
 
 
