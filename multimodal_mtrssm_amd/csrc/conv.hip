@@ -1467,9 +1467,9 @@ static bool wgrad_resident_enabled() {
   static const bool on = [] { const char* e = getenv("MTRSSM_WGRAD_RESIDENT"); return !(e && e[0] == '0'); }();
   return on;
 }
-// MTRSSM_WGRAD_RESIDENT_C32=1: also the 32-channel input layer (measured slower there than the register-direct kernel: 104 vs 97 us)
+// MTRSSM_WGRAD_RESIDENT_C32=0: the 32-channel input layer on the register-direct kernel (A/B runs)
 static bool wgrad_resident_c32() {
-  static const bool on = [] { const char* e = getenv("MTRSSM_WGRAD_RESIDENT_C32"); return e && e[0] == '1'; }();
+  static const bool on = [] { const char* e = getenv("MTRSSM_WGRAD_RESIDENT_C32"); return !(e && e[0] == '0'); }();
   return on;
 }
 // MTRSSM_WGRAD_PARTIALS=0: the staged-input kernel adds its tiles to dwp by atomics instead of storing partial sets

@@ -8,22 +8,23 @@
 // per instruction and is converted as often, each `a` element twice -- the kernel is VALU-bound (about 75 % of its issue
 // slots are conversions), and its 9.4 M fp32 atomics alone take ~60 us.  Here a workgroup owns a run of frames and
 //   * loads every frame of `src` and of `a` ONCE, coalesced (consecutive lanes = consecutive 16 bytes), activates / splits
-//     it once and writes it to LDS: `a` as a plain [co][pixel] bf16 image, src as THREE column-shifted copies (tx = 0, 1,
-//     2; zero where the shift leaves the row) of a channel-major image with a zero halo row between consecutive planes:
-//     the B operand of tap (ty, tx) is then one aligned 16-byte read of copy tx at row offset ty -- no selects, no per-tap
-//     conversion;
+//     it once and writes it to LDS: `a` as a plain [co][pixel] bf16 image, src as a channel-major image with a zero halo
+//     row between consecutive planes: a row tap (ty) is a 16-byte read at row offset ty, the column taps (tx) are funnel
+//     shifts of that fragment in registers -- a lane's 8 pixels are whole plane rows, so the shifted row needs no
+//     neighbour (three column-shifted copies in LDS instead made the LDS pipe the bottleneck: 2300 of its cycles per
+//     frame against 3456 of MFMA work, and the two did not overlap);
 //   * double-buffers those images: frame n + 1 is converted (VALU + ds_write_b64) while the MFMAs of frame n run, its
 //     raw values requested a whole frame ahead, so no HBM latency is exposed;
-//   * gives each wave nine accumulator tiles chosen so that it reads five taps instead of nine: the two waves of a ci tile
-//     hold {co tile 0: taps 0-4, co tile 1: taps 0-3} and {co tile 1: taps 4-8, co tile 0: taps 5-8};
+//   * gives each wave nine accumulator tiles chosen so that it reads two image rows instead of three: the two waves of a
+//     ci tile hold {co tile 0: taps 0-4, co tile 1: taps 0-3} and {co tile 1: taps 4-8, co tile 0: taps 5-8};
 //   * writes its partial tiles with plain 16-byte stores, in accumulator order, to a scratch slice of its own (`part`),
 //     summed and scattered into dwp by wgrad_reduce_partials_kernel right behind it in the stream: no atomics, run-to-run
 //     deterministic.  With part == NULL (no scratch: first call inside a stream capture, or MTRSSM_WGRAD_PARTIALS=0) the
 //     tiles leave by fp32 atomics in the dwp layout [co][tap][Cpad], as in the other kernels.
 // One barrier per frame.
 //
-// LDS images: src piece / copy [C][H + 1 rows][W] bf16 -- row 0 of every plane is the zero halo, shared with the plane
-// above (the copy ends with one more zero row); `a` piece [64][64 pixels + 8].  Both pitches are an odd number of 16-byte
+// LDS images: src piece [C][H + 1 rows][W] bf16 -- row 0 of every plane is the zero halo, shared with the plane above (the
+// image ends with one more zero row); `a` piece [64][64 pixels + 8].  Both pitches are an odd number of 16-byte
 // (W = 4: 8-byte, reads are two ds_read_b64 halves) slots, so the 32 channels one read covers fall on different banks.
 #pragma once
 
@@ -33,7 +34,7 @@ template <int W>
 __host__ __device__ constexpr int wgres_pitch() { return (64 / W + 1) * 2 * W; }  // 144 (W = 8), 136 (W = 4)
 constexpr int kWgresAPitch = 144;  // bytes per co row of the `a` image: 64 bf16 + 16
 template <int SPLIT, int C, int W>
-__host__ __device__ constexpr int wgres_xbuf_bytes() { return SPLIT * 3 * C * wgres_pitch<W>() + 16; }
+__host__ __device__ constexpr int wgres_xbuf_bytes() { return SPLIT * C * wgres_pitch<W>() + 16; }
 template <int SPLIT>
 __host__ __device__ constexpr int wgres_abuf_bytes() { return SPLIT * 64 * kWgresAPitch; }
 template <int SPLIT, int C, int W>
@@ -100,31 +101,13 @@ __global__ __launch_bounds__(64 * 2 * (C / 32), 1) void conv3x3_wgrad_resident_k
   const int xrow = (xi * 4) / W, xcol = (xi * 4) % W;
   const unsigned wofs = (unsigned)((tid >> 4) * PITCH + (xrow + 1) * RB + xcol * 2);
   const unsigned wofs_a = (unsigned)((tid >> 4) * kWgresAPitch + xi * 8);
-  const bool first_in_row = xcol == 0, last_in_row = xcol + 4 == W;
   auto stage_x = [&](const float4 v, const int j, const unsigned bufoff) __attribute__((always_inline)) {
     unsigned d0[SPLIT], d1[SPLIT];
     wg_split_pair<SPLIT>(act_sel(v.x), act_sel(v.y), d0);
     wg_split_pair<SPLIT>(act_sel(v.z), act_sel(v.w), d1);
 #pragma unroll
-    for (int p = 0; p < SPLIT; ++p) {
-      unsigned prev = 0u, next = 0u;  // the neighbouring items' pixels next to this one, zero past the row ends
-      if (W == 8) {
-        // lanes 2k / 2k + 1 hold the two halves of one row: quad_perm [0,0,2,2] hands the even lane's value to the odd
-        // one, [1,1,3,3] the odd lane's to the even one
-        prev = (unsigned)__builtin_amdgcn_update_dpp(0, (int)d1[p], 0xA0, 0xF, 0xF, false);
-        next = (unsigned)__builtin_amdgcn_update_dpp(0, (int)d0[p], 0xF5, 0xF, 0xF, false);
-        prev = first_in_row ? 0u : prev;
-        next = last_in_row ? 0u : next;
-      }
-      const unsigned mid = __builtin_amdgcn_alignbit(d1[p], d0[p], 16);  // pixels 1, 2
-      const uint2 c0 = make_uint2(__builtin_amdgcn_alignbit(d0[p], prev, 16), mid);   // S0[x] = X[x - 1]
-      const uint2 c1 = make_uint2(d0[p], d1[p]);
-      const uint2 c2 = make_uint2(mid, __builtin_amdgcn_alignbit(next, d1[p], 16));   // S2[x] = X[x + 1]
-      unsigned char* const wp = lds + bufoff + wofs + (unsigned)(j * (NT / 16) * PITCH) + (unsigned)(p * 3 * COPYB);
-      *reinterpret_cast<uint2*>(wp) = c0;
-      *reinterpret_cast<uint2*>(wp + COPYB) = c1;
-      *reinterpret_cast<uint2*>(wp + 2 * COPYB) = c2;
-    }
+    for (int p = 0; p < SPLIT; ++p)
+      *reinterpret_cast<uint2*>(lds + bufoff + wofs + (unsigned)(j * (NT / 16) * PITCH) + (unsigned)(p * COPYB)) = make_uint2(d0[p], d1[p]);
   };
   float bsum[AI];  // bias gradient: this thread's share of channel (tid >> 4) + j * NT / 16
 #pragma unroll
@@ -139,16 +122,21 @@ __global__ __launch_bounds__(64 * 2 * (C / 32), 1) void conv3x3_wgrad_resident_k
       *reinterpret_cast<uint2*>(lds_a + bufoff + wofs_a + (unsigned)(j * (NT / 16) * kWgresAPitch) + (unsigned)(p * APIECEB)) = make_uint2(d0[p], d1[p]);
   };
 
-  // ---- the wave's tiles: nine accumulators = (coA, b[0..4]) and (coB, b[0..3]); b[k] = tap (half ? 8 - k : k)
+  // ---- the wave's tiles.  Its B operands come from TWO image rows per k-step, the outer one (ty = 0 for half 0, ty = 2
+  // for half 1) and the centre one (ty = 1); the column taps are funnel shifts of those rows in registers (a lane's 8
+  // pixels are whole plane rows, so a shifted row needs no neighbour).  Five B slots:
+  //   0: outer row, tx = 0    1: outer, tx = 1    2: outer, tx = 2    3: centre, tx = (half 0: 0, half 1: 2)    4: centre, tx = 1
+  // nine accumulators = (coA, slots 0-4) and (coB, slots 0-3); coA = co tile `half`: half 0 holds {co 0: taps 0-4, co 1: taps
+  // 0-3}, half 1 {co 1: taps 6 7 8 5 4, co 0: taps 6 7 8 5}.
   const int coA = half, coB = half ^ 1;  // 32-channel tile of the co group
-  unsigned tapoff[5];
-#pragma unroll
-  for (int k = 0; k < 5; ++k) {
-    const int tap = half ? 8 - k : k;
-    tapoff[k] = (unsigned)((tap % 3) * COPYB + (tap / 3) * RB);
-  }
+  const int tyo = half ? 2 : 0;
   const unsigned lane_b = (unsigned)((tci * 32 + il) * PITCH + kl * 16);
   const unsigned lane_a0 = (unsigned)((coA * 32 + il) * kWgresAPitch + kl * 16), lane_a1 = (unsigned)((coB * 32 + il) * kWgresAPitch + kl * 16);
+  // W = 8: a fragment is one 16-byte row, rows ty apart are 16 bytes apart.  W = 4: a fragment is two 8-byte rows starting
+  // at row ty: the outer one is 16-byte aligned, the centre one straddles -- it is put together from the outer fragment and
+  // one more 8-byte row (`ext`).
+  const unsigned outer_off = lane_b + (unsigned)(tyo * RB);
+  const unsigned ext_off = lane_b + (W == 8 ? 16u : (half ? 8u : 16u));
 
   f32x16 acc[9];
 #pragma unroll
@@ -157,27 +145,42 @@ __global__ __launch_bounds__(64 * 2 * (C / 32), 1) void conv3x3_wgrad_resident_k
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   u32x4 qa[2][2][SPLIT];  // [set][co tile][piece]
-  u32x4 qb[2][5][SPLIT];  // [set][tap slot][piece]
+  u32x4 ro[2][SPLIT], rc[2][SPLIT];  // [set][piece]: outer row fragment; centre row fragment (W = 4: .xy = the extra row)
   auto operands = [&](const int q, const int set, const unsigned xoff, const unsigned aoff) __attribute__((always_inline)) {
 #pragma unroll
     for (int p = 0; p < SPLIT; ++p) {
       qa[set][0][p] = *reinterpret_cast<const u32x4*>(lds_a + aoff + lane_a0 + (unsigned)(p * APIECEB + q * 32));
       qa[set][1][p] = *reinterpret_cast<const u32x4*>(lds_a + aoff + lane_a1 + (unsigned)(p * APIECEB + q * 32));
-    }
-#pragma unroll
-    for (int k = 0; k < 5; ++k)
-#pragma unroll
-      for (int p = 0; p < SPLIT; ++p) {
-        const unsigned char* rp = lds + xoff + lane_b + tapoff[k] + (unsigned)(p * 3 * COPYB + q * 32);
-        if (W == 8) {
-          qb[set][k][p] = *reinterpret_cast<const u32x4*>(rp);
-        } else {  // 8-byte aligned: two halves
-          const uint2 lo = *reinterpret_cast<const uint2*>(rp), hi = *reinterpret_cast<const uint2*>(rp + 8);
-          qb[set][k][p] = u32x4{lo.x, lo.y, hi.x, hi.y};
-        }
+      ro[set][p] = *reinterpret_cast<const u32x4*>(lds + xoff + outer_off + (unsigned)(p * COPYB + q * 32));
+      if (W == 8) {
+        rc[set][p] = *reinterpret_cast<const u32x4*>(lds + xoff + ext_off + (unsigned)(p * COPYB + q * 32));
+      } else {
+        const uint2 e = *reinterpret_cast<const uint2*>(lds + xoff + ext_off + (unsigned)(p * COPYB + q * 32));
+        rc[set][p] = u32x4{e.x, e.y, 0u, 0u};
       }
+    }
+  };
+  auto ab = [](const unsigned hi, const unsigned lo) __attribute__((always_inline)) { return __builtin_amdgcn_alignbit(hi, lo, 16); };
+  auto shr1 = [&](const u32x4 f) __attribute__((always_inline)) {  // pixel x <- x - 1, zero into every row's first pixel
+    return W == 8 ? u32x4{f.x << 16, ab(f.y, f.x), ab(f.z, f.y), ab(f.w, f.z)} : u32x4{f.x << 16, ab(f.y, f.x), f.z << 16, ab(f.w, f.z)};
+  };
+  auto shl1 = [&](const u32x4 f) __attribute__((always_inline)) {  // pixel x <- x + 1, zero into every row's last pixel
+    return W == 8 ? u32x4{ab(f.y, f.x), ab(f.z, f.y), ab(f.w, f.z), f.w >> 16} : u32x4{ab(f.y, f.x), f.y >> 16, ab(f.w, f.z), f.w >> 16};
   };
   auto mfmas = [&](const int set) __attribute__((always_inline)) {
+    u32x4 qb[5][SPLIT];
+#pragma unroll
+    for (int p = 0; p < SPLIT; ++p) {
+      const u32x4 o = ro[set][p];
+      u32x4 c = rc[set][p];
+      if (W == 4) c = half ? u32x4{c.x, c.y, o.x, o.y} : u32x4{o.z, o.w, c.x, c.y};
+      const u32x4 cl = shl1(c), cr = shr1(c);
+      qb[0][p] = shr1(o);
+      qb[1][p] = o;
+      qb[2][p] = shl1(o);
+      qb[3][p] = half ? cl : cr;
+      qb[4][p] = c;
+    }
     // product-major: consecutive MFMAs go to different accumulator tiles, so none waits for its predecessor
 #pragma unroll
     for (int ord = SPLIT - 1; ord >= 0; --ord)
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(64 * 2 * (C / 32), 1) void conv3x3_wgrad_resident_k
 #pragma unroll
         for (int j = 0; j < 9; ++j)
           acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, qa[set][j < 5 ? 0 : 1][sa]),
-                                                           __builtin_bit_cast(bf16x8, qb[set][j < 5 ? j : j - 5][ord - sa]), acc[j], 0, 0, 0);
+                                                           __builtin_bit_cast(bf16x8, qb[j < 5 ? j : j - 5][ord - sa]), acc[j], 0, 0, 0);
   };
 
   // ---- raw frames: two register sets.  Set s is requested early in a frame and staged under the NEXT one, so every use
@@ -278,7 +281,7 @@ __global__ __launch_bounds__(64 * 2 * (C / 32), 1) void conv3x3_wgrad_resident_k
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
       const int k = j < 5 ? j : j - 5;
-      const int tap = half ? 8 - k : k;
+      const int tap = k < 3 ? tyo * 3 + k : (k == 3 ? (half ? 5 : 3) : 4);
       const int cot = cob + (j < 5 ? coA : coB) * 32;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_partials_kernel(const float4
     // f = ((wave * 9 + j) * 4 + gq) * 64 + lane  ->  rows cot + 8 gq + 4 kl + {0..3}, tap, ci (the kernel's tile assignment)
     const int lane = f & 63, gq = (f >> 6) & 3, wj = f >> 8, j = wj % 9, wave = wj / 9;
     const int il = lane & 31, kl = lane >> 5, tci = wave >> 1, half = wave & 1;
-    const int k = j < 5 ? j : j - 5, tap = half ? 8 - k : k;
+    const int k = j < 5 ? j : j - 5, tap = k < 3 ? (half ? 6 : 0) + k : (k == 3 ? (half ? 5 : 3) : 4);
     const int row = blockIdx.y * 64 + (j < 5 ? half : half ^ 1) * 32 + 8 * gq + 4 * kl;
     float* const o = dwp + ((size_t)row * 9 + tap) * cpad + tci * 32 + il;
     const size_t rs = (size_t)9 * cpad;
