@@ -1472,6 +1472,11 @@ static bool wgrad_resident_c32() {
   static const bool on = [] { const char* e = getenv("MTRSSM_WGRAD_RESIDENT_C32"); return !(e && e[0] == '0'); }();
   return on;
 }
+// MTRSSM_WGRAD_1X1_STAGED=0: the register-direct 1x1 kernel instead of the staged one (A/B runs)
+static bool wgrad_1x1_staged_enabled() {
+  static const bool on = [] { const char* e = getenv("MTRSSM_WGRAD_1X1_STAGED"); return !(e && e[0] == '0'); }();
+  return on;
+}
 // MTRSSM_WGRAD_PARTIALS=0: the staged-input kernel adds its tiles to dwp by atomics instead of storing partial sets
 static bool wgrad_partials_enabled() {
   static const bool on = [] { const char* e = getenv("MTRSSM_WGRAD_PARTIALS"); return !(e && e[0] == '0'); }();
@@ -1509,6 +1514,42 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
   const long ptot = (long)g->N * g->Hq * g->Wq;
   const int taps = g->KH * g->KW;
   const int ctot = g->C + g->C2;
+  if ((g->mfma_split == 1 || g->mfma_split == 2) && taps == 1 && g->SS == 1 && g->OFFY == 0 && g->OFFX == 0 && g->C2 == 0 && g->Hs == g->Hq &&
+      g->Ws == g->Wq && g->Hq * g->Wq == 64 && (g->C == 64 || g->C == 128) && g->Cout % 64 == 0 && g->Cout <= 65535 * 64 && g->Cpad >= g->C &&
+      !pre_act_a && (g->act == MTRSSM_ACT_IDENTITY || g->act == MTRSSM_ACT_ELU || g->act == MTRSSM_ACT_RELU) && !((uintptr_t)a & 15) &&
+      !((uintptr_t)src & 15) && wgrad_1x1_staged_enabled()) {
+    // 1x1 layers of the residual stacks on 64-pixel planes: operands staged once per frame (conv_wgrad_resident.h)
+    const int cogroups = g->Cout / 64;
+    int wgs = cu_count() / cogroups;
+    if (wgs < 1) wgs = 1;
+    if (wgs > g->N) wgs = g->N;
+    const int per = (g->N + wgs - 1) / wgs;
+    const dim3 grid((unsigned)((g->N + per - 1) / per), cogroups);
+    float* const part = wgrad_partials_enabled() ? wgrad_scratch(stream, (size_t)grid.x * cogroups * kWg1x1SetFloats * sizeof(float)) : nullptr;
+#define MTRSSM_WG1_LAUNCH(SP_, C_)                                                                                              \
+  {                                                                                                                             \
+    static bool attr_done = false; /* once per instantiation: never while another stream may be running the kernel */       \
+    constexpr int lds_b = wg1x1_lds_bytes<SP_, C_>();                                                                           \
+    if (!attr_done) {                                                                                                           \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_wgrad_staged_kernel<SP_, C_>),                            \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);                                             \
+      attr_done = true;                                                                                                         \
+    }                                                                                                                           \
+    set_last_kernel("mtrssm::conv1x1_wgrad_staged_kernel<" #SP_ ", " #C_ ">");                                                  \
+    hipLaunchKernelGGL((conv1x1_wgrad_staged_kernel<SP_, C_>), grid, dim3(512), lds_b, stream, *g, a, src, dwp, part, dbias,    \
+                       per);                                                                                                    \
+  }
+    const int sp = g->mfma_split;
+    if (g->C == 64) { if (sp == 2) MTRSSM_WG1_LAUNCH(2, 64) else MTRSSM_WG1_LAUNCH(1, 64) }
+    else { if (sp == 2) MTRSSM_WG1_LAUNCH(2, 128) else MTRSSM_WG1_LAUNCH(1, 128) }
+#undef MTRSSM_WG1_LAUNCH
+    if (part) {
+      const dim3 rgrid((unsigned)(2 * (g->C / 32) * 256 / 16 + (dbias ? 1 : 0)), cogroups);  // + the bias block
+      if (g->C == 64) hipLaunchKernelGGL(wgrad_reduce_partials1x1_kernel<64>, rgrid, dim3(256), 0, stream, reinterpret_cast<const float4*>(part), (int)grid.x, g->Cpad, dwp, dbias);
+      else hipLaunchKernelGGL(wgrad_reduce_partials1x1_kernel<128>, rgrid, dim3(256), 0, stream, reinterpret_cast<const float4*>(part), (int)grid.x, g->Cpad, dwp, dbias);
+    }
+    return launched("conv_weight_grad(1x1 staged)");
+  }
   if (g->mfma_split >= 1 && taps == 1 && g->SS == 1 && g->OFFY == 0 && g->OFFX == 0 && g->C2 == 0 && g->Hs == g->Hq && g->Ws == g->Wq &&
       (g->Hq * g->Wq) % 16 == 0 && g->Cout <= 128 && g->C <= 128 && g->C >= 8 && !((uintptr_t)a & 15) && !((uintptr_t)src & 15) &&
       ptot < (1L << 31)) {
@@ -1564,9 +1605,9 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
     }
 #undef MTRSSM_WGRES_LAUNCH
     if (part) {
-      const dim3 rgrid((unsigned)(set_floats / 4 / 16), cogroups);
-      if (g->C == 64) hipLaunchKernelGGL(wgrad_reduce_partials_kernel<64>, rgrid, dim3(256), 0, stream, reinterpret_cast<const float4*>(part), (int)grid.x, g->Cpad, dwp);
-      else hipLaunchKernelGGL(wgrad_reduce_partials_kernel<32>, rgrid, dim3(256), 0, stream, reinterpret_cast<const float4*>(part), (int)grid.x, g->Cpad, dwp);
+      const dim3 rgrid((unsigned)(wgres_tile_floats(g->C) / 4 / 16 + (dbias ? 1 : 0)), cogroups);  // + the bias block
+      if (g->C == 64) hipLaunchKernelGGL(wgrad_reduce_partials_kernel<64>, rgrid, dim3(256), 0, stream, reinterpret_cast<const float4*>(part), (int)grid.x, g->Cpad, dwp, dbias);
+      else hipLaunchKernelGGL(wgrad_reduce_partials_kernel<32>, rgrid, dim3(256), 0, stream, reinterpret_cast<const float4*>(part), (int)grid.x, g->Cpad, dwp, dbias);
     }
     return launched("conv_weight_grad(3x3 resident)");
   }

@@ -40,7 +40,10 @@ __host__ __device__ constexpr int wgres_abuf_bytes() { return SPLIT * 64 * kWgre
 template <int SPLIT, int C, int W>
 __host__ __device__ constexpr int wgres_lds_bytes() { return 2 * (wgres_xbuf_bytes<SPLIT, C, W>() + wgres_abuf_bytes<SPLIT>()); }
 // floats of one workgroup's partial tile set: its waves' nine 32x32 tiles
-__host__ __device__ constexpr int wgres_set_floats(int c) { return 2 * (c / 32) * 9 * 1024; }
+__host__ __device__ constexpr int wgres_tile_floats(int c) { return 2 * (c / 32) * 9 * 1024; }
+// ... followed by the workgroup's 64 bias-gradient sums (256 workgroups adding to the same 64 addresses took 10-25 us)
+__host__ __device__ constexpr int wgres_set_floats(int c) { return wgres_tile_floats(c) + 64; }
+constexpr int kWg1x1SetFloats = 8 * 1024 + 64;  // conv1x1_wgrad_staged_kernel: 8 waves x one tile, + 64 bias sums
 
 using wg_bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
 using wg_f32x2 = __attribute__((ext_vector_type(2))) float;
@@ -271,7 +274,7 @@ __global__ __launch_bounds__(64 * 2 * (C / 32), 1) void conv3x3_wgrad_resident_k
   if (part) {
     // accumulator order: float4 number ((wave * 9 + j) * 4 + r / 4) * 64 + lane of this workgroup's set -- every store
     // instruction writes 1 KiB in a row (wgrad_reduce_partials_kernel maps it back to dwp)
-    float4* const ps = reinterpret_cast<float4*>(part) + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NW * 9 * 4 * 64) + (size_t)wave * (9 * 4 * 64) + lane;
+    float4* const ps = reinterpret_cast<float4*>(part) + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (wgres_set_floats(C) / 4) + (size_t)wave * (9 * 4 * 64) + lane;
 #pragma unroll
     for (int j = 0; j < 9; ++j)
 #pragma unroll
@@ -298,7 +301,11 @@ __global__ __launch_bounds__(64 * 2 * (C / 32), 1) void conv3x3_wgrad_resident_k
       v += dpp_move<0x4E, 0xF>(0.f, v);   // quad_perm [2, 3, 0, 1]
       v += dpp_move<0x141, 0xF>(0.f, v);  // row_half_mirror
       v += dpp_move<0x140, 0xF>(0.f, v);  // row_mirror
-      if (xi == 0) atomicAdd(&dbias[cob + (tid >> 4) + j * (NT / 16)], v);
+      if (xi == 0) {
+        const int ch = (tid >> 4) + j * (NT / 16);
+        if (part) part[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * wgres_set_floats(C) + wgres_tile_floats(C) + ch] = v;
+        else atomicAdd(&dbias[cob + ch], v);
+      }
     }
   }
   if (prof) {
@@ -313,11 +320,11 @@ __global__ __launch_bounds__(64 * 2 * (C / 32), 1) void conv3x3_wgrad_resident_k
 // are ordered by their stream.
 template <int C>
 __global__ __launch_bounds__(256) void wgrad_reduce_partials_kernel(const float4* __restrict__ part, const int S, const int cpad,
-                                                                    float* __restrict__ dwp) {
-  constexpr int SET4 = wgres_set_floats(C) / 4;
+                                                                    float* __restrict__ dwp, float* __restrict__ dbias) {
+  constexpr int SET4 = wgres_set_floats(C) / 4, TILE4 = wgres_tile_floats(C) / 4;
   __shared__ float4 red[16][16];
   const int li = threadIdx.x & 15, sg = threadIdx.x >> 4;
-  const int f = blockIdx.x * 16 + li;  // host: grid.x * 16 == SET4
+  const int f = blockIdx.x * 16 + li;  // host: grid.x * 16 == TILE4 (+ 16: the bias block, launched when dbias != NULL)
   const float4* const p = part + (size_t)blockIdx.y * S * SET4 + f;
   float4 acc4[4];
 #pragma unroll
@@ -341,6 +348,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_partials_kernel(const float4
     float4 t = red[0][li];
 #pragma unroll
     for (int k = 1; k < 16; ++k) { t.x += red[k][li].x; t.y += red[k][li].y; t.z += red[k][li].z; t.w += red[k][li].w; }
+    if (f >= TILE4) {  // block-uniform: the bias sums of channels 4 li .. 4 li + 3 of this co group
+      float* const o = dbias + blockIdx.y * 64 + 4 * (f - TILE4);
+      o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w;
+      return;
+    }
     // f = ((wave * 9 + j) * 4 + gq) * 64 + lane  ->  rows cot + 8 gq + 4 kl + {0..3}, tap, ci (the kernel's tile assignment)
     const int lane = f & 63, gq = (f >> 6) & 3, wj = f >> 8, j = wj % 9, wave = wj / 9;
     const int il = lane & 31, kl = lane >> 5, tci = wave >> 1, half = wave & 1;
@@ -349,6 +361,222 @@ __global__ __launch_bounds__(256) void wgrad_reduce_partials_kernel(const float4
     float* const o = dwp + ((size_t)row * 9 + tap) * cpad + tci * 32 + il;
     const size_t rs = (size_t)9 * cpad;
     o[0] += t.x; o[rs] += t.y; o[2 * rs] += t.z; o[3 * rs] += t.w;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of the 1x1 layers of the residual stacks on 64-pixel planes (64 -> 64 in the encoders, 128 -> 64 in the
+// decoders), operands staged once per frame as in conv3x3_wgrad_resident_kernel:
+//   dW[co][ci] = sum over frames n and pixels p of  a[n][co][p] * act(src)[n][ci][p]
+// The register-direct kernel (conv_split.h: conv1x1_weight_grad_split_kernel) converts every `a` element once per ci tile
+// and every src element once per co tile (2x - 4x) on one wave per SIMD, and a single wave issues a VALU instruction every
+// ~5 cycles (tools/micro/mfma_shadow.hip): it is conversion-bound at about half the HBM rate.  Here a workgroup of EIGHT
+// waves (two per SIMD issue twice the VALU instructions per cycle) owns a run of frames; every thread loads, activates
+// and splits its share of each frame exactly once (coalesced 16-byte loads, requested TWO frames ahead through three
+// register sets: one frame in flight per CU does not cover the HBM latency at this rate) and writes it to
+// double-buffered [channel][64 pixels + 8] bf16 images; the MFMA work is small (6 or 12 per wave and frame): wave w holds
+// tile w % NTILE and, with four tiles, half of the k-steps of every frame.  One barrier per frame; partial tiles stored
+// (32 KiB per workgroup) and summed by wgrad_reduce_partials1x1_kernel, or by fp32 atomics when part == NULL.
+// ------------------------------------------------------------------------------------------------
+template <int SPLIT, int C>
+__host__ __device__ constexpr int wg1x1_lds_bytes() { return 2 * SPLIT * (64 + C) * kWgresAPitch; }
+
+template <int SPLIT, int C>
+__global__ __launch_bounds__(512, 1) void conv1x1_wgrad_staged_kernel(
+    const MtrssmConvGeom g, const float* __restrict__ a, const float* __restrict__ src, float* __restrict__ dwp,
+    float* __restrict__ part, float* __restrict__ dbias, const int frames_per_wg) {
+  static_assert(SPLIT == 1 || SPLIT == 2, "one or two bf16 pieces");
+  static_assert(C == 64 || C == 128, "input channels");
+  constexpr int NT = 512, P = kWgresAPitch;
+  constexpr int XI = C * 16 / NT, AI = 2, NI = XI + AI;  // float4 items per thread and frame: src, a (64 co * 16)
+  constexpr int NTILE = 2 * (C / 32), KS = 8 / NTILE;    // tiles per co group; waves per tile (each 4 / KS k-steps of a frame)
+  constexpr int APB = 64 * P, XPB = C * P;               // bytes of one piece of the a / src image
+  constexpr int BUFB = SPLIT * (APB + XPB);              // one buffer: [a pieces][src pieces]
+  extern __shared__ __attribute__((aligned(16))) unsigned char wg1_lds[];
+  unsigned char* const lds = wg1_lds;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int il = lane & 31, kl = lane >> 5;
+  const int tile = wave % NTILE, kpart = wave / NTILE;
+  const int tco = tile & 1, tci = tile >> 1;
+  const int n0 = blockIdx.x * frames_per_wg;
+  const int n1 = n0 + frames_per_wg < g.N ? n0 + frames_per_wg : g.N;
+  if (n0 >= n1) return;  // whole workgroup
+  const int nlast = n1 - 1;
+  const int cob = blockIdx.y * 64;
+  unsigned long long* const prof = (tid == 0 && blockIdx.y == 0 && g_res_prof) ? (blockIdx.x == 0 ? g_res_prof + 32 : (blockIdx.x == gridDim.x / 2 ? g_res_prof + 40 : nullptr)) : nullptr;
+  if (prof) prof[0] = __builtin_readcyclecounter();
+
+  const bool act_elu = g.act == MTRSSM_ACT_ELU, act_relu = g.act == MTRSSM_ACT_RELU, pre = g.pre_act != 0;
+  auto act_sel = [&](float x) __attribute__((always_inline)) {
+    float e = __expf(x) - 1.f;
+    asm volatile("" : "+v"(e));  // computed unconditionally: the compiler would branch around the exponential
+    const float neg = act_elu ? e : (act_relu ? 0.f : x);
+    return (x > 0.f || !pre) ? x : neg;
+  };
+
+  // staging: item j = float4 number tid + 512 j of the frame: 4 consecutive pixels of channel (tid >> 4) + 32 j
+  const float4* const xsrc = reinterpret_cast<const float4*>(src) + tid;
+  const float4* const asrc = reinterpret_cast<const float4*>(a + (size_t)cob * 64) + tid;
+  const size_t xfr = (size_t)C * 16, afr = (size_t)g.Cout * 16;  // float4 per frame
+  const unsigned wofs = (unsigned)((tid >> 4) * P + (tid & 15) * 8);
+  float bsum[AI];
+#pragma unroll
+  for (int j = 0; j < AI; ++j) bsum[j] = 0.f;
+  wg_f32x4 raw[3][NI];  // [set][a items, x items]
+  auto raw_load = [&](const int rs, const int n) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      const float4* const ptr = it < AI ? asrc + (size_t)n * afr + NT * it : xsrc + (size_t)n * xfr + NT * (it - AI);
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(raw[rs][it]) : "v"(ptr));
+    }
+  };
+  auto raw_wait = [&](const int rs) __attribute__((always_inline)) {  // the two younger sets may still be in flight
+    if constexpr (NI == 4) asm volatile("s_waitcnt vmcnt(8)" : "+v"(raw[rs][0]), "+v"(raw[rs][1]), "+v"(raw[rs][2]), "+v"(raw[rs][3]));
+    else asm volatile("s_waitcnt vmcnt(12)" : "+v"(raw[rs][0]), "+v"(raw[rs][1]), "+v"(raw[rs][2]), "+v"(raw[rs][3]), "+v"(raw[rs][4]), "+v"(raw[rs][5]));
+  };
+  auto stage = [&](const int rs, const unsigned bufoff) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      const wg_f32x4 v = raw[rs][it];
+      unsigned d0[SPLIT], d1[SPLIT];
+      if (it < AI) {
+        bsum[it] += (v.x + v.y) + (v.z + v.w);
+        wg_split_pair<SPLIT>(v.x, v.y, d0);
+        wg_split_pair<SPLIT>(v.z, v.w, d1);
+      } else {
+        wg_split_pair<SPLIT>(act_sel(v.x), act_sel(v.y), d0);
+        wg_split_pair<SPLIT>(act_sel(v.z), act_sel(v.w), d1);
+      }
+      const unsigned base = it < AI ? (unsigned)(it * 32 * P) : (unsigned)(SPLIT * APB + (it - AI) * 32 * P);
+      const unsigned piece = it < AI ? (unsigned)APB : (unsigned)XPB;
+#pragma unroll
+      for (int p = 0; p < SPLIT; ++p) *reinterpret_cast<uint2*>(lds + bufoff + base + wofs + p * piece) = make_uint2(d0[p], d1[p]);
+    }
+  };
+
+  const unsigned lane_a = (unsigned)((tco * 32 + il) * P + kl * 16);
+  const unsigned lane_b = (unsigned)(SPLIT * APB + (tci * 32 + il) * P + kl * 16);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  raw_load(0, n0);
+  raw_load(1, n0 + 1 < nlast ? n0 + 1 : nlast);
+  if (prof) prof[1] = __builtin_readcyclecounter();
+  // One frame: rs = (n - n0) % 3 and par = (n - n0) & 1 are literals at the call sites.
+  auto frame = [&](const int n, const int rs, const int par) __attribute__((always_inline)) {
+    const unsigned bufoff = par ? (unsigned)BUFB : 0u;
+    raw_load((rs + 2) % 3, n + 2 < nlast ? n + 2 : nlast);  // its set held frame n - 1, staged a frame ago
+    raw_wait(rs);
+    stage(rs, bufoff);
+    lds_barrier();  // images par complete; every wave is done reading images par ^ 1 (frame n - 1)
+#pragma unroll
+    for (int qq = 0; qq < 4 / KS; ++qq) {
+      const int q = kpart * (4 / KS) + qq;
+      u32x4 qa[SPLIT], qb[SPLIT];
+#pragma unroll
+      for (int p = 0; p < SPLIT; ++p) {
+        qa[p] = *reinterpret_cast<const u32x4*>(lds + bufoff + lane_a + (unsigned)(p * APB) + (unsigned)(q * 32));
+        qb[p] = *reinterpret_cast<const u32x4*>(lds + bufoff + lane_b + (unsigned)(p * XPB) + (unsigned)(q * 32));
+      }
+#pragma unroll
+      for (int ord = SPLIT - 1; ord >= 0; --ord)
+#pragma unroll
+        for (int sa = 0; sa <= ord; ++sa)
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, qa[sa]), __builtin_bit_cast(bf16x8, qb[ord - sa]), acc, 0, 0, 0);
+    }
+  };
+#pragma unroll 1
+  for (int n = n0; n < n1; n += 6) {
+    frame(n, 0, 0);
+    if (n + 1 < n1) frame(n + 1, 1, 1);
+    if (n + 2 < n1) frame(n + 2, 2, 0);
+    if (n + 3 < n1) frame(n + 3, 0, 1);
+    if (n + 4 < n1) frame(n + 4, 1, 0);
+    if (n + 5 < n1) frame(n + 5, 2, 1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped requests of the last frames
+  if (prof) prof[2] = __builtin_readcyclecounter();
+
+  if (part) {
+    // one tile per wave, accumulator order: float4 number (wave * 4 + r / 4) * 64 + lane of this workgroup's set (2048 atomic
+    // adders per address took 9-27 us of a 41 us launch; wgrad_reduce_partials1x1_kernel sums the sets behind this kernel)
+    float4* const ps = reinterpret_cast<float4*>(part) + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (kWg1x1SetFloats / 4) + (size_t)wave * 256 + lane;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) ps[gq * 64] = make_float4(acc[4 * gq], acc[4 * gq + 1], acc[4 * gq + 2], acc[4 * gq + 3]);
+  } else {
+    const int ci = tci * 32 + il;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = cob + tco * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
+      atomicAdd(&dwp[(size_t)row * g.Cpad + ci], acc[r]);
+    }
+  }
+  if (dbias != nullptr) {
+#pragma unroll
+    for (int j = 0; j < AI; ++j) {  // the 16 lanes of a DPP row share a channel
+      float v = bsum[j];
+      v += dpp_move<0xB1, 0xF>(0.f, v);
+      v += dpp_move<0x4E, 0xF>(0.f, v);
+      v += dpp_move<0x141, 0xF>(0.f, v);
+      v += dpp_move<0x140, 0xF>(0.f, v);
+      if ((tid & 15) == 0) {
+        const int ch = (tid >> 4) + j * 32;
+        if (part) part[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kWg1x1SetFloats + 8 * 1024 + ch] = v;
+        else atomicAdd(&dbias[cob + ch], v);
+      }
+    }
+  }
+  if (prof) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    prof[3] = __builtin_readcyclecounter();
+  }
+}
+
+// Partial tiles of conv1x1_wgrad_staged_kernel (part [cogroups][S][8 waves][256] float4, accumulator order) into dwp; a
+// workgroup's waves w and w + NTILE hold the same tile (k-halves), so the kernel sums 8 / NTILE x S slices per tile.
+template <int C>
+__global__ __launch_bounds__(256) void wgrad_reduce_partials1x1_kernel(const float4* __restrict__ part, const int S, const int cpad,
+                                                                       float* __restrict__ dwp, float* __restrict__ dbias) {
+  constexpr int NTILE = 2 * (C / 32), KS = 8 / NTILE, TILE4 = 256, SET4 = kWg1x1SetFloats / 4;
+  __shared__ float4 red[16][16];
+  const int li = threadIdx.x & 15, sg = threadIdx.x >> 4;
+  const int f = blockIdx.x * 16 + li;  // float4 of the NTILE tiles; host: grid.x * 16 == NTILE * 256 (+ 16: the bias block)
+  const bool bias = f >= NTILE * TILE4;  // block-uniform
+  const int tile = f / TILE4, ft = f - tile * TILE4;
+  const float4* const p = part + (size_t)blockIdx.y * S * SET4 + (bias ? (size_t)(8 * TILE4 + (f - NTILE * TILE4)) : (size_t)tile * TILE4 + ft);
+  float4 acc4[2];
+  acc4[0] = acc4[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int ks = bias ? 1 : KS;
+  const int slices = S * ks;  // slice i = (workgroup i / ks, k-half i % ks)
+  int i = sg;
+  for (; i + 16 < slices; i += 32) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int ii = i + 16 * u;
+      const float4 v = p[(size_t)(ii / ks) * SET4 + (size_t)(ii % ks) * (NTILE * TILE4)];
+      acc4[u].x += v.x; acc4[u].y += v.y; acc4[u].z += v.z; acc4[u].w += v.w;
+    }
+  }
+  for (; i < slices; i += 16) {
+    const float4 v = p[(size_t)(i / ks) * SET4 + (size_t)(i % ks) * (NTILE * TILE4)];
+    acc4[0].x += v.x; acc4[0].y += v.y; acc4[0].z += v.z; acc4[0].w += v.w;
+  }
+  red[sg][li] = make_float4(acc4[0].x + acc4[1].x, acc4[0].y + acc4[1].y, acc4[0].z + acc4[1].z, acc4[0].w + acc4[1].w);
+  __syncthreads();
+  if (sg == 0) {
+    float4 v = red[0][li];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) { v.x += red[k][li].x; v.y += red[k][li].y; v.z += red[k][li].z; v.w += red[k][li].w; }
+    if (bias) {
+      float* const o = dbias + blockIdx.y * 64 + 4 * (f - NTILE * TILE4);
+      o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w;
+      return;
+    }
+    const int lane = ft & 63, gq = ft >> 6, il = lane & 31, kl = lane >> 5;
+    const int tco = tile & 1, tci = tile >> 1;
+    float* const o = dwp + (size_t)(blockIdx.y * 64 + tco * 32 + 8 * gq + 4 * kl) * cpad + tci * 32 + il;
+    o[0] += v.x; o[cpad] += v.y; o[2 * (size_t)cpad] += v.z; o[3 * (size_t)cpad] += v.w;
   }
 }
 
