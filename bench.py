@@ -399,7 +399,7 @@ def main() -> None:  # noqa: PLR0914, PLR0915
                 # algorithmic block, so their ceiling is the dense bf16 peak / products (bf16x2: 2500 / 3 = 833).  The roof
                 # that binds is the roofline model's: a kernel whose arithmetic intensity (algorithmic FLOPs per
                 # algorithmic byte) lies below the ridge peak / HBM rate is priced against HBM, above it against the MFMA.
-                split = any(tag in name for tag in ("split_kernel", "resident_kernel", "stream_kernel"))
+                split = any(tag in name for tag in ("split_kernel", "resident_kernel", "stream_kernel", "staged_kernel"))
                 products = MFMA_PRODUCTS[args.conv_mfma] if split else 1
                 peak = MFMA_BF16_PEAK_TFLOPS / products if split else MFMA_F32_PEAK_TFLOPS
                 achieved = row["flops"] / secs / 1e12

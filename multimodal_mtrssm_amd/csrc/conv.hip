@@ -1544,7 +1544,7 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
     else { if (sp == 2) MTRSSM_WG1_LAUNCH(2, 128) else MTRSSM_WG1_LAUNCH(1, 128) }
 #undef MTRSSM_WG1_LAUNCH
     if (part) {
-      const dim3 rgrid((unsigned)(2 * (g->C / 32) * 256 / 16 + (dbias ? 1 : 0)), cogroups);  // + the bias block
+      const dim3 rgrid((unsigned)(2 * (g->C / 32) * 256 / 8 + (dbias ? 2 : 0)), cogroups);  // + the two bias blocks
       if (g->C == 64) hipLaunchKernelGGL(wgrad_reduce_partials1x1_kernel<64>, rgrid, dim3(256), 0, stream, reinterpret_cast<const float4*>(part), (int)grid.x, g->Cpad, dwp, dbias);
       else hipLaunchKernelGGL(wgrad_reduce_partials1x1_kernel<128>, rgrid, dim3(256), 0, stream, reinterpret_cast<const float4*>(part), (int)grid.x, g->Cpad, dwp, dbias);
     }
@@ -1605,7 +1605,7 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
     }
 #undef MTRSSM_WGRES_LAUNCH
     if (part) {
-      const dim3 rgrid((unsigned)(wgres_tile_floats(g->C) / 4 / 16 + (dbias ? 1 : 0)), cogroups);  // + the bias block
+      const dim3 rgrid((unsigned)(wgres_tile_floats(g->C) / 4 / 8 + (dbias ? 2 : 0)), cogroups);  // + the two bias blocks
       if (g->C == 64) hipLaunchKernelGGL(wgrad_reduce_partials_kernel<64>, rgrid, dim3(256), 0, stream, reinterpret_cast<const float4*>(part), (int)grid.x, g->Cpad, dwp, dbias);
       else hipLaunchKernelGGL(wgrad_reduce_partials_kernel<32>, rgrid, dim3(256), 0, stream, reinterpret_cast<const float4*>(part), (int)grid.x, g->Cpad, dwp, dbias);
     }

@@ -315,29 +315,30 @@ __global__ __launch_bounds__(64 * 2 * (C / 32), 1) void conv3x3_wgrad_resident_k
 }
 
 // Sum of the S partial tile sets of every co group (part [cogroups][S][set floats], accumulator order) into dwp.  Thread =
-// one float4 of the set (rows r .. r + 3 of one accumulator column) x one of 16 slices of S, the slices met in LDS; 16
-// lanes read 256-byte runs.  dwp is read-modified-written without atomics: launches that accumulate into one dwp chunk
-// are ordered by their stream.
+// one float4 of the set (rows r .. r + 3 of one accumulator column) x one of 32 slices of S (four loads in flight), the
+// slices met in LDS; 8 lanes read one 128-byte line.  dwp is read-modified-written without atomics: launches that
+// accumulate into one dwp chunk are ordered by their stream.
 template <int C>
 __global__ __launch_bounds__(256) void wgrad_reduce_partials_kernel(const float4* __restrict__ part, const int S, const int cpad,
                                                                     float* __restrict__ dwp, float* __restrict__ dbias) {
   constexpr int SET4 = wgres_set_floats(C) / 4, TILE4 = wgres_tile_floats(C) / 4;
-  __shared__ float4 red[16][16];
-  const int li = threadIdx.x & 15, sg = threadIdx.x >> 4;
-  const int f = blockIdx.x * 16 + li;  // host: grid.x * 16 == TILE4 (+ 16: the bias block, launched when dbias != NULL)
+  constexpr int NL = 8, NG = 32;  // 8 float4 columns (one 128-byte line per set) x 32 slices of S per workgroup
+  __shared__ float4 red[NG][NL];
+  const int li = threadIdx.x & (NL - 1), sg = threadIdx.x / NL;
+  const int f = blockIdx.x * NL + li;  // host: grid.x * 8 == TILE4 (+ 16: the two bias blocks, launched when dbias != NULL)
   const float4* const p = part + (size_t)blockIdx.y * S * SET4 + f;
   float4 acc4[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) acc4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
   int s = sg;
-  for (; s + 48 < S; s += 64) {
+  for (; s + 3 * NG < S; s += 4 * NG) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const float4 v = p[(size_t)(s + 16 * u) * SET4];
+      const float4 v = p[(size_t)(s + NG * u) * SET4];
       acc4[u].x += v.x; acc4[u].y += v.y; acc4[u].z += v.z; acc4[u].w += v.w;
     }
   }
-  for (; s < S; s += 16) {
+  for (; s < S; s += NG) {
     const float4 v = p[(size_t)s * SET4];
     acc4[0].x += v.x; acc4[0].y += v.y; acc4[0].z += v.z; acc4[0].w += v.w;
   }
@@ -347,8 +348,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_partials_kernel(const float4
   if (sg == 0) {
     float4 t = red[0][li];
 #pragma unroll
-    for (int k = 1; k < 16; ++k) { t.x += red[k][li].x; t.y += red[k][li].y; t.z += red[k][li].z; t.w += red[k][li].w; }
-    if (f >= TILE4) {  // block-uniform: the bias sums of channels 4 li .. 4 li + 3 of this co group
+    for (int k = 1; k < NG; ++k) { t.x += red[k][li].x; t.y += red[k][li].y; t.z += red[k][li].z; t.w += red[k][li].w; }
+    if (f >= TILE4) {  // block-uniform: the bias sums of channels 4 (f - TILE4) .. + 3 of this co group
       float* const o = dbias + blockIdx.y * 64 + 4 * (f - TILE4);
       o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w;
       return;
@@ -539,35 +540,38 @@ template <int C>
 __global__ __launch_bounds__(256) void wgrad_reduce_partials1x1_kernel(const float4* __restrict__ part, const int S, const int cpad,
                                                                        float* __restrict__ dwp, float* __restrict__ dbias) {
   constexpr int NTILE = 2 * (C / 32), KS = 8 / NTILE, TILE4 = 256, SET4 = kWg1x1SetFloats / 4;
-  __shared__ float4 red[16][16];
-  const int li = threadIdx.x & 15, sg = threadIdx.x >> 4;
-  const int f = blockIdx.x * 16 + li;  // float4 of the NTILE tiles; host: grid.x * 16 == NTILE * 256 (+ 16: the bias block)
+  constexpr int NL = 8, NG = 32;  // 8 float4 columns (one 128-byte line per slice) x 32 slice groups per workgroup
+  __shared__ float4 red[NG][NL];
+  const int li = threadIdx.x & (NL - 1), sg = threadIdx.x / NL;
+  const int f = blockIdx.x * NL + li;  // float4 of the NTILE tiles; host: grid.x * 8 == NTILE * 256 (+ 16: two bias blocks)
   const bool bias = f >= NTILE * TILE4;  // block-uniform
   const int tile = f / TILE4, ft = f - tile * TILE4;
   const float4* const p = part + (size_t)blockIdx.y * S * SET4 + (bias ? (size_t)(8 * TILE4 + (f - NTILE * TILE4)) : (size_t)tile * TILE4 + ft);
-  float4 acc4[2];
-  acc4[0] = acc4[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 acc4[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) acc4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
   const int ks = bias ? 1 : KS;
   const int slices = S * ks;  // slice i = (workgroup i / ks, k-half i % ks)
   int i = sg;
-  for (; i + 16 < slices; i += 32) {
+  for (; i + 3 * NG < slices; i += 4 * NG) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int ii = i + 16 * u;
+    for (int u = 0; u < 4; ++u) {
+      const int ii = i + NG * u;
       const float4 v = p[(size_t)(ii / ks) * SET4 + (size_t)(ii % ks) * (NTILE * TILE4)];
       acc4[u].x += v.x; acc4[u].y += v.y; acc4[u].z += v.z; acc4[u].w += v.w;
     }
   }
-  for (; i < slices; i += 16) {
+  for (; i < slices; i += NG) {
     const float4 v = p[(size_t)(i / ks) * SET4 + (size_t)(i % ks) * (NTILE * TILE4)];
     acc4[0].x += v.x; acc4[0].y += v.y; acc4[0].z += v.z; acc4[0].w += v.w;
   }
-  red[sg][li] = make_float4(acc4[0].x + acc4[1].x, acc4[0].y + acc4[1].y, acc4[0].z + acc4[1].z, acc4[0].w + acc4[1].w);
+  red[sg][li] = make_float4((acc4[0].x + acc4[1].x) + (acc4[2].x + acc4[3].x), (acc4[0].y + acc4[1].y) + (acc4[2].y + acc4[3].y),
+                            (acc4[0].z + acc4[1].z) + (acc4[2].z + acc4[3].z), (acc4[0].w + acc4[1].w) + (acc4[2].w + acc4[3].w));
   __syncthreads();
   if (sg == 0) {
     float4 v = red[0][li];
 #pragma unroll
-    for (int k = 1; k < 16; ++k) { v.x += red[k][li].x; v.y += red[k][li].y; v.z += red[k][li].z; v.w += red[k][li].w; }
+    for (int k = 1; k < NG; ++k) { v.x += red[k][li].x; v.y += red[k][li].y; v.z += red[k][li].z; v.w += red[k][li].w; }
     if (bias) {
       float* const o = dbias + blockIdx.y * 64 + 4 * (f - NTILE * TILE4);
       o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w;

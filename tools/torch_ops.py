@@ -43,9 +43,11 @@ for ev in prof.events():
         continue
     where = "?"
     for fr in ev.stack:
-        if here in fr and "tools/torch_ops.py" not in fr:
-            where = fr.replace(here + "/", "")
+        if ("multimodal_mtrssm_amd/" in fr or "bench.py" in fr) and "torch_ops.py" not in fr:
+            where = fr[fr.index("multimodal_mtrssm_amd/") if "multimodal_mtrssm_amd/" in fr else fr.index("bench.py"):]
             break
+    if where == "?" and ev.stack:
+        where = "(autograd) " + ev.stack[0][-60:]
     key = (ev.name, where)
     rows[key][0] += len(ev.kernels)
     rows[key][1] += sum(k.duration for k in ev.kernels)
