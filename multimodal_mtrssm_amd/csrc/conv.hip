@@ -1477,6 +1477,11 @@ static bool wgrad_1x1_staged_enabled() {
   static const bool on = [] { const char* e = getenv("MTRSSM_WGRAD_1X1_STAGED"); return !(e && e[0] == '0'); }();
   return on;
 }
+// MTRSSM_WGRAD_S2_STAGED=0: the patch-staged kernel for the second encoder layer instead of the staged one (A/B runs)
+static bool wgrad_s2_staged_enabled() {
+  static const bool on = [] { const char* e = getenv("MTRSSM_WGRAD_S2_STAGED"); return !(e && e[0] == '0'); }();
+  return on;
+}
 // MTRSSM_WGRAD_PARTIALS=0: the staged-input kernel adds its tiles to dwp by atomics instead of storing partial sets
 static bool wgrad_partials_enabled() {
   static const bool on = [] { const char* e = getenv("MTRSSM_WGRAD_PARTIALS"); return !(e && e[0] == '0'); }();
@@ -1653,6 +1658,37 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
     else if (sp == 2) hipLaunchKernelGGL((conv_weight_grad_thin_split_kernel<2>), grid, dim3(1024), 0, stream, *g, a, src, src2, pre_act_a, dwp, dbias, per, log2_wq);
     else hipLaunchKernelGGL((conv_weight_grad_thin_split_kernel<1>), grid, dim3(1024), 0, stream, *g, a, src, src2, pre_act_a, dwp, dbias, per, log2_wq);
     return launched("conv_weight_grad(thin split)");
+  }
+  if ((g->mfma_split == 1 || g->mfma_split == 2) && g->KH == 3 && g->KW == 3 && g->SS == 2 && g->TS == 1 && g->OFFY == -1 && g->OFFX == -1 &&
+      g->C2 == 0 && g->C == 8 && g->Cout == 16 && g->Hq * g->Wq == 256 && (g->Wq == 16 || g->Wq == 8) && g->Hs == 2 * g->Hq && g->Ws == 2 * g->Wq &&
+      g->Cpad >= 8 && !pre_act_a && (g->act == MTRSSM_ACT_IDENTITY || g->act == MTRSSM_ACT_ELU || g->act == MTRSSM_ACT_RELU) &&
+      !((uintptr_t)a & 15) && !((uintptr_t)src & 15) && wgrad_s2_staged_enabled()) {
+    // second encoder layer (3x3 / stride 2, 8 -> 16, 256-pixel output planes): operands staged once per frame (conv_wgrad_resident.h)
+    int wgs = cu_count();
+    if (wgs > g->N) wgs = g->N;
+    const int per = (g->N + wgs - 1) / wgs;
+    const dim3 grid((unsigned)((g->N + per - 1) / per));
+    float* const part = wgrad_partials_enabled() ? wgrad_scratch(stream, (size_t)grid.x * kWgS2SetFloats * sizeof(float)) : nullptr;
+#define MTRSSM_WGS2_LAUNCH(SP_, W_)                                                                                              \
+  {                                                                                                                             \
+    static bool attr_done = false; /* once per instantiation: never while another stream may be running the kernel */       \
+    constexpr int lds_b = wgs2_lds_bytes<SP_, W_>();                                                                            \
+    if (!attr_done) {                                                                                                           \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3s2_wgrad_staged_kernel<SP_, W_>),                           \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);                                             \
+      attr_done = true;                                                                                                         \
+    }                                                                                                                           \
+    set_last_kernel("mtrssm::conv3x3s2_wgrad_staged_kernel<" #SP_ ", " #W_ ">");                                                 \
+    hipLaunchKernelGGL((conv3x3s2_wgrad_staged_kernel<SP_, W_>), grid, dim3(512), lds_b, stream, *g, a, src, dwp, part, dbias,   \
+                       per);                                                                                                    \
+  }
+    const int sp = g->mfma_split;
+    if (g->Wq == 16) { if (sp == 2) MTRSSM_WGS2_LAUNCH(2, 16) else MTRSSM_WGS2_LAUNCH(1, 16) }
+    else { if (sp == 2) MTRSSM_WGS2_LAUNCH(2, 8) else MTRSSM_WGS2_LAUNCH(1, 8) }
+#undef MTRSSM_WGS2_LAUNCH
+    if (part)
+      hipLaunchKernelGGL(wgrad_reduce_partials_s2_kernel, dim3(dbias ? 49 : 48), dim3(256), 0, stream, reinterpret_cast<const float4*>(part), (int)grid.x, g->Cpad, dwp, dbias);
+    return launched("conv_weight_grad(3x3 s2 staged)");
   }
   // ---- patch-staged kernel when the 64-pixel groups tile the frames exactly
   if (g->TS == 1 && g->Wq <= kGP && kGP % g->Wq == 0) {

@@ -584,4 +584,248 @@ __global__ __launch_bounds__(256) void wgrad_reduce_partials1x1_kernel(const flo
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of the second encoder layer (3x3 / stride 2 / pad 1, 8 -> 16 channels, 256-pixel output planes: 16x16
+// vision, 32x8 audio), staged like the kernels above:
+//   dW[co][ky][kx][ci] = sum over frames n and output pixels (oy, ox) of  a[n][co][oy][ox] * act(src)[n][ci][2 oy + ky - 1][2 ox + kx - 1]
+// The patch-staged kernel (conv_split.h: conv_weight_grad_split_kernel<1, 2>) gathers its patches by 4-byte loads and runs
+// at 0.13 of the HBM rate (235-246 us for 157 MB).  Here every frame of `a` (16 x 256) and of src (8 x 2Ho x 2Wo) is loaded
+// once with coalesced 16-byte loads (eight waves, requests two frames ahead through three register sets), converted once and
+// written to LDS; src DE-INTERLEAVED by column parity (even / odd image, one zero halo row on top of every plane), so that the
+// 8 consecutive output pixels of a lane's B fragment are 8 consecutive elements: kx = 1 reads the even image at ox, kx = 2 the
+// odd image at ox, kx = 0 the odd image at ox - 1 = a funnel shift of the kx = 2 fragment with one more element in front.
+// MFMA columns are (tap, ci) pairs, 72 of them in three 32-column tiles; rows are the 16 co (the upper half of the 32-row
+// tile is unused).  Wave w: column tile w & 3 (3: staging only), k-steps (w >> 2) * 8 .. + 8 of the frame's 16.  Partial set:
+// float4 number (w * 2 + r / 4) * 64 + lane, r < 8, + 16 bias sums.
+// ------------------------------------------------------------------------------------------------
+constexpr int kWgS2SetFloats = 8 * 2 * 64 * 4 + 16;
+template <int WO>
+__host__ __device__ constexpr int wgs2_cip() { return (((256 / WO * 2 + 1) * (2 * WO)) / 16 | 1) * 16; }  // bytes per channel of one src image: odd in 16-byte slots
+template <int SPLIT, int WO>
+__host__ __device__ constexpr int wgs2_lds_bytes() { return 2 * SPLIT * (2 * 8 * wgs2_cip<WO>() + 16 * 528); }
+
+template <int SPLIT, int WO>
+__global__ __launch_bounds__(512, 1) void conv3x3s2_wgrad_staged_kernel(
+    const MtrssmConvGeom g, const float* __restrict__ a, const float* __restrict__ src, float* __restrict__ dwp,
+    float* __restrict__ part, float* __restrict__ dbias, const int frames_per_wg) {
+  static_assert(SPLIT == 1 || SPLIT == 2, "one or two bf16 pieces");
+  static_assert(WO == 16 || WO == 8, "output plane 16x16 or 32x8");
+  constexpr int NT = 512, C = 8, CO = 16, HO = 256 / WO, HS = 2 * HO, WS = 2 * WO;
+  constexpr int ROWB = WS;                 // bytes per row of one parity image: WS / 2 bf16
+  constexpr int CIP = wgs2_cip<WO>();      // bytes per channel: (HS + 1) rows, padded
+  constexpr int XCOPY = C * CIP;           // one parity image of one piece
+  constexpr int AP = 528, APB = CO * AP;   // `a` image: [co][256 pixels + 8] bf16
+  constexpr int BUFB = SPLIT * (2 * XCOPY + APB);  // one buffer: [piece][even image][odd image] then [piece][a image]
+  constexpr int XI = C * HS * WS / 4 / NT, AI = CO * 256 / 4 / NT, NI = XI + AI;  // 4 + 2 float4 items per thread and frame
+  extern __shared__ __attribute__((aligned(16))) unsigned char wgs2_lds[];
+  unsigned char* const lds = wgs2_lds;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int il = lane & 31, kl = lane >> 5;
+  const int ct = wave & 3, kh = wave >> 2;
+  const int n0 = blockIdx.x * frames_per_wg;
+  const int n1 = n0 + frames_per_wg < g.N ? n0 + frames_per_wg : g.N;
+  if (n0 >= n1) return;  // whole workgroup
+  const int nlast = n1 - 1;
+
+  const bool act_elu = g.act == MTRSSM_ACT_ELU, act_relu = g.act == MTRSSM_ACT_RELU, pre = g.pre_act != 0;
+  auto act_sel = [&](float x) __attribute__((always_inline)) {
+    float e = __expf(x) - 1.f;
+    asm volatile("" : "+v"(e));  // computed unconditionally: the compiler would branch around the exponential
+    const float neg = act_elu ? e : (act_relu ? 0.f : x);
+    return (x > 0.f || !pre) ? x : neg;
+  };
+
+  // zero both buffers once: the halo rows are never written again
+  for (int o = tid * 16; o < 2 * BUFB; o += NT * 16) *reinterpret_cast<uint4*>(lds + o) = make_uint4(0u, 0u, 0u, 0u);
+
+  // staging: src item j = float4 number tid + 512 j of the frame = 4 consecutive columns c0 .. c0 + 3 of one row of one
+  // channel; `a` item j = 4 consecutive pixels of channel tid / 64 + 8 j
+  const float4* const xsrc = reinterpret_cast<const float4*>(src) + tid;
+  const float4* const asrc = reinterpret_cast<const float4*>(a) + tid;
+  constexpr size_t xfr = (size_t)C * HS * WS / 4, afr = (size_t)CO * 256 / 4;  // float4 per frame
+  float bsum[AI];
+#pragma unroll
+  for (int j = 0; j < AI; ++j) bsum[j] = 0.f;
+  wg_f32x4 raw[3][NI];  // [set][a items, src items]
+  auto raw_load = [&](const int rs, const int n) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      const float4* const ptr = it < AI ? asrc + (size_t)n * afr + NT * it : xsrc + (size_t)n * xfr + NT * (it - AI);
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(raw[rs][it]) : "v"(ptr));
+    }
+  };
+  auto raw_wait = [&](const int rs) __attribute__((always_inline)) {  // the two younger sets may still be in flight
+    static_assert(NI == 6, "six items");
+    asm volatile("s_waitcnt vmcnt(12)" : "+v"(raw[rs][0]), "+v"(raw[rs][1]), "+v"(raw[rs][2]), "+v"(raw[rs][3]), "+v"(raw[rs][4]), "+v"(raw[rs][5]));
+  };
+  auto stage = [&](const int rs, const unsigned bufoff) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      const wg_f32x4 v = raw[rs][it];
+      if (it < AI) {
+        bsum[it] += (v.x + v.y) + (v.z + v.w);
+        unsigned d0[SPLIT], d1[SPLIT];
+        wg_split_pair<SPLIT>(v.x, v.y, d0);
+        wg_split_pair<SPLIT>(v.z, v.w, d1);
+        const int f = tid + NT * it;  // co = f / 64, pixel = 4 (f % 64)
+        const unsigned o = bufoff + (unsigned)(SPLIT * 2 * XCOPY) + (unsigned)((f >> 6) * AP + (f & 63) * 8);
+#pragma unroll
+        for (int p = 0; p < SPLIT; ++p) *reinterpret_cast<uint2*>(lds + o + p * APB) = make_uint2(d0[p], d1[p]);
+      } else {
+        unsigned de[SPLIT], dd[SPLIT];  // even columns (c0, c0 + 2), odd columns (c0 + 1, c0 + 3)
+        wg_split_pair<SPLIT>(act_sel(v.x), act_sel(v.z), de);
+        wg_split_pair<SPLIT>(act_sel(v.y), act_sel(v.w), dd);
+        const int f = tid + NT * (it - AI);
+        const int ci = f / (HS * WS / 4), rem = f - ci * (HS * WS / 4), row = rem / (WS / 4), c4 = rem - row * (WS / 4);
+        const unsigned o = bufoff + (unsigned)(ci * CIP + (row + 1) * ROWB + c4 * 4);  // columns c0 / 2, c0 / 2 + 1 of the parity images
+#pragma unroll
+        for (int p = 0; p < SPLIT; ++p) {
+          *reinterpret_cast<unsigned*>(lds + o + p * 2 * XCOPY) = de[p];
+          *reinterpret_cast<unsigned*>(lds + o + p * 2 * XCOPY + XCOPY) = dd[p];
+        }
+      }
+    }
+  };
+
+  // the lane's column of the tile: (tap, ci); columns 72 .. 95 of tile 2 are padding (computed on tap 8, never stored)
+  const int col = ct * 32 + il, colc = col < 72 ? col : 71;
+  const int tap = colc >> 3, ci = colc & 7, ky = tap / 3, kx = tap - 3 * ky;
+  // k-step s covers output pixels 16 s .. 16 s + 15, this lane 8 of them: WO = 16: row s, columns 8 kl ..; WO = 8: row 2 s + kl
+  const unsigned lane_b = (unsigned)((kx == 1 ? 0 : XCOPY) + ci * CIP + ky * ROWB + (WO == 16 ? kl * 16 : kl * 2 * ROWB));
+  constexpr unsigned kStepB = WO == 16 ? 2 * ROWB : 4 * ROWB;
+  const unsigned lane_a = (unsigned)(SPLIT * 2 * XCOPY + (il & 15) * AP + kl * 16);
+  const bool shifted = kx == 0;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  raw_load(0, n0);
+  raw_load(1, n0 + 1 < nlast ? n0 + 1 : nlast);
+  lds_barrier();  // the zeroes are in place
+  // One frame: rs = (n - n0) % 3 and par = (n - n0) & 1 are literals at the call sites.
+  auto frame = [&](const int n, const int rs, const int par) __attribute__((always_inline)) {
+    const unsigned bufoff = par ? (unsigned)BUFB : 0u;
+    raw_load((rs + 2) % 3, n + 2 < nlast ? n + 2 : nlast);  // its set held frame n - 1, staged a frame ago
+    raw_wait(rs);
+    stage(rs, bufoff);
+    lds_barrier();  // images par complete; every wave is done reading images par ^ 1 (frame n - 1)
+    if (ct < 3) {
+#pragma unroll
+      for (int ss = 0; ss < 8; ++ss) {
+        const int s = kh * 8 + ss;
+        u32x4 qa[SPLIT], qb[SPLIT];
+#pragma unroll
+        for (int p = 0; p < SPLIT; ++p) {
+          qa[p] = *reinterpret_cast<const u32x4*>(lds + bufoff + lane_a + (unsigned)(p * APB) + (unsigned)(s * 32));
+          const unsigned bo = bufoff + lane_b + (unsigned)(p * 2 * XCOPY) + (unsigned)s * kStepB;
+          const u32x4 f = *reinterpret_cast<const u32x4*>(lds + bo);
+          // kx = 0: the odd image one element to the left; the element in front of the fragment is the last one of the
+          // row's first half (WO = 16, second half) or the zero left of the row
+          unsigned prev = 0u;
+          if (WO == 16) prev = kl ? (unsigned)*reinterpret_cast<const unsigned short*>(lds + bo - 2) : 0u;
+          const u32x4 sh = u32x4{(f.x << 16) | prev, __builtin_amdgcn_alignbit(f.y, f.x, 16), __builtin_amdgcn_alignbit(f.z, f.y, 16), __builtin_amdgcn_alignbit(f.w, f.z, 16)};
+          qb[p] = shifted ? sh : f;
+        }
+#pragma unroll
+        for (int ord = SPLIT - 1; ord >= 0; --ord)
+#pragma unroll
+          for (int sa = 0; sa <= ord; ++sa)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, qa[sa]), __builtin_bit_cast(bf16x8, qb[ord - sa]), acc, 0, 0, 0);
+      }
+    }
+  };
+#pragma unroll 1
+  for (int n = n0; n < n1; n += 6) {
+    frame(n, 0, 0);
+    if (n + 1 < n1) frame(n + 1, 1, 1);
+    if (n + 2 < n1) frame(n + 2, 2, 0);
+    if (n + 3 < n1) frame(n + 3, 0, 1);
+    if (n + 4 < n1) frame(n + 4, 1, 0);
+    if (n + 5 < n1) frame(n + 5, 2, 1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped requests of the last frames
+
+  if (part) {
+    float* const set = part + (size_t)blockIdx.x * kWgS2SetFloats;
+    float4* const ps = reinterpret_cast<float4*>(set) + (size_t)wave * 128 + lane;
+    ps[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);   // rows 4 kl + 0 .. 3
+    ps[64] = make_float4(acc[4], acc[5], acc[6], acc[7]);  // rows 8 + 4 kl + 0 .. 3
+    if (dbias != nullptr) {
+#pragma unroll
+      for (int j = 0; j < AI; ++j) {  // a wave's 64 lanes share channel wave + 8 j
+        const float v = wave_sum(bsum[j]);
+        if (lane == 0) set[8 * 2 * 64 * 4 + wave + 8 * j] = v;
+      }
+    }
+  } else {
+    if (ct < 3 && col < 72) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * kl;
+        atomicAdd(&dwp[((size_t)row * 9 + tap) * g.Cpad + ci], acc[r]);
+      }
+    }
+    if (dbias != nullptr) {
+#pragma unroll
+      for (int j = 0; j < AI; ++j) {
+        const float v = wave_sum(bsum[j]);
+        if (lane == 0) atomicAdd(&dbias[wave + 8 * j], v);
+      }
+    }
+  }
+}
+
+// Partial sets of conv3x3s2_wgrad_staged_kernel into dwp / dbias: 72 columns x 16 rows, two k-halves per workgroup.
+__global__ __launch_bounds__(256) void wgrad_reduce_partials_s2_kernel(const float4* __restrict__ part, const int S, const int cpad,
+                                                                       float* __restrict__ dwp, float* __restrict__ dbias) {
+  constexpr int SET4 = kWgS2SetFloats / 4, NL = 8, NG = 32;
+  __shared__ float4 red[NG][NL];
+  const int li = threadIdx.x & (NL - 1), sg = threadIdx.x / NL;
+  const int f = blockIdx.x * NL + li;  // float4 (ct * 2 + half) * 64 + lane of the three column tiles: 384 of them, then 4 bias float4
+  const bool bias = f >= 384;          // block-uniform (48 tile blocks, then one bias block of which 4 columns are used)
+  if (bias && f >= 388) {              // padding columns of the bias block: nothing to read
+    red[sg][li] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int ct = f >> 7, rem = f & 127;
+  float4 acc4[2];
+  acc4[0] = acc4[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!(bias && f >= 388)) {
+    const int ks = bias ? 1 : 2;
+    const int slices = S * ks;  // slice i = (workgroup i / ks, k-half i % ks): waves ct and ct + 4
+    const float4* const p = part + (bias ? (size_t)(8 * 128 + (f - 384)) : (size_t)ct * 128 + rem);
+    int i = sg;
+    for (; i + NG < slices; i += 2 * NG) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int ii = i + NG * u;
+        const float4 v = p[(size_t)(ii / ks) * SET4 + (size_t)(ii % ks) * (4 * 128)];
+        acc4[u].x += v.x; acc4[u].y += v.y; acc4[u].z += v.z; acc4[u].w += v.w;
+      }
+    }
+    for (; i < slices; i += NG) {
+      const float4 v = p[(size_t)(i / ks) * SET4 + (size_t)(i % ks) * (4 * 128)];
+      acc4[0].x += v.x; acc4[0].y += v.y; acc4[0].z += v.z; acc4[0].w += v.w;
+    }
+    red[sg][li] = make_float4(acc4[0].x + acc4[1].x, acc4[0].y + acc4[1].y, acc4[0].z + acc4[1].z, acc4[0].w + acc4[1].w);
+  }
+  __syncthreads();
+  if (sg == 0) {
+    float4 v = red[0][li];
+#pragma unroll
+    for (int k = 1; k < NG; ++k) { v.x += red[k][li].x; v.y += red[k][li].y; v.z += red[k][li].z; v.w += red[k][li].w; }
+    if (bias) {
+      if (f < 388) { float* const o = dbias + 4 * (f - 384); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
+      return;
+    }
+    const int half = rem >> 6, lane = rem & 63, il = lane & 31, kl = lane >> 5;
+    const int col = ct * 32 + il;
+    if (col < 72) {
+      const int tap = col >> 3, ci = col & 7, row = 8 * half + 4 * kl;
+      float* const o = dwp + ((size_t)row * 9 + tap) * cpad + ci;
+      const size_t rs = (size_t)9 * cpad;
+      o[0] += v.x; o[rs] += v.y; o[2 * rs] += v.z; o[3 * rs] += v.w;
+    }
+  }
+}
+
 }  // namespace mtrssm

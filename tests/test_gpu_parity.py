@@ -453,6 +453,9 @@ CONV_CASES = [
     (1, 64, 8, 8, 64, 3, 1, 1, True, False),    # staged-operand weight gradient (conv3x3_wgrad_resident_kernel): ONE frame, one workgroup
     (700, 64, 16, 4, 128, 3, 1, 1, True, False),  # ... three frames per workgroup (odd run), two co groups, 16x4 plane; 1300 above: six / five
     (5, 64, 8, 8, 64, 3, 1, 1, False, False),   # ... no activation
+    (3, 8, 64, 16, 16, 3, 2, 1, True, False),   # second encoder layer, audio plane (32x8 output): staged stride-2 weight gradient (conv3x3s2_wgrad_staged_kernel<2, 8>); (2, 8, 32, 32, 16, ...) above is the vision plane (<2, 16>)
+    (1500, 8, 32, 32, 16, 3, 2, 1, True, False),  # ... six frames per workgroup: the three raw register sets and both image buffers go round
+    (700, 8, 64, 16, 16, 3, 2, 1, False, False),  # ... three frames per workgroup, no activation
 ]
 
 

@@ -1,7 +1,8 @@
 """Profiling probe (not part of the product): one conv layer of the bench workload, forward / backward, repeated.
 
-usage: python tools/conv_probe.py MODE CIN COUT H W K [FRAMES] [REPS] [bwd]
+usage: [STRIDE=2] python tools/conv_probe.py MODE CIN COUT H W K [FRAMES] [REPS] [bwd]
 """
+import os
 import sys
 
 import torch
@@ -20,7 +21,7 @@ wt = (torch.randn(cout, cin, k, k, generator=g) * 0.1).to(dev).requires_grad_(bw
 b = torch.randn(cout, generator=g).to(dev).requires_grad_(bwd)
 _lib.TIMERS.enable()
 for _ in range(reps):
-    y = conv.conv2d(x, wt, b, stride=1, padding=k // 2, pre_act=True, act=2)
+    y = conv.conv2d(x, wt, b, stride=int(os.environ.get("STRIDE", "1")), padding=k // 2, pre_act=True, act=2)
     if bwd:
         y.backward(torch.ones_like(y))
 torch.cuda.synchronize()
