@@ -1721,6 +1721,37 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
       hipLaunchKernelGGL(wgrad_reduce_partials_t4_kernel, dim3(kWgT4SetFloats / 4 / 8), dim3(256), 0, stream, reinterpret_cast<const float4*>(part), (int)grid.x, g->Cpad, dwp);
     return launched("conv_weight_grad(k4 s2 staged)");
   }
+  if ((g->mfma_split == 1 || g->mfma_split == 2) && g->KH == 4 && g->KW == 4 && g->SS == 2 && g->TS == 1 && g->OFFY == -1 && g->OFFX == -1 &&
+      g->C2 == 0 && g->C == 32 && g->Cout == 64 && g->Hq * g->Wq == 64 && (g->Wq == 8 || g->Wq == 4) && g->Hs == 2 * g->Hq && g->Ws == 2 * g->Wq &&
+      g->Cpad >= 32 && !g->pre_act && !dbias && (g->act == MTRSSM_ACT_IDENTITY || g->act == MTRSSM_ACT_ELU || g->act == MTRSSM_ACT_RELU || !pre_act_a) &&
+      !((uintptr_t)a & 15) && !((uintptr_t)src & 15) && wgrad_s2_staged_enabled()) {
+    // the decoders' first ConvTranspose2d (k = 4 / stride 2, 64 -> 32, 64-pixel input planes): operands staged once per frame
+    int wgs = cu_count();
+    if (wgs > g->N) wgs = g->N;
+    const int per = (g->N + wgs - 1) / wgs;
+    const dim3 grid((unsigned)((g->N + per - 1) / per));
+    float* const part = wgrad_partials_enabled() ? wgrad_scratch(stream, (size_t)grid.x * kWgT4bSetFloats * sizeof(float)) : nullptr;
+#define MTRSSM_WGT4B_LAUNCH(SP_, W_)                                                                                             \
+  {                                                                                                                             \
+    static bool attr_done = false; /* once per instantiation: never while another stream may be running the kernel */       \
+    constexpr int lds_b = wgt4b_lds_bytes<SP_, W_>();                                                                           \
+    if (!attr_done) {                                                                                                           \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convt4s2b_wgrad_staged_kernel<SP_, W_>),                           \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);                                             \
+      attr_done = true;                                                                                                         \
+    }                                                                                                                           \
+    set_last_kernel("mtrssm::convt4s2b_wgrad_staged_kernel<" #SP_ ", " #W_ ">");                                                 \
+    hipLaunchKernelGGL((convt4s2b_wgrad_staged_kernel<SP_, W_>), grid, dim3(512), lds_b, stream, *g, a, src, pre_act_a, dwp,     \
+                       part, per);                                                                                              \
+  }
+    const int sp = g->mfma_split;
+    if (g->Wq == 8) { if (sp == 2) MTRSSM_WGT4B_LAUNCH(2, 8) else MTRSSM_WGT4B_LAUNCH(1, 8) }
+    else { if (sp == 2) MTRSSM_WGT4B_LAUNCH(2, 4) else MTRSSM_WGT4B_LAUNCH(1, 4) }
+#undef MTRSSM_WGT4B_LAUNCH
+    if (part)
+      hipLaunchKernelGGL(wgrad_reduce_partials_t4b_kernel, dim3(kWgT4bSetFloats / 4 / 8), dim3(256), 0, stream, reinterpret_cast<const float4*>(part), (int)grid.x, g->Cpad, dwp);
+    return launched("conv_weight_grad(k4 s2 staged, 64 rows)");
+  }
   // ---- patch-staged kernel when the 64-pixel groups tile the frames exactly
   if (g->TS == 1 && g->Wq <= kGP && kGP % g->Wq == 0) {
     const PatchGeom pg(*g, kGP);

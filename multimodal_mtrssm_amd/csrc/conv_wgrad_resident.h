@@ -1025,4 +1025,211 @@ __global__ __launch_bounds__(256) void wgrad_reduce_partials_t4_kernel(const flo
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// ... and of the decoders' FIRST ConvTranspose2d (k = 4, stride 2, pad 1, 64 -> 32 channels; input planes of 64 pixels: 8x8
+// vision, 16x4 audio).  32 src channels per tap make every 32-column tile ONE tap with lane = src channel, so the column
+// shift is wave-uniform: wave w holds taps 2 w (odd image: kx = 0 shifted by one with a zero in front, kx = 2 as it stands)
+// and 2 w + 1 (even image: kx = 1 as it stands, kx = 3 shifted the other way) for both 32-row tiles of the 64 ci = four
+// accumulator tiles.  A lane's 8 pixels are one whole row (8x8) or two whole rows (16x4: two 8-byte reads two image rows
+// apart), so no neighbour element is needed.  Partial set: float4 number ((w * 4 + tile) * 4 + r / 4) * 64 + lane,
+// tile = 2 (row tile) + (tap & 1).
+// ------------------------------------------------------------------------------------------------
+constexpr int kWgT4bSetFloats = 8 * 4 * 4 * 64 * 4;
+template <int WO>
+__host__ __device__ constexpr int wgt4b_cip() { return (((64 / WO * 2 + 2) * (2 * WO)) / 16 | 1) * 16; }
+template <int SPLIT, int WO>
+__host__ __device__ constexpr int wgt4b_lds_bytes() { return SPLIT * (2 * 32 * wgt4b_cip<WO>() + 64 * kWgresAPitch); }
+
+template <int SPLIT, int WO>
+__global__ __launch_bounds__(512, 1) void convt4s2b_wgrad_staged_kernel(
+    const MtrssmConvGeom g, const float* __restrict__ a, const float* __restrict__ src, const int pre_act_a, float* __restrict__ dwp,
+    float* __restrict__ part, const int frames_per_wg) {
+  static_assert(SPLIT == 1 || SPLIT == 2, "one or two bf16 pieces");
+  static_assert(WO == 8 || WO == 4, "input plane 8x8 or 16x4");
+  constexpr int NT = 512, C = 32, CO = 64, HO = 64 / WO, HS = 2 * HO, WS = 2 * WO;
+  constexpr int ROWB = WS;                 // bytes per row of one parity image: WS / 2 bf16
+  constexpr int CIP = wgt4b_cip<WO>();     // bytes per channel: (HS + 2) rows, padded
+  constexpr int XCOPY = C * CIP;           // one parity image of one piece
+  constexpr int AP = kWgresAPitch, APB = CO * AP;  // `a` image: [ci][64 pixels + 8] bf16
+  constexpr int XI = C * HS * WS / 4 / NT, AI = CO * 64 / 4 / NT, NI = XI + AI;  // 4 + 2 float4 items per thread and frame
+  extern __shared__ __attribute__((aligned(16))) unsigned char wgt4b_lds[];
+  unsigned char* const lds = wgt4b_lds;    // [piece][even image][odd image] then [piece][a image]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int il = lane & 31, kl = lane >> 5;
+  const int n0 = blockIdx.x * frames_per_wg;
+  const int n1 = n0 + frames_per_wg < g.N ? n0 + frames_per_wg : g.N;
+  if (n0 >= n1) return;  // whole workgroup
+  const int nlast = n1 - 1;
+
+  const bool act_elu = g.act == MTRSSM_ACT_ELU, act_relu = g.act == MTRSSM_ACT_RELU, pre = pre_act_a != 0;
+  auto act_sel = [&](float x) __attribute__((always_inline)) {
+    float e = __expf(x) - 1.f;
+    asm volatile("" : "+v"(e));  // computed unconditionally: the compiler would branch around the exponential
+    const float neg = act_elu ? e : (act_relu ? 0.f : x);
+    return (x > 0.f || !pre) ? x : neg;
+  };
+
+  for (int o = tid * 16; o < wgt4b_lds_bytes<SPLIT, WO>(); o += NT * 16) *reinterpret_cast<uint4*>(lds + o) = make_uint4(0u, 0u, 0u, 0u);
+
+  const float4* const xsrc = reinterpret_cast<const float4*>(src) + tid;
+  const float4* const asrc = reinterpret_cast<const float4*>(a) + tid;
+  constexpr size_t xfr = (size_t)C * HS * WS / 4, afr = (size_t)CO * 64 / 4;  // float4 per frame
+  wg_f32x4 raw[3][NI];  // [set][a items, src items]
+  auto raw_load = [&](const int rs, const int n) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      const float4* const ptr = it < AI ? asrc + (size_t)n * afr + NT * it : xsrc + (size_t)n * xfr + NT * (it - AI);
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(raw[rs][it]) : "v"(ptr));
+    }
+  };
+  auto raw_wait = [&](const int rs) __attribute__((always_inline)) {  // the two younger sets may still be in flight
+    static_assert(NI == 6, "six items");
+    asm volatile("s_waitcnt vmcnt(12)" : "+v"(raw[rs][0]), "+v"(raw[rs][1]), "+v"(raw[rs][2]), "+v"(raw[rs][3]), "+v"(raw[rs][4]), "+v"(raw[rs][5]));
+  };
+  auto stage = [&](const int rs) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      const wg_f32x4 v = raw[rs][it];
+      if (it < AI) {
+        unsigned d0[SPLIT], d1[SPLIT];
+        wg_split_pair<SPLIT>(act_sel(v.x), act_sel(v.y), d0);
+        wg_split_pair<SPLIT>(act_sel(v.z), act_sel(v.w), d1);
+        const int f = tid + NT * it;  // ci = f / 16, pixel = 4 (f % 16)
+        const unsigned o = (unsigned)(SPLIT * 2 * XCOPY) + (unsigned)((f >> 4) * AP + (f & 15) * 8);
+#pragma unroll
+        for (int p = 0; p < SPLIT; ++p) *reinterpret_cast<uint2*>(lds + o + p * APB) = make_uint2(d0[p], d1[p]);
+      } else {
+        unsigned de[SPLIT], dd[SPLIT];  // even columns (c0, c0 + 2), odd columns (c0 + 1, c0 + 3)
+        wg_split_pair<SPLIT>(v.x, v.z, de);
+        wg_split_pair<SPLIT>(v.y, v.w, dd);
+        const int f = tid + NT * (it - AI);
+        const int co = f / (HS * WS / 4), rem = f - co * (HS * WS / 4), row = rem / (WS / 4), c4 = rem - row * (WS / 4);
+        const unsigned o = (unsigned)(co * CIP + (row + 1) * ROWB + c4 * 4);
+#pragma unroll
+        for (int p = 0; p < SPLIT; ++p) {
+          *reinterpret_cast<unsigned*>(lds + o + p * 2 * XCOPY) = de[p];
+          *reinterpret_cast<unsigned*>(lds + o + p * 2 * XCOPY + XCOPY) = dd[p];
+        }
+      }
+    }
+  };
+
+  // taps 2 w (odd image) and 2 w + 1 (even image): ky = w >> 1 for both, kx = 2 (w & 1) and 2 (w & 1) + 1; lane = src channel
+  const int ky = wave >> 1;
+  const bool hi = (wave & 1) != 0;  // kx in {2, 3}: the odd-image tap as it stands, the even-image tap shifted towards x + 1
+  // k-step s covers input pixels 16 s .. 16 s + 15, this lane 8 of them: WO = 8: row 2 s + kl; WO = 4: rows 4 s + 2 kl, + 1
+  const unsigned lane_b = (unsigned)(il * CIP + ky * ROWB + kl * (WO == 8 ? 2 * ROWB : 4 * ROWB));
+  constexpr unsigned kStepB = WO == 8 ? 4 * ROWB : 8 * ROWB;
+  const unsigned lane_a = (unsigned)(SPLIT * 2 * XCOPY + il * AP + kl * 16);
+  f32x16 acc[4];  // [row tile * 2 + (tap & 1)]
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  auto ab = [](const unsigned h, const unsigned l) __attribute__((always_inline)) { return __builtin_amdgcn_alignbit(h, l, 16); };
+  auto shr1 = [&](const u32x4 f) __attribute__((always_inline)) {  // element x <- x - 1, zero into every row's first element
+    return WO == 8 ? u32x4{f.x << 16, ab(f.y, f.x), ab(f.z, f.y), ab(f.w, f.z)} : u32x4{f.x << 16, ab(f.y, f.x), f.z << 16, ab(f.w, f.z)};
+  };
+  auto shl1 = [&](const u32x4 f) __attribute__((always_inline)) {  // element x <- x + 1, zero into every row's last element
+    return WO == 8 ? u32x4{ab(f.y, f.x), ab(f.z, f.y), ab(f.w, f.z), f.w >> 16} : u32x4{ab(f.y, f.x), f.y >> 16, ab(f.w, f.z), f.w >> 16};
+  };
+  auto read_frag = [&](const unsigned off) __attribute__((always_inline)) {
+    if (WO == 8) return *reinterpret_cast<const u32x4*>(lds + off);
+    const uint2 r0 = *reinterpret_cast<const uint2*>(lds + off), r1 = *reinterpret_cast<const uint2*>(lds + off + 2 * ROWB);
+    return u32x4{r0.x, r0.y, r1.x, r1.y};
+  };
+
+  raw_load(0, n0);
+  raw_load(1, n0 + 1 < nlast ? n0 + 1 : nlast);
+  auto frame = [&](const int n, const int rs) __attribute__((always_inline)) {  // rs = (n - n0) % 3, a literal at the call sites
+    raw_load((rs + 2) % 3, n + 2 < nlast ? n + 2 : nlast);  // its set held frame n - 1, staged a frame ago
+    raw_wait(rs);
+    lds_barrier();  // every wave is done reading the previous frame's images (first frame: the zeroes are in place)
+    stage(rs);
+    lds_barrier();  // images complete
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      u32x4 qa[2][SPLIT], qb[2][SPLIT];
+#pragma unroll
+      for (int p = 0; p < SPLIT; ++p) {
+        qa[0][p] = *reinterpret_cast<const u32x4*>(lds + lane_a + (unsigned)(p * APB) + (unsigned)(s * 32));
+        qa[1][p] = *reinterpret_cast<const u32x4*>(lds + lane_a + (unsigned)(32 * AP + p * APB) + (unsigned)(s * 32));
+        const unsigned bo = lane_b + (unsigned)(p * 2 * XCOPY) + (unsigned)s * kStepB;
+        const u32x4 fe = read_frag(bo), fo = read_frag(bo + XCOPY);
+        const u32x4 fos = shr1(fo), fes = shl1(fe);
+        qb[0][p] = hi ? fo : fos;   // tap 2 w: kx = 2 : kx = 0
+        qb[1][p] = hi ? fes : fe;   // tap 2 w + 1: kx = 3 : kx = 1
+      }
+#pragma unroll
+      for (int ord = SPLIT - 1; ord >= 0; --ord)
+#pragma unroll
+        for (int sa = 0; sa <= ord; ++sa)
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, qa[t >> 1][sa]), __builtin_bit_cast(bf16x8, qb[t & 1][ord - sa]), acc[t], 0, 0, 0);
+    }
+  };
+#pragma unroll 1
+  for (int n = n0; n < n1; n += 3) {
+    frame(n, 0);
+    if (n + 1 < n1) frame(n + 1, 1);
+    if (n + 2 < n1) frame(n + 2, 2);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped requests of the last frames
+
+  if (part) {
+    float4* const ps = reinterpret_cast<float4*>(part) + (size_t)blockIdx.x * (kWgT4bSetFloats / 4) + (size_t)wave * 1024 + lane;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) ps[(t * 4 + gq) * 64] = make_float4(acc[t][4 * gq], acc[t][4 * gq + 1], acc[t][4 * gq + 2], acc[t][4 * gq + 3]);
+  } else {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (t >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
+        atomicAdd(&dwp[((size_t)row * 16 + 2 * wave + (t & 1)) * g.Cpad + il], acc[t][r]);
+      }
+  }
+}
+
+// Partial sets of convt4s2b_wgrad_staged_kernel into dwp.
+__global__ __launch_bounds__(256) void wgrad_reduce_partials_t4b_kernel(const float4* __restrict__ part, const int S, const int cpad,
+                                                                        float* __restrict__ dwp) {
+  constexpr int SET4 = kWgT4bSetFloats / 4, NL = 8, NG = 32;
+  __shared__ float4 red[NG][NL];
+  const int li = threadIdx.x & (NL - 1), sg = threadIdx.x / NL;
+  const int f = blockIdx.x * NL + li;  // host: grid.x * 8 == SET4
+  const float4* const p = part + f;
+  float4 acc4[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) acc4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  int s = sg;
+  for (; s + 3 * NG < S; s += 4 * NG) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float4 v = p[(size_t)(s + NG * u) * SET4];
+      acc4[u].x += v.x; acc4[u].y += v.y; acc4[u].z += v.z; acc4[u].w += v.w;
+    }
+  }
+  for (; s < S; s += NG) {
+    const float4 v = p[(size_t)s * SET4];
+    acc4[0].x += v.x; acc4[0].y += v.y; acc4[0].z += v.z; acc4[0].w += v.w;
+  }
+  red[sg][li] = make_float4((acc4[0].x + acc4[1].x) + (acc4[2].x + acc4[3].x), (acc4[0].y + acc4[1].y) + (acc4[2].y + acc4[3].y),
+                            (acc4[0].z + acc4[1].z) + (acc4[2].z + acc4[3].z), (acc4[0].w + acc4[1].w) + (acc4[2].w + acc4[3].w));
+  __syncthreads();
+  if (sg == 0) {
+    float4 v = red[0][li];
+#pragma unroll
+    for (int k = 1; k < NG; ++k) { v.x += red[k][li].x; v.y += red[k][li].y; v.z += red[k][li].z; v.w += red[k][li].w; }
+    const int lane = f & 63, gq = (f >> 6) & 3, t = (f >> 8) & 3, wave = f >> 10, il = lane & 31, kl = lane >> 5;
+    const int tap = 2 * wave + (t & 1), row = (t >> 1) * 32 + 8 * gq + 4 * kl;
+    float* const o = dwp + ((size_t)row * 16 + tap) * cpad + il;
+    const size_t rs = (size_t)16 * cpad;
+    o[0] += v.x; o[rs] += v.y; o[2 * rs] += v.z; o[3 * rs] += v.w;
+  }
+}
+
 }  // namespace mtrssm

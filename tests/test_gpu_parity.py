@@ -520,6 +520,8 @@ DECONV_CASES = [
     (3, 32, 32, 8, 16, 4, 2, 1, 0, True),  # second decoder layer, audio plane: staged weight gradient (convt4s2_wgrad_staged_kernel<2, 8>); (2, 32, 16, 16, 16, ...) above is the vision plane (<2, 16>)
     (700, 32, 16, 16, 16, 4, 2, 1, 0, True),  # ... three frames per workgroup: the raw register sets go round
     (300, 32, 32, 8, 16, 4, 2, 1, 0, False),  # ... two frames per workgroup (the last ones one), no activation
+    (700, 64, 8, 8, 32, 4, 2, 1, 0, True),    # first decoder layer (convt4s2b_wgrad_staged_kernel<2, 8>): three frames per workgroup; (3, 64, 8, 8, 32, ...) and (5, 64, 16, 4, 32, ...) above are its one-frame cases (<2, 8>, <2, 4>)
+    (300, 64, 16, 4, 32, 4, 2, 1, 0, False),  # ... audio plane, two frames per workgroup, no activation
 ]
 
 
