@@ -1232,4 +1232,235 @@ __global__ __launch_bounds__(256) void wgrad_reduce_partials_t4b_kernel(const fl
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of the FIRST encoder layer (3x3 / stride 2 / pad 1; one frame channel + two frame-independent
+// coordinate channels -> 8; 1024-pixel output planes: 32x32 vision, 64x16 audio), the recipe of
+// conv3x3s2_wgrad_staged_kernel on a thin layer:
+//   dW[co][ky][kx][c] = sum over frames n and output pixels of  a[n][co][oy][ox] * act(src ++ coords)[n][c][2 oy + ky - 1][2 ox + kx - 1]
+// 27 (tap, channel) columns = one MFMA tile with 8 of its 32 rows used; all eight waves hold that tile for eight of the
+// frame's 64 k-steps each (the reduce kernel adds the eight).  The coordinate channels are staged once per workgroup.
+// Partial set: float4 number w * 64 + lane (rows 4 kl .. + 3 of column il), + 8 bias sums.
+// ------------------------------------------------------------------------------------------------
+constexpr int kWgThinSetFloats = 8 * 64 * 4 + 8;
+template <int WO>
+__host__ __device__ constexpr int wgthin_cip() { return (((1024 / WO * 2 + 1) * (2 * WO)) / 16 | 1) * 16; }
+template <int SPLIT, int WO>
+__host__ __device__ constexpr int wgthin_lds_bytes() { return SPLIT * (2 * 3 * wgthin_cip<WO>() + 8 * 2064) + 128; }
+
+template <int SPLIT, int WO>
+__global__ __launch_bounds__(512, 1) void conv3x3s2_thin_wgrad_staged_kernel(
+    const MtrssmConvGeom g, const float* __restrict__ a, const float* __restrict__ src, const float* __restrict__ coords,
+    float* __restrict__ dwp, float* __restrict__ part, float* __restrict__ dbias, const int frames_per_wg) {
+  static_assert(SPLIT == 1 || SPLIT == 2, "one or two bf16 pieces");
+  static_assert(WO == 32 || WO == 16, "output plane 32x32 or 64x16");
+  constexpr int NT = 512, CH = 3, CO = 8, HO = 1024 / WO, HS = 2 * HO, WS = 2 * WO;
+  constexpr int ROWB = WS;                 // bytes per row of one parity image: WS / 2 bf16
+  constexpr int CIP = wgthin_cip<WO>();    // bytes per channel: (HS + 1) rows, padded
+  constexpr int XCOPY = CH * CIP;          // one parity image of one piece: [frame channel, coordinate y, coordinate x]
+  constexpr int AP = 2064, APB = CO * AP;  // `a` image: [co][1024 pixels + 8] bf16
+  constexpr int XI = HS * WS / 4 / NT, AI = CO * 1024 / 4 / NT, NI = XI + AI;  // 2 + 4 float4 items per thread and frame
+  constexpr int LDSB = SPLIT * (2 * XCOPY + APB);
+  extern __shared__ __attribute__((aligned(16))) unsigned char wgthin_lds[];
+  unsigned char* const lds = wgthin_lds;   // [piece][even image][odd image], [piece][a image], 32 floats of bias scratch
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int il = lane & 31, kl = lane >> 5;
+  const int n0 = blockIdx.x * frames_per_wg;
+  const int n1 = n0 + frames_per_wg < g.N ? n0 + frames_per_wg : g.N;
+  if (n0 >= n1) return;  // whole workgroup
+  const int nlast = n1 - 1;
+
+  const bool act_elu = g.act == MTRSSM_ACT_ELU, act_relu = g.act == MTRSSM_ACT_RELU, pre = g.pre_act != 0;
+  auto act_sel = [&](float x) __attribute__((always_inline)) {
+    float e = __expf(x) - 1.f;
+    asm volatile("" : "+v"(e));  // computed unconditionally: the compiler would branch around the exponential
+    const float neg = act_elu ? e : (act_relu ? 0.f : x);
+    return (x > 0.f || !pre) ? x : neg;
+  };
+
+  for (int o = tid * 16; o < wgthin_lds_bytes<SPLIT, WO>(); o += NT * 16) *reinterpret_cast<uint4*>(lds + o) = make_uint4(0u, 0u, 0u, 0u);
+
+  // a src / coordinate float4 = 4 consecutive columns c0 .. c0 + 3 of one row: even columns to the even image, odd to the odd one
+  auto stage_src = [&](const float4 v, const int ch, const int f) __attribute__((always_inline)) {
+    unsigned de[SPLIT], dd[SPLIT];
+    wg_split_pair<SPLIT>(act_sel(v.x), act_sel(v.z), de);
+    wg_split_pair<SPLIT>(act_sel(v.y), act_sel(v.w), dd);
+    const int row = f / (WS / 4), c4 = f - row * (WS / 4);
+    const unsigned o = (unsigned)(ch * CIP + (row + 1) * ROWB + c4 * 4);
+#pragma unroll
+    for (int p = 0; p < SPLIT; ++p) {
+      *reinterpret_cast<unsigned*>(lds + o + p * 2 * XCOPY) = de[p];
+      *reinterpret_cast<unsigned*>(lds + o + p * 2 * XCOPY + XCOPY) = dd[p];
+    }
+  };
+
+  const float4* const xsrc = reinterpret_cast<const float4*>(src) + tid;
+  const float4* const asrc = reinterpret_cast<const float4*>(a) + tid;
+  constexpr size_t xfr = (size_t)HS * WS / 4, afr = (size_t)CO * 1024 / 4;  // float4 per frame
+  float bsum[AI];
+#pragma unroll
+  for (int j = 0; j < AI; ++j) bsum[j] = 0.f;
+  wg_f32x4 raw[3][NI];  // [set][a items, src items]
+  auto raw_load = [&](const int rs, const int n) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      const float4* const ptr = it < AI ? asrc + (size_t)n * afr + NT * it : xsrc + (size_t)n * xfr + NT * (it - AI);
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(raw[rs][it]) : "v"(ptr));
+    }
+  };
+  auto raw_wait = [&](const int rs) __attribute__((always_inline)) {  // the two younger sets may still be in flight
+    static_assert(NI == 6, "six items");
+    asm volatile("s_waitcnt vmcnt(12)" : "+v"(raw[rs][0]), "+v"(raw[rs][1]), "+v"(raw[rs][2]), "+v"(raw[rs][3]), "+v"(raw[rs][4]), "+v"(raw[rs][5]));
+  };
+  auto stage = [&](const int rs) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      const wg_f32x4 v = raw[rs][it];
+      if (it < AI) {
+        bsum[it] += (v.x + v.y) + (v.z + v.w);
+        unsigned d0[SPLIT], d1[SPLIT];
+        wg_split_pair<SPLIT>(v.x, v.y, d0);
+        wg_split_pair<SPLIT>(v.z, v.w, d1);
+        const int f = tid + NT * it;  // co = f / 256, pixel = 4 (f % 256)
+        const unsigned o = (unsigned)(SPLIT * 2 * XCOPY) + (unsigned)((f >> 8) * AP + (f & 255) * 8);
+#pragma unroll
+        for (int p = 0; p < SPLIT; ++p) *reinterpret_cast<uint2*>(lds + o + p * APB) = make_uint2(d0[p], d1[p]);
+      } else {
+        stage_src(make_float4(v.x, v.y, v.z, v.w), 0, tid + NT * (it - AI));
+      }
+    }
+  };
+
+  // the lane's column: (tap, channel) = (il / 3, il % 3); lanes 27 .. 31 are padding (computed on column 26, never stored)
+  const int colc = il < 27 ? il : 26;
+  const int tap = colc / 3, ch = colc - 3 * tap, ky = tap / 3, kx = tap - 3 * ky;
+  const unsigned lane_b = (unsigned)((kx == 1 ? 0 : XCOPY) + ch * CIP + ky * ROWB + kl * 16);
+  const unsigned lane_a = (unsigned)(SPLIT * 2 * XCOPY + (il & 7) * AP + kl * 16);
+  const bool shifted = kx == 0;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  raw_load(0, n0);
+  raw_load(1, n0 + 1 < nlast ? n0 + 1 : nlast);
+  lds_barrier();  // the zeroes are in place
+  // the coordinate channels, once: 2 x HS x WS floats = 4 float4 per thread
+#pragma unroll
+  for (int j = 0; j < 2 * XI; ++j) {
+    const int f = tid + NT * j;  // channel f / (HS WS / 4)
+    stage_src(reinterpret_cast<const float4*>(coords)[f], 1 + f / (HS * WS / 4), f % (HS * WS / 4));
+  }
+  auto frame = [&](const int n, const int rs) __attribute__((always_inline)) {  // rs = (n - n0) % 3, a literal at the call sites
+    raw_load((rs + 2) % 3, n + 2 < nlast ? n + 2 : nlast);  // its set held frame n - 1, staged a frame ago
+    raw_wait(rs);
+    lds_barrier();  // every wave is done reading the previous frame's images
+    stage(rs);
+    lds_barrier();  // images complete
+#pragma unroll
+    for (int ss = 0; ss < 8; ++ss) {
+      const int s = wave * 8 + ss;  // k-step: output pixels 16 s .. 16 s + 15; WO = 32: row s / 2, half s & 1; WO = 16: row s
+      const unsigned soff = WO == 32 ? (unsigned)((s >> 1) * 2 * ROWB + (s & 1) * 32) : (unsigned)(s * 2 * ROWB);
+      const bool has_prev = WO == 32 ? ((s & 1) | kl) != 0 : kl != 0;
+      u32x4 qa[SPLIT], qb[SPLIT];
+#pragma unroll
+      for (int p = 0; p < SPLIT; ++p) {
+        qa[p] = *reinterpret_cast<const u32x4*>(lds + lane_a + (unsigned)(p * APB) + (unsigned)(s * 32));
+        const unsigned bo = lane_b + (unsigned)(p * 2 * XCOPY) + soff;
+        const u32x4 f = *reinterpret_cast<const u32x4*>(lds + bo);
+        const unsigned prev = has_prev ? (unsigned)*reinterpret_cast<const unsigned short*>(lds + bo - 2) : 0u;
+        const u32x4 sh = u32x4{(f.x << 16) | prev, __builtin_amdgcn_alignbit(f.y, f.x, 16), __builtin_amdgcn_alignbit(f.z, f.y, 16), __builtin_amdgcn_alignbit(f.w, f.z, 16)};
+        qb[p] = shifted ? sh : f;
+      }
+#pragma unroll
+      for (int ord = SPLIT - 1; ord >= 0; --ord)
+#pragma unroll
+        for (int sa = 0; sa <= ord; ++sa)
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, qa[sa]), __builtin_bit_cast(bf16x8, qb[ord - sa]), acc, 0, 0, 0);
+    }
+  };
+#pragma unroll 1
+  for (int n = n0; n < n1; n += 3) {
+    frame(n, 0);
+    if (n + 1 < n1) frame(n + 1, 1);
+    if (n + 2 < n1) frame(n + 2, 2);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped requests of the last frames
+
+  // bias sums: `a` item j of this thread belongs to channel tid / 256 + 2 j: four waves per channel, met in LDS
+  float* const bred = reinterpret_cast<float*>(lds + LDSB);  // [item][wave]
+  if (dbias != nullptr) {
+    lds_barrier();  // the images are dead
+#pragma unroll
+    for (int j = 0; j < AI; ++j) {
+      const float v = wave_sum(bsum[j]);
+      if (lane == 0) bred[j * 8 + wave] = v;
+    }
+    lds_barrier();
+  }
+  if (part) {
+    float* const set = part + (size_t)blockIdx.x * kWgThinSetFloats;
+    reinterpret_cast<float4*>(set)[wave * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);  // rows 4 kl + 0 .. 3
+    if (dbias != nullptr && tid < 8) {
+      const int j = tid >> 1, w0 = 4 * (tid & 1);  // channel tid = w0 / 4 + 2 j
+      set[8 * 64 * 4 + tid] = (bred[j * 8 + w0] + bred[j * 8 + w0 + 1]) + (bred[j * 8 + w0 + 2] + bred[j * 8 + w0 + 3]);
+    }
+  } else {
+    if (il < 27) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(&dwp[((size_t)(4 * kl + r) * 9 + tap) * g.Cpad + ch], acc[r]);
+    }
+    if (dbias != nullptr && tid < 8) {
+      const int j = tid >> 1, w0 = 4 * (tid & 1);
+      atomicAdd(&dbias[tid], (bred[j * 8 + w0] + bred[j * 8 + w0 + 1]) + (bred[j * 8 + w0 + 2] + bred[j * 8 + w0 + 3]));
+    }
+  }
+}
+
+// Partial sets of conv3x3s2_thin_wgrad_staged_kernel into dwp / dbias: one tile, eight k-parts per workgroup.
+__global__ __launch_bounds__(256) void wgrad_reduce_partials_thin_kernel(const float4* __restrict__ part, const int S, const int cpad,
+                                                                         float* __restrict__ dwp, float* __restrict__ dbias) {
+  constexpr int SET4 = kWgThinSetFloats / 4, NL = 8, NG = 32;
+  __shared__ float4 red[NG][NL];
+  const int li = threadIdx.x & (NL - 1), sg = threadIdx.x / NL;
+  const int f = blockIdx.x * NL + li;  // lane's float4 (64 of them: 8 blocks), then the bias block (2 float4 used)
+  const bool bias = f >= 64;           // block-uniform
+  float4 acc4[2];
+  acc4[0] = acc4[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!(bias && f >= 66)) {
+    const int ks = bias ? 1 : 8;
+    const int slices = S * ks;  // slice i = (workgroup i / ks, wave i % ks)
+    const float4* const p = part + (bias ? (size_t)(8 * 64 + (f - 64)) : (size_t)f);
+    int i = sg;
+    for (; i + NG < slices; i += 2 * NG) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int ii = i + NG * u;
+        const float4 v = p[(size_t)(ii / ks) * SET4 + (size_t)(ii % ks) * 64];
+        acc4[u].x += v.x; acc4[u].y += v.y; acc4[u].z += v.z; acc4[u].w += v.w;
+      }
+    }
+    for (; i < slices; i += NG) {
+      const float4 v = p[(size_t)(i / ks) * SET4 + (size_t)(i % ks) * 64];
+      acc4[0].x += v.x; acc4[0].y += v.y; acc4[0].z += v.z; acc4[0].w += v.w;
+    }
+  }
+  red[sg][li] = make_float4(acc4[0].x + acc4[1].x, acc4[0].y + acc4[1].y, acc4[0].z + acc4[1].z, acc4[0].w + acc4[1].w);
+  __syncthreads();
+  if (sg == 0) {
+    float4 v = red[0][li];
+#pragma unroll
+    for (int k = 1; k < NG; ++k) { v.x += red[k][li].x; v.y += red[k][li].y; v.z += red[k][li].z; v.w += red[k][li].w; }
+    if (bias) {
+      if (f < 66) { float* const o = dbias + 4 * (f - 64); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
+      return;
+    }
+    const int il = f & 31, kl = f >> 5;
+    if (il < 27) {
+      const int tap = il / 3, ch = il - 3 * tap;
+      float* const o = dwp + ((size_t)(4 * kl) * 9 + tap) * cpad + ch;
+      const size_t rs = (size_t)9 * cpad;
+      o[0] += v.x; o[rs] += v.y; o[2 * rs] += v.z; o[3 * rs] += v.w;
+    }
+  }
+}
+
 }  // namespace mtrssm

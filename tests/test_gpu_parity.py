@@ -456,6 +456,8 @@ CONV_CASES = [
     (3, 8, 64, 16, 16, 3, 2, 1, True, False),   # second encoder layer, audio plane (32x8 output): staged stride-2 weight gradient (conv3x3s2_wgrad_staged_kernel<2, 8>); (2, 8, 32, 32, 16, ...) above is the vision plane (<2, 16>)
     (1500, 8, 32, 32, 16, 3, 2, 1, True, False),  # ... six frames per workgroup: the three raw register sets and both image buffers go round
     (700, 8, 64, 16, 16, 3, 2, 1, False, False),  # ... three frames per workgroup, no activation
+    (700, 1, 64, 64, 8, 3, 2, 1, True, True),   # first encoder layer, staged (conv3x3s2_thin_wgrad_staged_kernel<2, 32>): three frames per workgroup, activation on frame and coordinate channels; (4, 1, 64, 64, 8, ...) / (3, 1, 128, 32, 8, ...) above are its one-frame cases
+    (300, 1, 128, 32, 8, 3, 2, 1, False, True),  # ... audio plane (<2, 16>), two frames per workgroup
 ]
 
 
