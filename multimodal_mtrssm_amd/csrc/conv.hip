@@ -1672,6 +1672,37 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
       hipLaunchKernelGGL(wgrad_reduce_partials_thin_kernel, dim3(dbias ? 9 : 8), dim3(256), 0, stream, reinterpret_cast<const float4*>(part), (int)grid.x, g->Cpad, dwp, dbias);
     return launched("conv_weight_grad(3x3 s2 thin staged)");
   }
+  if ((g->mfma_split == 1 || g->mfma_split == 2) && g->KH == 4 && g->KW == 4 && g->SS == 2 && g->TS == 1 && g->OFFY == -1 && g->OFFX == -1 &&
+      g->C == 1 && g->C2 == 0 && g->Cout == 16 && g->Hq * g->Wq == 1024 && (g->Wq == 32 || g->Wq == 16) && g->Hs == 2 * g->Hq && g->Ws == 2 * g->Wq &&
+      g->Cpad >= 1 && !g->pre_act && !dbias && (g->act == MTRSSM_ACT_IDENTITY || g->act == MTRSSM_ACT_ELU || g->act == MTRSSM_ACT_RELU || !pre_act_a) &&
+      !((uintptr_t)a & 15) && !((uintptr_t)src & 15) && wgrad_s2_staged_enabled()) {
+    // the decoders' last ConvTranspose2d (k = 4 / stride 2, 16 -> 1, 1024-pixel input planes): operands staged once per frame
+    int wgs = cu_count();
+    if (wgs > g->N) wgs = g->N;
+    const int per = (g->N + wgs - 1) / wgs;
+    const dim3 grid((unsigned)((g->N + per - 1) / per));
+    float* const part = wgrad_partials_enabled() ? wgrad_scratch(stream, (size_t)grid.x * kWgThinTSetFloats * sizeof(float)) : nullptr;
+#define MTRSSM_WGTHINT_LAUNCH(SP_, W_)                                                                                           \
+  {                                                                                                                             \
+    static bool attr_done = false; /* once per instantiation: never while another stream may be running the kernel */       \
+    constexpr int lds_b = wgthint_lds_bytes<SP_, W_>();                                                                         \
+    if (!attr_done) {                                                                                                           \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convt4s2_thin_wgrad_staged_kernel<SP_, W_>),                       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);                                             \
+      attr_done = true;                                                                                                         \
+    }                                                                                                                           \
+    set_last_kernel("mtrssm::convt4s2_thin_wgrad_staged_kernel<" #SP_ ", " #W_ ">");                                             \
+    hipLaunchKernelGGL((convt4s2_thin_wgrad_staged_kernel<SP_, W_>), grid, dim3(512), lds_b, stream, *g, a, src, pre_act_a, dwp, \
+                       part, per);                                                                                              \
+  }
+    const int sp = g->mfma_split;
+    if (g->Wq == 32) { if (sp == 2) MTRSSM_WGTHINT_LAUNCH(2, 32) else MTRSSM_WGTHINT_LAUNCH(1, 32) }
+    else { if (sp == 2) MTRSSM_WGTHINT_LAUNCH(2, 16) else MTRSSM_WGTHINT_LAUNCH(1, 16) }
+#undef MTRSSM_WGTHINT_LAUNCH
+    if (part)
+      hipLaunchKernelGGL(wgrad_reduce_partials_thint_kernel, dim3(16), dim3(256), 0, stream, reinterpret_cast<const float4*>(part), (int)grid.x, g->Cpad, dwp);
+    return launched("conv_weight_grad(k4 s2 thin staged)");
+  }
   if (g->mfma_split >= 1 && g->Cout <= 32 && taps * ctot <= 32 && g->Wq >= 8 && (g->Wq & (g->Wq - 1)) == 0 && (g->Hq * g->Wq) % 16 == 0 &&
       !((uintptr_t)a & 15) && ptot < (1L << 31) && (long)g->N * g->C * g->Hs * g->Ws < (1L << 40) && !no_direct_wgrad()) {
     // thin strided layers: one MFMA tile, A straight from HBM, B gathered per lane (conv_split.h: conv_weight_grad_thin_split_kernel)

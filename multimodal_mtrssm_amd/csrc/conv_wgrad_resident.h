@@ -1463,4 +1463,189 @@ __global__ __launch_bounds__(256) void wgrad_reduce_partials_thin_kernel(const f
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of the decoders' LAST ConvTranspose2d (k = 4, stride 2, pad 1, 16 -> 1 channel; input planes of 1024
+// pixels: 32x32 vision, 64x16 audio): convt4s2_wgrad_staged_kernel on a thin layer.  `a` is the layer input (16 channels,
+// activated here), src the one-channel output gradient; 16 (tap) columns and 16 rows = a quarter of one MFMA tile, held by
+// all eight waves for eight of the frame's 64 k-steps each.  Partial set: float4 number (w * 2 + r / 4) * 64 + lane, r < 8.
+// ------------------------------------------------------------------------------------------------
+constexpr int kWgThinTSetFloats = 8 * 2 * 64 * 4;
+template <int WO>
+__host__ __device__ constexpr int wgthint_cip() { return (((1024 / WO * 2 + 2) * (2 * WO)) / 16 | 1) * 16; }
+template <int SPLIT, int WO>
+__host__ __device__ constexpr int wgthint_lds_bytes() { return SPLIT * (2 * wgthint_cip<WO>() + 16 * 2064); }
+
+template <int SPLIT, int WO>
+__global__ __launch_bounds__(512, 1) void convt4s2_thin_wgrad_staged_kernel(
+    const MtrssmConvGeom g, const float* __restrict__ a, const float* __restrict__ src, const int pre_act_a, float* __restrict__ dwp,
+    float* __restrict__ part, const int frames_per_wg) {
+  static_assert(SPLIT == 1 || SPLIT == 2, "one or two bf16 pieces");
+  static_assert(WO == 32 || WO == 16, "input plane 32x32 or 64x16");
+  constexpr int NT = 512, CO = 16, HO = 1024 / WO, HS = 2 * HO, WS = 2 * WO;
+  constexpr int ROWB = WS;                  // bytes per row of one parity image: WS / 2 bf16
+  constexpr int XCOPY = wgthint_cip<WO>();  // one parity image of one piece: (HS + 2) rows, padded
+  constexpr int AP = 2064, APB = CO * AP;   // `a` image: [ci][1024 pixels + 8] bf16
+  constexpr int XI = HS * WS / 4 / NT, AI = CO * 1024 / 4 / NT, NI = XI + AI;  // 2 + 8 float4 items per thread and frame
+  extern __shared__ __attribute__((aligned(16))) unsigned char wgthint_lds[];
+  unsigned char* const lds = wgthint_lds;   // [piece][even image][odd image] then [piece][a image]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int il = lane & 31, kl = lane >> 5;
+  const int n0 = blockIdx.x * frames_per_wg;
+  const int n1 = n0 + frames_per_wg < g.N ? n0 + frames_per_wg : g.N;
+  if (n0 >= n1) return;  // whole workgroup
+  const int nlast = n1 - 1;
+
+  const bool act_elu = g.act == MTRSSM_ACT_ELU, act_relu = g.act == MTRSSM_ACT_RELU, pre = pre_act_a != 0;
+  auto act_sel = [&](float x) __attribute__((always_inline)) {
+    float e = __expf(x) - 1.f;
+    asm volatile("" : "+v"(e));  // computed unconditionally: the compiler would branch around the exponential
+    const float neg = act_elu ? e : (act_relu ? 0.f : x);
+    return (x > 0.f || !pre) ? x : neg;
+  };
+
+  for (int o = tid * 16; o < wgthint_lds_bytes<SPLIT, WO>(); o += NT * 16) *reinterpret_cast<uint4*>(lds + o) = make_uint4(0u, 0u, 0u, 0u);
+
+  const float4* const xsrc = reinterpret_cast<const float4*>(src) + tid;
+  const float4* const asrc = reinterpret_cast<const float4*>(a) + tid;
+  constexpr size_t xfr = (size_t)HS * WS / 4, afr = (size_t)CO * 1024 / 4;  // float4 per frame
+  wg_f32x4 raw[3][NI];  // [set][a items, src items]
+  auto raw_load = [&](const int rs, const int n) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      const float4* const ptr = it < AI ? asrc + (size_t)n * afr + NT * it : xsrc + (size_t)n * xfr + NT * (it - AI);
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(raw[rs][it]) : "v"(ptr));
+    }
+  };
+  auto raw_wait = [&](const int rs) __attribute__((always_inline)) {  // the two younger sets may still be in flight
+    static_assert(NI == 10, "ten items");
+    asm volatile("s_waitcnt vmcnt(20)" : "+v"(raw[rs][0]), "+v"(raw[rs][1]), "+v"(raw[rs][2]), "+v"(raw[rs][3]), "+v"(raw[rs][4]), "+v"(raw[rs][5]),
+                 "+v"(raw[rs][6]), "+v"(raw[rs][7]), "+v"(raw[rs][8]), "+v"(raw[rs][9]));
+  };
+  auto stage = [&](const int rs) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      const wg_f32x4 v = raw[rs][it];
+      if (it < AI) {
+        unsigned d0[SPLIT], d1[SPLIT];
+        wg_split_pair<SPLIT>(act_sel(v.x), act_sel(v.y), d0);
+        wg_split_pair<SPLIT>(act_sel(v.z), act_sel(v.w), d1);
+        const int f = tid + NT * it;  // ci = f / 256, pixel = 4 (f % 256)
+        const unsigned o = (unsigned)(SPLIT * 2 * XCOPY) + (unsigned)((f >> 8) * AP + (f & 255) * 8);
+#pragma unroll
+        for (int p = 0; p < SPLIT; ++p) *reinterpret_cast<uint2*>(lds + o + p * APB) = make_uint2(d0[p], d1[p]);
+      } else {
+        unsigned de[SPLIT], dd[SPLIT];  // even columns (c0, c0 + 2), odd columns (c0 + 1, c0 + 3)
+        wg_split_pair<SPLIT>(v.x, v.z, de);
+        wg_split_pair<SPLIT>(v.y, v.w, dd);
+        const int f = tid + NT * (it - AI);
+        const int row = f / (WS / 4), c4 = f - row * (WS / 4);
+        const unsigned o = (unsigned)((row + 1) * ROWB + c4 * 4);
+#pragma unroll
+        for (int p = 0; p < SPLIT; ++p) {
+          *reinterpret_cast<unsigned*>(lds + o + p * 2 * XCOPY) = de[p];
+          *reinterpret_cast<unsigned*>(lds + o + p * 2 * XCOPY + XCOPY) = dd[p];
+        }
+      }
+    }
+  };
+
+  // the lane's column = tap il & 15 (lanes 16 .. 31 repeat the columns, never stored)
+  const int tap = il & 15, ky = tap >> 2, kx = tap & 3;
+  const bool odd = kx == 0 || kx == 2;
+  const unsigned lane_b = (unsigned)((odd ? XCOPY : 0) + ky * ROWB + kl * 16);
+  const unsigned lane_a = (unsigned)(SPLIT * 2 * XCOPY + (il & 15) * AP + kl * 16);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  raw_load(0, n0);
+  raw_load(1, n0 + 1 < nlast ? n0 + 1 : nlast);
+  auto frame = [&](const int n, const int rs) __attribute__((always_inline)) {  // rs = (n - n0) % 3, a literal at the call sites
+    raw_load((rs + 2) % 3, n + 2 < nlast ? n + 2 : nlast);  // its set held frame n - 1, staged a frame ago
+    raw_wait(rs);
+    lds_barrier();  // every wave is done reading the previous frame's images (first frame: the zeroes are in place)
+    stage(rs);
+    lds_barrier();  // images complete
+#pragma unroll
+    for (int ss = 0; ss < 8; ++ss) {
+      const int s = wave * 8 + ss;  // k-step: input pixels 16 s .. 16 s + 15; WO = 32: row s / 2, half s & 1; WO = 16: row s
+      const unsigned soff = WO == 32 ? (unsigned)((s >> 1) * 2 * ROWB + (s & 1) * 32) : (unsigned)(s * 2 * ROWB);
+      const bool has_prev = WO == 32 ? ((s & 1) | kl) != 0 : kl != 0;
+      const bool has_next = WO == 32 ? ((s & 1) & kl) == 0 : kl == 0;
+      u32x4 qa[SPLIT], qb[SPLIT];
+#pragma unroll
+      for (int p = 0; p < SPLIT; ++p) {
+        qa[p] = *reinterpret_cast<const u32x4*>(lds + lane_a + (unsigned)(p * APB) + (unsigned)(s * 32));
+        const unsigned bo = lane_b + (unsigned)(p * 2 * XCOPY) + soff;
+        const u32x4 f = *reinterpret_cast<const u32x4*>(lds + bo);
+        const unsigned prev = has_prev ? (unsigned)*reinterpret_cast<const unsigned short*>(lds + bo - 2) : 0u;
+        const unsigned next = has_next ? (unsigned)*reinterpret_cast<const unsigned short*>(lds + bo + 16) : 0u;
+        const u32x4 shr = u32x4{(f.x << 16) | prev, __builtin_amdgcn_alignbit(f.y, f.x, 16), __builtin_amdgcn_alignbit(f.z, f.y, 16), __builtin_amdgcn_alignbit(f.w, f.z, 16)};
+        const u32x4 shl = u32x4{__builtin_amdgcn_alignbit(f.y, f.x, 16), __builtin_amdgcn_alignbit(f.z, f.y, 16), __builtin_amdgcn_alignbit(f.w, f.z, 16), (f.w >> 16) | (next << 16)};
+        qb[p] = kx == 0 ? shr : (kx == 3 ? shl : f);
+      }
+#pragma unroll
+      for (int ord = SPLIT - 1; ord >= 0; --ord)
+#pragma unroll
+        for (int sa = 0; sa <= ord; ++sa)
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, qa[sa]), __builtin_bit_cast(bf16x8, qb[ord - sa]), acc, 0, 0, 0);
+    }
+  };
+#pragma unroll 1
+  for (int n = n0; n < n1; n += 3) {
+    frame(n, 0);
+    if (n + 1 < n1) frame(n + 1, 1);
+    if (n + 2 < n1) frame(n + 2, 2);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped requests of the last frames
+
+  if (part) {
+    float4* const ps = reinterpret_cast<float4*>(part) + (size_t)blockIdx.x * (kWgThinTSetFloats / 4) + (size_t)wave * 128 + lane;
+    ps[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);   // rows 4 kl + 0 .. 3
+    ps[64] = make_float4(acc[4], acc[5], acc[6], acc[7]);  // rows 8 + 4 kl + 0 .. 3
+  } else if (il < 16) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) atomicAdd(&dwp[((size_t)((r & 3) + 8 * (r >> 2) + 4 * kl) * 16 + tap) * g.Cpad], acc[r]);
+  }
+}
+
+// Partial sets of convt4s2_thin_wgrad_staged_kernel into dwp: one tile, eight k-parts per workgroup.
+__global__ __launch_bounds__(256) void wgrad_reduce_partials_thint_kernel(const float4* __restrict__ part, const int S, const int cpad,
+                                                                          float* __restrict__ dwp) {
+  constexpr int SET4 = kWgThinTSetFloats / 4, NL = 8, NG = 32;
+  __shared__ float4 red[NG][NL];
+  const int li = threadIdx.x & (NL - 1), sg = threadIdx.x / NL;
+  const int f = blockIdx.x * NL + li;  // half * 64 + lane: 128 of them (host: 16 blocks)
+  const float4* const p = part + f;
+  float4 acc4[2];
+  acc4[0] = acc4[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int slices = S * 8;  // slice i = (workgroup i / 8, wave i % 8)
+  int i = sg;
+  for (; i + NG < slices; i += 2 * NG) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int ii = i + NG * u;
+      const float4 v = p[(size_t)(ii >> 3) * SET4 + (size_t)(ii & 7) * 128];
+      acc4[u].x += v.x; acc4[u].y += v.y; acc4[u].z += v.z; acc4[u].w += v.w;
+    }
+  }
+  for (; i < slices; i += NG) {
+    const float4 v = p[(size_t)(i >> 3) * SET4 + (size_t)(i & 7) * 128];
+    acc4[0].x += v.x; acc4[0].y += v.y; acc4[0].z += v.z; acc4[0].w += v.w;
+  }
+  red[sg][li] = make_float4(acc4[0].x + acc4[1].x, acc4[0].y + acc4[1].y, acc4[0].z + acc4[1].z, acc4[0].w + acc4[1].w);
+  __syncthreads();
+  if (sg == 0) {
+    float4 v = red[0][li];
+#pragma unroll
+    for (int k = 1; k < NG; ++k) { v.x += red[k][li].x; v.y += red[k][li].y; v.z += red[k][li].z; v.w += red[k][li].w; }
+    const int half = f >> 6, lane = f & 63, il = lane & 31, kl = lane >> 5;
+    if (il < 16) {
+      float* const o = dwp + ((size_t)(8 * half + 4 * kl) * 16 + il) * cpad;
+      const size_t rs = (size_t)16 * cpad;
+      o[0] += v.x; o[rs] += v.y; o[2 * rs] += v.z; o[3 * rs] += v.w;
+    }
+  }
+}
+
 }  // namespace mtrssm

@@ -524,6 +524,8 @@ DECONV_CASES = [
     (300, 32, 32, 8, 16, 4, 2, 1, 0, False),  # ... two frames per workgroup (the last ones one), no activation
     (700, 64, 8, 8, 32, 4, 2, 1, 0, True),    # first decoder layer (convt4s2b_wgrad_staged_kernel<2, 8>): three frames per workgroup; (3, 64, 8, 8, 32, ...) and (5, 64, 16, 4, 32, ...) above are its one-frame cases (<2, 8>, <2, 4>)
     (300, 64, 16, 4, 32, 4, 2, 1, 0, False),  # ... audio plane, two frames per workgroup, no activation
+    (700, 16, 32, 32, 1, 4, 2, 1, 0, True),   # last decoder layer, staged weight gradient (convt4s2_thin_wgrad_staged_kernel<2, 32>): three frames per workgroup; (2, 16, 32, 32, 1, ...) and (2, 16, 64, 16, 1, ...) above are its one-frame cases
+    (300, 16, 64, 16, 1, 4, 2, 1, 0, False),  # ... audio plane (<2, 16>), two frames per workgroup, no activation
 ]
 
 
