@@ -1814,6 +1814,30 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
       hipLaunchKernelGGL(wgrad_reduce_partials_t4b_kernel, dim3(kWgT4bSetFloats / 4 / 8), dim3(256), 0, stream, reinterpret_cast<const float4*>(part), (int)grid.x, g->Cpad, dwp);
     return launched("conv_weight_grad(k4 s2 staged, 64 rows)");
   }
+  if ((g->mfma_split == 1 || g->mfma_split == 2) && g->KH == 3 && g->KW == 3 && g->SS == 2 && g->TS == 1 && g->OFFY == -1 && g->OFFX == -1 &&
+      g->C2 == 0 && g->C == 16 && g->Cout == 32 && g->Hq * g->Wq == 64 && (g->Wq == 8 || g->Wq == 4) && g->Hs == 2 * g->Hq && g->Ws == 2 * g->Wq &&
+      g->Cpad >= 16 && !pre_act_a && (g->act == MTRSSM_ACT_IDENTITY || g->act == MTRSSM_ACT_ELU || g->act == MTRSSM_ACT_RELU) &&
+      !((uintptr_t)a & 15) && !((uintptr_t)src & 15) && wgrad_s2_staged_enabled()) {
+    // third encoder layer (3x3 / stride 2, 16 -> 32, 64-pixel output planes): operands staged once per frame
+    int wgs = cu_count();
+    if (wgs > g->N) wgs = g->N;
+    const int per = (g->N + wgs - 1) / wgs;
+    const dim3 grid((unsigned)((g->N + per - 1) / per));
+    float* const part = wgrad_partials_enabled() ? wgrad_scratch(stream, (size_t)grid.x * kWgS2cSetFloats * sizeof(float)) : nullptr;
+#define MTRSSM_WGS2C_LAUNCH(SP_, W_)                                                                                             \
+  {                                                                                                                             \
+    set_last_kernel("mtrssm::conv3x3s2c_wgrad_staged_kernel<" #SP_ ", " #W_ ">");                                                \
+    hipLaunchKernelGGL((conv3x3s2c_wgrad_staged_kernel<SP_, W_>), grid, dim3(512), wgs2c_lds_bytes<SP_>(), stream, *g, a, src,   \
+                       dwp, part, dbias, per);                                                                                  \
+  }
+    const int sp = g->mfma_split;
+    if (g->Wq == 8) { if (sp == 2) MTRSSM_WGS2C_LAUNCH(2, 8) else MTRSSM_WGS2C_LAUNCH(1, 8) }
+    else { if (sp == 2) MTRSSM_WGS2C_LAUNCH(2, 4) else MTRSSM_WGS2C_LAUNCH(1, 4) }
+#undef MTRSSM_WGS2C_LAUNCH
+    if (part)
+      hipLaunchKernelGGL(wgrad_reduce_partials_s2c_kernel, dim3(dbias ? 161 : 160), dim3(256), 0, stream, reinterpret_cast<const float4*>(part), (int)grid.x, g->Cpad, dwp, dbias);
+    return launched("conv_weight_grad(3x3 s2 staged, 16 -> 32)");
+  }
   // ---- patch-staged kernel when the 64-pixel groups tile the frames exactly
   if (g->TS == 1 && g->Wq <= kGP && kGP % g->Wq == 0) {
     const PatchGeom pg(*g, kGP);

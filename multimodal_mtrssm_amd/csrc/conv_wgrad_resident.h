@@ -1648,4 +1648,214 @@ __global__ __launch_bounds__(256) void wgrad_reduce_partials_thint_kernel(const 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// ... and of the THIRD encoder layer (3x3 / stride 2 / pad 1, 16 -> 32 channels, 64-pixel output planes: 8x8 vision, 16x4
+// audio): 144 (tap, ci) columns in five 32-column tiles (waves 0 - 4, the rest only stage), all 32 rows, four k-steps per
+// frame.  A lane's 8 output pixels are one whole row (8x8) or two whole rows (16x4: two 8-byte reads two image rows apart),
+// so kx = 0 is a funnel shift with zeros.  Partial set: float4 number (w * 4 + r / 4) * 64 + lane, + 32 bias sums.
+// ------------------------------------------------------------------------------------------------
+constexpr int kWgS2cSetFloats = 8 * 4 * 64 * 4 + 32;
+template <int SPLIT>
+__host__ __device__ constexpr int wgs2c_lds_bytes() { return SPLIT * (2 * 16 * 272 + 32 * kWgresAPitch); }
+
+template <int SPLIT, int WO>
+__global__ __launch_bounds__(512, 1) void conv3x3s2c_wgrad_staged_kernel(
+    const MtrssmConvGeom g, const float* __restrict__ a, const float* __restrict__ src, float* __restrict__ dwp,
+    float* __restrict__ part, float* __restrict__ dbias, const int frames_per_wg) {
+  static_assert(SPLIT == 1 || SPLIT == 2, "one or two bf16 pieces");
+  static_assert(WO == 8 || WO == 4, "output plane 8x8 or 16x4");
+  constexpr int NT = 512, C = 16, CO = 32, HO = 64 / WO, HS = 2 * HO, WS = 2 * WO;
+  constexpr int ROWB = WS;                 // bytes per row of one parity image: WS / 2 bf16
+  constexpr int CIP = 272;                 // bytes per channel: (HS + 1) rows (272 / 264 bytes), an odd number of 16-byte slots
+  static_assert((HS + 1) * ROWB <= CIP, "channel pitch");
+  constexpr int XCOPY = C * CIP;           // one parity image of one piece
+  constexpr int AP = kWgresAPitch, APB = CO * AP;  // `a` image: [co][64 pixels + 8] bf16
+  constexpr int XI = C * HS * WS / 4 / NT, AI = CO * 64 / 4 / NT, NI = XI + AI;  // 2 + 1 float4 items per thread and frame
+  extern __shared__ __attribute__((aligned(16))) unsigned char wgs2c_lds[];
+  unsigned char* const lds = wgs2c_lds;    // [piece][even image][odd image] then [piece][a image]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int il = lane & 31, kl = lane >> 5;
+  const int n0 = blockIdx.x * frames_per_wg;
+  const int n1 = n0 + frames_per_wg < g.N ? n0 + frames_per_wg : g.N;
+  if (n0 >= n1) return;  // whole workgroup
+  const int nlast = n1 - 1;
+
+  const bool act_elu = g.act == MTRSSM_ACT_ELU, act_relu = g.act == MTRSSM_ACT_RELU, pre = g.pre_act != 0;
+  auto act_sel = [&](float x) __attribute__((always_inline)) {
+    float e = __expf(x) - 1.f;
+    asm volatile("" : "+v"(e));  // computed unconditionally: the compiler would branch around the exponential
+    const float neg = act_elu ? e : (act_relu ? 0.f : x);
+    return (x > 0.f || !pre) ? x : neg;
+  };
+
+  for (int o = tid * 16; o < wgs2c_lds_bytes<SPLIT>(); o += NT * 16) *reinterpret_cast<uint4*>(lds + o) = make_uint4(0u, 0u, 0u, 0u);
+
+  const float4* const xsrc = reinterpret_cast<const float4*>(src) + tid;
+  const float4* const asrc = reinterpret_cast<const float4*>(a) + tid;
+  constexpr size_t xfr = (size_t)C * HS * WS / 4, afr = (size_t)CO * 64 / 4;  // float4 per frame
+  float bsum = 0.f;  // this thread's share of channel tid / 16
+  wg_f32x4 raw[3][NI];  // [set][a item, src items]
+  auto raw_load = [&](const int rs, const int n) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      const float4* const ptr = it < AI ? asrc + (size_t)n * afr + NT * it : xsrc + (size_t)n * xfr + NT * (it - AI);
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(raw[rs][it]) : "v"(ptr));
+    }
+  };
+  auto raw_wait = [&](const int rs) __attribute__((always_inline)) {  // the two younger sets may still be in flight
+    static_assert(NI == 3, "three items");
+    asm volatile("s_waitcnt vmcnt(6)" : "+v"(raw[rs][0]), "+v"(raw[rs][1]), "+v"(raw[rs][2]));
+  };
+  auto stage = [&](const int rs) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      const wg_f32x4 v = raw[rs][it];
+      if (it < AI) {
+        bsum += (v.x + v.y) + (v.z + v.w);
+        unsigned d0[SPLIT], d1[SPLIT];
+        wg_split_pair<SPLIT>(v.x, v.y, d0);
+        wg_split_pair<SPLIT>(v.z, v.w, d1);
+        const unsigned o = (unsigned)(SPLIT * 2 * XCOPY) + (unsigned)((tid >> 4) * AP + (tid & 15) * 8);
+#pragma unroll
+        for (int p = 0; p < SPLIT; ++p) *reinterpret_cast<uint2*>(lds + o + p * APB) = make_uint2(d0[p], d1[p]);
+      } else {
+        unsigned de[SPLIT], dd[SPLIT];  // even columns (c0, c0 + 2), odd columns (c0 + 1, c0 + 3)
+        wg_split_pair<SPLIT>(act_sel(v.x), act_sel(v.z), de);
+        wg_split_pair<SPLIT>(act_sel(v.y), act_sel(v.w), dd);
+        const int f = tid + NT * (it - AI);
+        const int ci = f / (HS * WS / 4), rem = f - ci * (HS * WS / 4), row = rem / (WS / 4), c4 = rem - row * (WS / 4);
+        const unsigned o = (unsigned)(ci * CIP + (row + 1) * ROWB + c4 * 4);
+#pragma unroll
+        for (int p = 0; p < SPLIT; ++p) {
+          *reinterpret_cast<unsigned*>(lds + o + p * 2 * XCOPY) = de[p];
+          *reinterpret_cast<unsigned*>(lds + o + p * 2 * XCOPY + XCOPY) = dd[p];
+        }
+      }
+    }
+  };
+
+  // the lane's column: (tap, ci) = (col >> 4, col & 15); columns 144 .. 159 of tile 4 are padding (computed on column 143)
+  const int col = wave * 32 + il, colc = col < 144 ? col : 143;
+  const int tap = colc >> 4, ci = colc & 15, ky = tap / 3, kx = tap - 3 * ky;
+  // k-step s covers output pixels 16 s .. 16 s + 15, this lane 8 of them: WO = 8: row 2 s + kl; WO = 4: rows 4 s + 2 kl, + 1
+  const unsigned lane_b = (unsigned)((kx == 1 ? 0 : XCOPY) + ci * CIP + ky * ROWB + kl * (WO == 8 ? 2 * ROWB : 4 * ROWB));
+  constexpr unsigned kStepB = WO == 8 ? 4 * ROWB : 8 * ROWB;
+  const unsigned lane_a = (unsigned)(SPLIT * 2 * XCOPY + il * AP + kl * 16);
+  const bool shifted = kx == 0;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  raw_load(0, n0);
+  raw_load(1, n0 + 1 < nlast ? n0 + 1 : nlast);
+  auto frame = [&](const int n, const int rs) __attribute__((always_inline)) {  // rs = (n - n0) % 3, a literal at the call sites
+    raw_load((rs + 2) % 3, n + 2 < nlast ? n + 2 : nlast);  // its set held frame n - 1, staged a frame ago
+    raw_wait(rs);
+    lds_barrier();  // every wave is done reading the previous frame's images (first frame: the zeroes are in place)
+    stage(rs);
+    lds_barrier();  // images complete
+    if (wave < 5) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        u32x4 qa[SPLIT], qb[SPLIT];
+#pragma unroll
+        for (int p = 0; p < SPLIT; ++p) {
+          qa[p] = *reinterpret_cast<const u32x4*>(lds + lane_a + (unsigned)(p * APB) + (unsigned)(s * 32));
+          const unsigned bo = lane_b + (unsigned)(p * 2 * XCOPY) + (unsigned)s * kStepB;
+          u32x4 f;
+          if (WO == 8) {
+            f = *reinterpret_cast<const u32x4*>(lds + bo);
+          } else {
+            const uint2 r0 = *reinterpret_cast<const uint2*>(lds + bo), r1 = *reinterpret_cast<const uint2*>(lds + bo + 2 * ROWB);
+            f = u32x4{r0.x, r0.y, r1.x, r1.y};
+          }
+          const u32x4 sh = WO == 8 ? u32x4{f.x << 16, __builtin_amdgcn_alignbit(f.y, f.x, 16), __builtin_amdgcn_alignbit(f.z, f.y, 16), __builtin_amdgcn_alignbit(f.w, f.z, 16)}
+                                   : u32x4{f.x << 16, __builtin_amdgcn_alignbit(f.y, f.x, 16), f.z << 16, __builtin_amdgcn_alignbit(f.w, f.z, 16)};
+          qb[p] = shifted ? sh : f;
+        }
+#pragma unroll
+        for (int ord = SPLIT - 1; ord >= 0; --ord)
+#pragma unroll
+          for (int sa = 0; sa <= ord; ++sa)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, qa[sa]), __builtin_bit_cast(bf16x8, qb[ord - sa]), acc, 0, 0, 0);
+      }
+    }
+  };
+#pragma unroll 1
+  for (int n = n0; n < n1; n += 3) {
+    frame(n, 0);
+    if (n + 1 < n1) frame(n + 1, 1);
+    if (n + 2 < n1) frame(n + 2, 2);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped requests of the last frames
+
+  float bv = bsum;  // the 16 lanes of a DPP row share channel tid / 16
+  bv += dpp_move<0xB1, 0xF>(0.f, bv);
+  bv += dpp_move<0x4E, 0xF>(0.f, bv);
+  bv += dpp_move<0x141, 0xF>(0.f, bv);
+  bv += dpp_move<0x140, 0xF>(0.f, bv);
+  if (part) {
+    float* const set = part + (size_t)blockIdx.x * kWgS2cSetFloats;
+    if (wave < 5) {
+      float4* const ps = reinterpret_cast<float4*>(set) + (size_t)wave * 256 + lane;
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) ps[gq * 64] = make_float4(acc[4 * gq], acc[4 * gq + 1], acc[4 * gq + 2], acc[4 * gq + 3]);
+    }
+    if (dbias != nullptr && (tid & 15) == 0) set[8 * 4 * 64 * 4 + (tid >> 4)] = bv;
+  } else {
+    if (wave < 5 && col < 144) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) atomicAdd(&dwp[((size_t)((r & 3) + 8 * (r >> 2) + 4 * kl) * 9 + tap) * g.Cpad + ci], acc[r]);
+    }
+    if (dbias != nullptr && (tid & 15) == 0) atomicAdd(&dbias[tid >> 4], bv);
+  }
+}
+
+// Partial sets of conv3x3s2c_wgrad_staged_kernel into dwp / dbias.
+__global__ __launch_bounds__(256) void wgrad_reduce_partials_s2c_kernel(const float4* __restrict__ part, const int S, const int cpad,
+                                                                        float* __restrict__ dwp, float* __restrict__ dbias) {
+  constexpr int SET4 = kWgS2cSetFloats / 4, NL = 8, NG = 32;
+  __shared__ float4 red[NG][NL];
+  const int li = threadIdx.x & (NL - 1), sg = threadIdx.x / NL;
+  const int f = blockIdx.x * NL + li;  // float4 of the five column tiles: 1280 (160 blocks), then 8 bias float4 (one block)
+  const bool bias = f >= 1280;         // block-uniform
+  const float4* const p = part + (bias ? (size_t)(8 * 256 + (f - 1280)) : (size_t)f);
+  float4 acc4[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) acc4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  int s = sg;
+  for (; s + 3 * NG < S; s += 4 * NG) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float4 v = p[(size_t)(s + NG * u) * SET4];
+      acc4[u].x += v.x; acc4[u].y += v.y; acc4[u].z += v.z; acc4[u].w += v.w;
+    }
+  }
+  for (; s < S; s += NG) {
+    const float4 v = p[(size_t)s * SET4];
+    acc4[0].x += v.x; acc4[0].y += v.y; acc4[0].z += v.z; acc4[0].w += v.w;
+  }
+  red[sg][li] = make_float4((acc4[0].x + acc4[1].x) + (acc4[2].x + acc4[3].x), (acc4[0].y + acc4[1].y) + (acc4[2].y + acc4[3].y),
+                            (acc4[0].z + acc4[1].z) + (acc4[2].z + acc4[3].z), (acc4[0].w + acc4[1].w) + (acc4[2].w + acc4[3].w));
+  __syncthreads();
+  if (sg == 0) {
+    float4 v = red[0][li];
+#pragma unroll
+    for (int k = 1; k < NG; ++k) { v.x += red[k][li].x; v.y += red[k][li].y; v.z += red[k][li].z; v.w += red[k][li].w; }
+    if (bias) {
+      float* const o = dbias + 4 * (f - 1280);
+      o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w;
+      return;
+    }
+    const int lane = f & 63, gq = (f >> 6) & 3, wave = f >> 8, il = lane & 31, kl = lane >> 5;
+    const int col = wave * 32 + il;
+    if (col < 144) {
+      const int tap = col >> 4, ci = col & 15, row = 8 * gq + 4 * kl;
+      float* const o = dwp + ((size_t)row * 9 + tap) * cpad + ci;
+      const size_t rs = (size_t)9 * cpad;
+      o[0] += v.x; o[rs] += v.y; o[2 * rs] += v.z; o[3 * rs] += v.w;
+    }
+  }
+}
+
 }  // namespace mtrssm

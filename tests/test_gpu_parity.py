@@ -458,6 +458,9 @@ CONV_CASES = [
     (700, 8, 64, 16, 16, 3, 2, 1, False, False),  # ... three frames per workgroup, no activation
     (700, 1, 64, 64, 8, 3, 2, 1, True, True),   # first encoder layer, staged (conv3x3s2_thin_wgrad_staged_kernel<2, 32>): three frames per workgroup, activation on frame and coordinate channels; (4, 1, 64, 64, 8, ...) / (3, 1, 128, 32, 8, ...) above are its one-frame cases
     (300, 1, 128, 32, 8, 3, 2, 1, False, True),  # ... audio plane (<2, 16>), two frames per workgroup
+    (700, 16, 16, 16, 32, 3, 2, 1, True, False),  # third encoder layer, staged (conv3x3s2c_wgrad_staged_kernel<2, 8>): three frames per workgroup; (3, 16, 16, 16, 32, ...) above is its one-frame case
+    (300, 16, 32, 8, 32, 3, 2, 1, False, False),  # ... audio plane (16x4 output, <2, 4>), two frames per workgroup, no activation
+    (5, 16, 32, 8, 32, 3, 2, 1, True, False),   # ... one frame per workgroup
 ]
 
 
