@@ -372,7 +372,7 @@ int mtrssm_mmtrssm_rollout_bwd(const MtrssmMmtrssmDims* dims, const MtrssmMmtrss
  * wp is the packed weight matrix [CoutPad][KH*KW][Cpad], zero padded (Cpad % 16 == 0, CoutPad % 32 == 0,
  * CoutPad % 64 == 0 when Cout > 32), 16-byte aligned; wq: its bf16 pieces (see mtrssm_pack_conv_weight), 16-byte aligned, or NULL.
  *
- * mtrssm_conv_weight_grad accumulates (atomically; the caller zeroes dwp)
+ * mtrssm_conv_weight_grad accumulates (the caller zeroes dwp)
  *   dwp[co][ty*KW+tx][c] += sum_{n, y<Hq, x<Wq} preA(a[n,co,y,x]) * pre(S[n,c,y*SS+ty*TS+OFFY,x*SS+tx*TS+OFFX])
  * with a of shape [N, Cout, Hq, Wq] (geometry must have OS=1, QY=QX=0).  When dbias != NULL (allowed only with
  * pre_act_a == 0) it also accumulates the bias gradient dbias[co] += sum_{n,y,x} a[n,co,y,x] in the same pass.
@@ -380,8 +380,17 @@ int mtrssm_mmtrssm_rollout_bwd(const MtrssmMmtrssmDims* dims, const MtrssmMmtrss
  * planes read both operands straight from HBM into the MFMA register layout (k = pixels is contiguous in NCHW); layers with
  * <= 32 output channels and <= 32 (tap, channel) columns on power-of-two-wide planes run one MFMA tile with a per-lane
  * gathered operand; everything else stages 64-pixel groups through LDS (persistent workgroups); mfma_split = 0 and odd
- * geometries use the fp32 kernels of csrc/conv.hip.  All of them accumulate with fp32 atomics: results are equal up to the
+ * geometries use the fp32 kernels of csrc/conv.hip.  Those accumulate with fp32 atomics: results are equal up to the
  * arrival order of the partial sums.
+ * The layer shapes of the reference's default encoders / decoders (mfma_split 1 or 2, pre_act_a as those layers set it: the
+ * 3x3 and 1x1 layers of the residual stacks on 64-pixel planes, the three 3x3 / stride-2 convolutions, the three k = 4 /
+ * stride-2 transposed convolutions; csrc/conv_wgrad_resident.h) run staged kernels instead: every workgroup stores ONE
+ * partial set of its tiles and bias sums into a scratch buffer the library keeps per stream (hipMalloc on first use, 38 MB
+ * at those shapes, kept for the life of the process), and a second kernel on the same stream adds the sets to dwp / dbias by
+ * plain read-modify-write -- bitwise reproducible from run to run.  The caller must therefore not accumulate into the same
+ * dwp / dbias from ANOTHER stream at the same time (the atomics of the other kernels allowed that); calls on one stream
+ * are ordered.  A first call on a stream that is being captured finds no scratch buffer and takes the atomics form of the
+ * same kernels; MTRSSM_WGRAD_PARTIALS=0 selects that form always.
  * ------------------------------------------------------------------------------------------ */
 typedef struct MtrssmConvGeom {
   int32_t N;                    /* frames (B*T) */
