@@ -1,12 +1,19 @@
+// Staged weight-gradient kernels (included by conv.hip after conv_split.h): a workgroup per CU owns a run of frames, loads
+// every frame of both operands once, converts it once, keeps it in LDS for the MFMAs and leaves ONE partial set for a
+// reduce kernel.  In this file: the 3x3 / stride 1 layers of the residual stacks (first, with the reasoning), their 1x1
+// layers, the encoders' three 3x3 / stride-2 convolutions and the decoders' three k = 4 / stride-2 transposed convolutions.
+//
 // Weight gradient of the 3x3 / stride 1 / pad 1 layers of the residual stacks on 64-pixel planes (8x8 vision, 16x4 audio)
-// with BOTH operands staged once per frame (included by conv.hip after conv_split.h).
+// with BOTH operands staged once per frame.
 //
 //   dW[co][ty][tx][ci] = sum over frames n and pixels (y, x) of  a[n][co][y][x] * act(src)[n][ci][y + ty - 1][x + tx - 1]
 //
 // The register-direct kernel (conv_split.h: conv3x3_weight_grad_split_kernel) lets every lane load, activate and split its
 // own operands: each src element is fetched 2 (co tiles) x 3 (window rows) times by 16-byte loads that touch 32 cache lines
 // per instruction and is converted as often, each `a` element twice -- the kernel is VALU-bound (about 75 % of its issue
-// slots are conversions), and its 9.4 M fp32 atomics alone take ~60 us.  Here a workgroup owns a run of frames and
+// slots are conversions), and ~60 us of every launch pass after its loop (9.4 M fp32 atomics of the tiles, and -- the larger
+// part, see profiles/round2_notes.md -- the bias sums every workgroup adds to the same 64 addresses).  Here a workgroup
+// owns a run of frames and
 //   * loads every frame of `src` and of `a` ONCE, coalesced (consecutive lanes = consecutive 16 bytes), activates / splits
 //     it once and writes it to LDS: `a` as a plain [co][pixel] bf16 image, src as a channel-major image with a zero halo
 //     row between consecutive planes: a row tap (ty) is a 16-byte read at row offset ty, the column taps (tx) are funnel
