@@ -1487,8 +1487,8 @@ static bool wgrad_partials_enabled() {
   static const bool on = [] { const char* e = getenv("MTRSSM_WGRAD_PARTIALS"); return !(e && e[0] == '0'); }();
   return on;
 }
-// Scratch for the partial tile sets of conv3x3_wgrad_resident_kernel: one buffer per stream (launches of a stream reuse it
-// in order), grown on demand, kept for the life of the process (~38 MB at the bench shapes).  NULL when it cannot be
+// Scratch for the partial tile sets of the staged weight-gradient kernels: one buffer per stream (launches of a stream reuse
+// it in order), grown on demand, kept for the life of the process (~38 MB at the bench shapes).  NULL when it cannot be
 // provided -- the stream is being captured and the buffer is not there yet, or the allocation fails -- and the caller
 // falls back to atomics.
 static float* wgrad_scratch(hipStream_t stream, size_t bytes) {
@@ -1501,7 +1501,8 @@ static float* wgrad_scratch(hipStream_t stream, size_t bytes) {
   if (hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
   float* p = nullptr;
   if (hipMalloc(reinterpret_cast<void**>(&p), bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-  if (e.first) (void)hipFree(e.first);  // waits for the device: queued launches that read the old buffer are done
+  // the outgrown buffer is NOT freed: a captured graph of this stream may hold its address (replays would write freed
+  // memory); it stays allocated for the life of the process like the current one (sizes only grow, a few steps at most)
   e = {p, bytes};
   return p;
 }
