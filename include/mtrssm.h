@@ -129,9 +129,12 @@ int mtrssm_mrssm_rollout_fwd(const MtrssmMrssmDims* dims, const MtrssmMrssmFwdWe
  *   wf_t = w2_t . wih_t  ([H][3D] = (W_ih W2)^T),   bf = W_ih b2 + b_ih,
  * so sv_h2 is NOT written (recompute h2 = W2 h1 + b2 as one batched GEMM where dW_ih needs it).
  * workspace: caller-owned device memory of mtrssm_mrssm_cluster_workspace_bytes() bytes, 16-byte aligned; the call zeroes
- * it.  Its first int32 is a status word: 0 after a good launch, else the code of a spin that gave up (results invalid).
+ * everything but its first 16 bytes.  Its first int32 is a STICKY status word: the caller zeroes it once when allocating; a
+ * launch in which a spin gave up stores a non-zero code there (results invalid) and no launch clears it, so one check at any
+ * later synchronisation point sees every earlier failure (mtrssm_adamw_apply can be given the word: it then skips the update).
  * The grid is 4 x min(B, 64) workgroups that must be co-resident (one per CU): launch it on a GPU this process has to
- * itself.  mtrssm_mrssm_cluster_supported() says whether the dims fit this regime (else use mtrssm_mrssm_rollout_fwd). */
+ * itself.  mtrssm_mrssm_cluster_supported() says whether the dims AND the current device (CU count >= grid) fit this regime
+ * (else use mtrssm_mrssm_rollout_fwd). */
 typedef struct MtrssmMrssmClusterWeights {
   const float* w1s_t;  /* [S][H] */
   const float* wf_t;   /* [H][3D]  (W_ih W2)^T */
@@ -202,6 +205,26 @@ typedef struct MtrssmMrssmBwdIO {
 int64_t mtrssm_mrssm_cluster_bwd_workspace_bytes(const MtrssmMrssmDims* dims);
 int mtrssm_mrssm_rollout_bwd_cluster(const MtrssmMrssmDims* dims, const MtrssmMrssmClusterWeights* weights, const MtrssmMrssmBwdIO* io,
                                      void* workspace, int64_t workspace_bytes, void* stream);
+
+/* The same scans for LARGE deterministic / hidden sizes (D or H >= 256; BASELINE configs[4]: D = H = 1024, S = 128), ALL compute
+ * units of the chip on one tile of 32 batch rows (csrc/mrssm_wide.hip): every matrix product of a timestep is cut into
+ * 16-column output tiles, each streamed by one CU per step as bf16 pieces in MFMA operand order (packed by the call, once per
+ * launch), the batch rows are the MFMA N dimension (v_mfma_f32_16x16x32_bf16), consecutive layers meet through exchange vectors
+ * in L2 and a grid-wide barrier (4 per forward timestep, 5 per backward one).  pieces = 3: every fp32 operand as three bf16
+ * pieces, six products per k-block (exact to 2^-24: fp32-grade; the default of the Python layer); 2: two pieces, three products
+ * (16 significant bits).  Weights / fused input path / sv_h2 / d_h2 exactly as for the cluster calls above.
+ * workspace: caller-owned, 256-byte aligned, mtrssm_mrssm_wide_workspace_bytes() / _bwd_workspace_bytes() bytes.  Its first
+ * int32 is a STICKY status word: the caller zeroes it once when allocating; a launch whose barrier gave up stores a non-zero
+ * code there (results invalid) and no launch ever clears it (mtrssm_adamw_apply can be given the word and then skips the update).
+ * The grid is one workgroup per CU, all of which must be resident: a GPU this process has to itself.
+ * mtrssm_mrssm_wide_supported() = 1 when dims and device fit (D, H multiples of 16, K <= 64, D/16 + H/16 <= CU count). */
+int mtrssm_mrssm_wide_supported(const MtrssmMrssmDims* dims, int32_t pieces);
+int64_t mtrssm_mrssm_wide_workspace_bytes(const MtrssmMrssmDims* dims, int32_t pieces);
+int64_t mtrssm_mrssm_wide_bwd_workspace_bytes(const MtrssmMrssmDims* dims, int32_t pieces);
+int mtrssm_mrssm_rollout_fwd_wide(const MtrssmMrssmDims* dims, const MtrssmMrssmClusterWeights* weights, const MtrssmMrssmFwdIO* io,
+                                  int32_t pieces, void* workspace, int64_t workspace_bytes, void* stream);
+int mtrssm_mrssm_rollout_bwd_wide(const MtrssmMrssmDims* dims, const MtrssmMrssmClusterWeights* weights, const MtrssmMrssmBwdIO* io,
+                                  int32_t pieces, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Reverse-time scan (BPTT).  Weight gradients are NOT accumulated inside the serial loop: the
  * kernel emits the per-step pre-activation gradients above and the caller forms every dW as one
@@ -385,12 +408,12 @@ int mtrssm_mmtrssm_rollout_bwd(const MtrssmMmtrssmDims* dims, const MtrssmMmtrss
  * The layer shapes of the reference's default encoders / decoders (mfma_split 1 or 2, pre_act_a as those layers set it: the
  * 3x3 and 1x1 layers of the residual stacks on 64-pixel planes, the three 3x3 / stride-2 convolutions, the three k = 4 /
  * stride-2 transposed convolutions; csrc/conv_wgrad_resident.h) run staged kernels instead: every workgroup stores ONE
- * partial set of its tiles and bias sums into a scratch buffer the library keeps per stream (hipMalloc on first use, 38 MB
- * at those shapes, kept for the life of the process), and a second kernel on the same stream adds the sets to dwp / dbias by
- * plain read-modify-write -- bitwise reproducible from run to run.  The caller must therefore not accumulate into the same
- * dwp / dbias from ANOTHER stream at the same time (the atomics of the other kernels allowed that); calls on one stream
- * are ordered.  A first call on a stream that is being captured finds no scratch buffer and takes the atomics form of the
- * same kernels; MTRSSM_WGRAD_PARTIALS=0 selects that form always.
+ * partial set of its tiles and bias sums into `workspace` -- caller-owned device memory, 256-byte aligned, at least
+ * mtrssm_conv_weight_grad_workspace_bytes() bytes, free for reuse as soon as the call's kernels have run (calls on one stream may
+ * share one buffer) -- and a second kernel on the same stream adds the sets to dwp / dbias by plain read-modify-write: bitwise
+ * reproducible from run to run.  The caller must therefore not accumulate into the same dwp / dbias from ANOTHER stream at the
+ * same time (the atomics of the other kernels allow that); calls on one stream are ordered.  With workspace NULL or too small
+ * (and with MTRSSM_WGRAD_PARTIALS=0) the same kernels add their tiles by atomics.  The library itself allocates nothing.
  * ------------------------------------------------------------------------------------------ */
 typedef struct MtrssmConvGeom {
   int32_t N;                    /* frames (B*T) */
@@ -439,7 +462,10 @@ int mtrssm_pack_conv_weight(const float* w, int32_t O, int32_t I, int32_t KH, in
 #define MTRSSM_PACK_DESC_WORDS 16
 int mtrssm_pack_conv_weights(const int64_t* table, int32_t count, int32_t blocks_per_weight, void* stream);
 int mtrssm_conv_weight_grad(const MtrssmConvGeom* g, const float* a, const float* src, const float* src2,
-                            int32_t pre_act_a, float* dwp, float* dbias, void* stream);
+                            int32_t pre_act_a, float* dwp, float* dbias, void* workspace, int64_t workspace_bytes, void* stream);
+/* Bytes of workspace the kernel chosen for this geometry wants for its partial tile sets (0: none; -1: invalid geometry; up to
+ * ~38 MB for the reference's layer shapes at B*T = 3200 frames).  A host-side query, nothing is launched. */
+int64_t mtrssm_conv_weight_grad_workspace_bytes(const MtrssmConvGeom* g, int32_t pre_act_a);
 /* End of backward: add every packed conv weight gradient [OPad][taps][IPad] of the step into its parameter-layout target
  * [O][I][KH][KW] (a view of the flat gradient buffer) and clear the packed buffers, in ONE launch.  table (device memory):
  * `count` rows of 8 int64 = { packed pointer, target pointer, O, I, taps = KH*KW, IPad, 0, 0 }. */
@@ -520,10 +546,14 @@ int mtrssm_adamw_step(float* param, const float* grad, float* exp_avg, float* ex
  * captured train step records no memset node (a captured multi-megabyte hipMemsetAsync left foreign bytes at the buffer's head
  * on replay under ROCm 7.2). */
 int mtrssm_clear(void* p, int64_t bytes, void* stream);
-int mtrssm_adamw_prepare(const float* grad, int64_t n, float* sumsq, float* state, float beta1, float beta2, void* stream);
+/* status (device int32, may be NULL): the sticky status word of the step's cooperative scan kernels (first word of the workspace of
+ * mtrssm_mrssm_rollout_*_cluster / _wide).  Non-zero = an exchange of the step gave up, its gradients are invalid: prepare then
+ * does not count the step and apply leaves parameters and moments untouched (the host raises when it next polls the word). */
+int mtrssm_adamw_prepare(const float* grad, int64_t n, float* sumsq, float* state, const int32_t* status, float beta1, float beta2,
+                         void* stream);
 int mtrssm_adamw_apply(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const uint8_t* active, int64_t n,
-                       const float* sumsq, const float* state, float clip_norm, float grad_scale, float beta1, float beta2,
-                       float eps, float weight_decay, void* stream);
+                       const float* sumsq, const float* state, const int32_t* status, float clip_norm, float grad_scale, float beta1,
+                       float beta2, float eps, float weight_decay, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Dense fp32 GEMM on the fp32 MFMA with the elementwise neighbours fused in.  Replaces the nn.Linear / MLP calls around

@@ -93,6 +93,11 @@ SYMBOLS: dict[str, tuple[type | None, list[type]]] = {
     "mtrssm_mrssm_rollout_fwd_cluster": (C.c_int, [C.POINTER(MrssmDims), C.POINTER(MrssmClusterWeights), C.POINTER(MrssmFwdIO), _p, C.c_int64, _p]),
     "mtrssm_mrssm_cluster_bwd_workspace_bytes": (C.c_int64, [C.POINTER(MrssmDims)]),
     "mtrssm_mrssm_rollout_bwd_cluster": (C.c_int, [C.POINTER(MrssmDims), C.POINTER(MrssmClusterWeights), C.POINTER(MrssmBwdIO), _p, C.c_int64, _p]),
+    "mtrssm_mrssm_wide_supported": (C.c_int, [C.POINTER(MrssmDims), _i]),
+    "mtrssm_mrssm_wide_workspace_bytes": (C.c_int64, [C.POINTER(MrssmDims), _i]),
+    "mtrssm_mrssm_wide_bwd_workspace_bytes": (C.c_int64, [C.POINTER(MrssmDims), _i]),
+    "mtrssm_mrssm_rollout_fwd_wide": (C.c_int, [C.POINTER(MrssmDims), C.POINTER(MrssmClusterWeights), C.POINTER(MrssmFwdIO), _i, _p, C.c_int64, _p]),
+    "mtrssm_mrssm_rollout_bwd_wide": (C.c_int, [C.POINTER(MrssmDims), C.POINTER(MrssmClusterWeights), C.POINTER(MrssmBwdIO), _i, _p, C.c_int64, _p]),
     "mtrssm_mrssm_rollout_bwd": (C.c_int, [C.POINTER(MrssmDims), C.POINTER(MrssmBwdWeights), C.POINTER(MrssmBwdIO), _p]),
     "mtrssm_mmtrssm_rollout_fwd": (C.c_int, [C.POINTER(MmtrssmDims), C.POINTER(MmtrssmFwdWeights), C.POINTER(MmtrssmFwdIO), _p]),
     "mtrssm_mmtrssm_rollout_bwd": (C.c_int, [C.POINTER(MmtrssmDims), C.POINTER(MmtrssmBwdWeights), C.POINTER(MmtrssmBwdIO), _p]),
@@ -103,7 +108,8 @@ SYMBOLS: dict[str, tuple[type | None, list[type]]] = {
     "mtrssm_pack_conv_weight": (C.c_int, [_p, _i, _i, _i, _i, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _i, _i, _i, _p, _p, _p]),
     "mtrssm_pack_conv_weights": (C.c_int, [_p, _i, _i, _p]),
     "mtrssm_unpack_conv_grads": (C.c_int, [_p, _i, _i, _p]),
-    "mtrssm_conv_weight_grad": (C.c_int, [C.POINTER(ConvGeom), _p, _p, _p, _i, _p, _p, _p]),
+    "mtrssm_conv_weight_grad": (C.c_int, [C.POINTER(ConvGeom), _p, _p, _p, _i, _p, _p, _p, C.c_int64, _p]),
+    "mtrssm_conv_weight_grad_workspace_bytes": (C.c_int64, [C.POINTER(ConvGeom), _i]),
     "mtrssm_channel_sum": (C.c_int, [_p, _i, _i, _i, _p, _p]),
     "mtrssm_convt_k4s2_thin": (C.c_int, [_i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _p, _p]),
     "mtrssm_convt_quad_supported": (C.c_int, [C.POINTER(ConvGeom)]),
@@ -117,8 +123,8 @@ SYMBOLS: dict[str, tuple[type | None, list[type]]] = {
     "mtrssm_adamw_step": (C.c_int, [_p, _p, _p, _p, C.c_int64, _p, _f, _f, _f, _f, _f, _f, _f, _i, _p]),
     "mtrssm_gemm": (C.c_int, [C.POINTER(Gemm), _p]),
     "mtrssm_clear": (C.c_int, [_p, C.c_int64, _p]),
-    "mtrssm_adamw_prepare": (C.c_int, [_p, C.c_int64, _p, _p, _f, _f, _p]),
-    "mtrssm_adamw_apply": (C.c_int, [_p, _p, _p, _p, _p, C.c_int64, _p, _p, _f, _f, _f, _f, _f, _f, _p]),
+    "mtrssm_adamw_prepare": (C.c_int, [_p, C.c_int64, _p, _p, _p, _f, _f, _p]),
+    "mtrssm_adamw_apply": (C.c_int, [_p, _p, _p, _p, _p, C.c_int64, _p, _p, _p, _f, _f, _f, _f, _f, _f, _p]),
 }
 
 _LIB: C.CDLL | None = None

@@ -75,7 +75,7 @@ class _PackPlan:
         self.serial = 0
         self.table: Tensor | None = None
         self.table_serials: tuple = ()
-        self.pinned = False  # a captured graph reads the packed buffers: entries are never dropped then
+        self.pinned = 0  # live captured graphs reading the packed buffers: entries are never dropped while > 0
 
     def invalidate(self) -> None:
         self.epoch += 1
@@ -127,6 +127,7 @@ _PLAN = _PackPlan()
 
 def begin_step(device: torch.device) -> None:
     """Start of a train / validation step: pack every conv weight the previous step used, in one launch."""
+    _GRAD_SINK.discard()
     if PACK_PLAN and device.type == "cuda":
         _PLAN.begin_step(device)
 
@@ -442,6 +443,16 @@ class _ConvGradSink:
             torch.autograd.Variable._execution_engine.queue_callback(self.flush)  # noqa: SLF001
         return e[0]
 
+    def discard(self) -> None:
+        """A backward pass raised before autograd ran ``flush`` (its final callbacks are dropped then): the packed buffers hold
+        half-finished sums and ``pending`` would stay set for good -- every later backward would skip ``queue_callback`` and the
+        conv weights would silently stop receiving gradients.  Called at the next ``begin_step`` / ``zero_grad``: clear the
+        buffers and re-arm."""
+        if self.pending:
+            self.pending = False
+            for packed, _dst, _owner in self.entries.values():
+                packed.zero_()
+
     def flush(self) -> None:
         self.pending = False
         if any(v[2]() is None for v in self.entries.values()):
@@ -461,6 +472,18 @@ class _ConvGradSink:
 _GRAD_SINK = _ConvGradSink()
 
 
+def discard_pending_grads() -> None:
+    """Start of a step (``begin_step``, ``FlatParameters.zero_grad``): drop what a backward that raised left in the sink."""
+    _GRAD_SINK.discard()
+
+
+def flush_pending_grads() -> None:
+    """``FlatAdamW.step`` / ``FlatDataParallel.reduce``: gradients still parked in the sink (autograd never ran the flush
+    callback because the backward raised, and the caller went on) are added to the flat buffer before it is consumed."""
+    if _GRAD_SINK.pending:
+        _GRAD_SINK.flush()
+
+
 def reset_scratch(*, pin: bool = False) -> None:
     """Forget the partly used zeroed chunks (the next weight gradient opens a fresh one).  ``graph.CapturedTrainStep`` calls
     this right before and right after a capture: a chunk zeroed BEFORE the capture would come back dirty on the second
@@ -468,7 +491,36 @@ def reset_scratch(*, pin: bool = False) -> None:
     buffer of the step plan alive for good (the captured kernels read those addresses)."""
     _ZERO_CHUNKS.clear()
     if pin:
-        _PLAN.pinned = True
+        _PLAN.pinned += 1
+
+
+def unpin_scratch() -> None:
+    """The captured graph that asked for ``reset_scratch(pin=True)`` is gone: the step plan may drop entries again."""
+    _PLAN.pinned = max(0, _PLAN.pinned - 1)
+
+
+# Workspace of the staged weight-gradient kernels (their partial tile sets, include/mtrssm.h: mtrssm_conv_weight_grad): ONE
+# buffer per (device, stream), shared by every weight-gradient launch of that stream (they run in order), sized by the
+# library's own query, grown on demand.  Outgrown buffers are kept: a captured hipGraph may still hold their address.
+_WGRAD_WS: dict[tuple, Tensor] = {}
+_WGRAD_WS_RETIRED: list[Tensor] = []
+_WGRAD_NEED: dict[tuple, int] = {}
+
+
+def _wgrad_workspace(geom: C.Structure, pre_act_a: int, device: torch.device) -> Tensor | None:
+    gkey = (tuple(getattr(geom, n) for n, _ in geom._fields_), pre_act_a)
+    need = _WGRAD_NEED.get(gkey)
+    if need is None:
+        need = _WGRAD_NEED[gkey] = max(0, int(_lib.load().mtrssm_conv_weight_grad_workspace_bytes(C.byref(geom), pre_act_a)))
+    if need == 0:
+        return None
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WGRAD_WS.get(key)
+    if ws is None or ws.numel() * 4 < need:
+        if ws is not None:
+            _WGRAD_WS_RETIRED.append(ws)
+        ws = _WGRAD_WS[key] = torch.empty((need + 3) // 4 + 64, device=device, dtype=torch.float32)
+    return ws
 
 
 def _weight_grad(a: Tensor, src: Tensor, coords: Tensor | None, kh: int, kw: int, stride: int, pad: int, pre_act_a: bool,  # noqa: PLR0913
@@ -494,10 +546,11 @@ def _weight_grad(a: Tensor, src: Tensor, coords: Tensor | None, kh: int, kw: int
                  OS=1, QY=0, QX=0, Ho=hq, Wo=wq, Cout=o, CoutPad=opad, pre_act=int(pre_act_src), act=act)
     flops = 2.0 * n * hq * wq * o * kh * kw * (c + c2)
     nbytes = 4.0 * (a.numel() + src.numel())
+    ws = _wgrad_workspace(geom, int(pre_act_a), a.device)
     _lib.check(_lib.TIMERS.call(
         "mtrssm_conv_weight_grad", lib.mtrssm_conv_weight_grad, C.byref(geom), _lib.ptr(a), _lib.ptr(src), _lib.ptr(coords),
-        int(pre_act_a), _lib.ptr(dwp), _lib.ptr(dbias), _lib.stream_ptr(a.device), flops=flops, nbytes=nbytes),
-        "mtrssm_conv_weight_grad")
+        int(pre_act_a), _lib.ptr(dwp), _lib.ptr(dbias), _lib.raw_ptr(ws), 0 if ws is None else ws.numel() * 4, _lib.stream_ptr(a.device),
+        flops=flops, nbytes=nbytes), "mtrssm_conv_weight_grad")
     g_w = None if sunk is not None else dwp[:o, :, : c + c2].reshape(o, kh, kw, c + c2).permute(0, 3, 1, 2)
     return g_w, (None if bias_sunk is not None else dbias)
 

@@ -29,7 +29,7 @@ int conv_gather_gemm_pair_launch(const MtrssmConvGeom*, const float*, const floa
 int pack_conv_weight_launch(const float*, int, int, int, int, long, long, long, long, int, int, int, float*, unsigned short*, hipStream_t);
 int pack_conv_weights_launch(const int64_t*, int, int, hipStream_t);
 int conv_gather_pair_merges(const MtrssmConvGeom*, const MtrssmConvGeom*, bool);
-int conv_weight_grad_launch(const MtrssmConvGeom*, const float*, const float*, const float*, int, float*, float*, hipStream_t);
+int conv_weight_grad_launch(const MtrssmConvGeom*, const float*, const float*, const float*, int, float*, float*, void*, size_t, size_t*, hipStream_t);
 int channel_sum_launch(const float*, int, int, int, float*, hipStream_t);
 int convt_k4s2_thin_launch(int, int, int, int, int, const float*, const float*, const float*, int, int, float*, hipStream_t);
 int conv_convt_quad_supported(const MtrssmConvGeom*);
@@ -50,9 +50,28 @@ size_t mrssm_cluster_bwd_workspace_bytes(const MtrssmMrssmDims*);
 int mrssm_bwd_cluster_launch(const MtrssmMrssmDims*, const MtrssmMrssmClusterWeights*, const MtrssmMrssmBwdIO*, void*, size_t, hipStream_t);
 int mrssm_fwd_cluster_launch(const MtrssmMrssmDims*, const MtrssmMrssmClusterWeights*, const MtrssmMrssmFwdIO*, void*, size_t, hipStream_t);
 int unpack_conv_grads_launch(const int64_t*, int, int, hipStream_t);
-int adamw_prepare_launch(const float*, int64_t, float*, float*, float, float, hipStream_t);
-int adamw_apply_launch(float*, const float*, float*, float*, const unsigned char*, int64_t, const float*, const float*, float, float, float, float,
-                       float, float, hipStream_t);
+int mrssm_wide_supported(const MtrssmMrssmDims*, int);
+size_t mrssm_wide_workspace_bytes(const MtrssmMrssmDims*, int);
+size_t mrssm_wide_bwd_workspace_bytes(const MtrssmMrssmDims*, int);
+int mrssm_wide_fwd_launch(const MtrssmMrssmDims*, const MtrssmMrssmClusterWeights*, const MtrssmMrssmFwdIO*, int, void*, size_t, hipStream_t);
+int mrssm_wide_bwd_launch(const MtrssmMrssmDims*, const MtrssmMrssmClusterWeights*, const MtrssmMrssmBwdIO*, int, void*, size_t, hipStream_t);
+int adamw_prepare_launch(const float*, int64_t, float*, float*, const int*, float, float, hipStream_t);
+int adamw_apply_launch(float*, const float*, float*, float*, const unsigned char*, int64_t, const float*, const float*, const int*, float, float, float,
+                       float, float, float, hipStream_t);
+
+// Compute units of the calling thread's current device (0 when there is no device): the kernels whose workgroups wait for each
+// other size their grids by it.  A cache of an immutable device property, not state.
+int device_cu_count() {
+  static int cached[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  if (dev < 0 || dev >= 64) return 0;
+  if (cached[dev] > 0) return cached[dev];
+  int v = 0;
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) { (void)hipGetLastError(); return 0; }
+  cached[dev] = v;
+  return v;
+}
 
 }  // namespace mtrssm
 
@@ -108,17 +127,31 @@ MTRSSM_API int mtrssm_mrssm_rollout_bwd_cluster(const MtrssmMrssmDims* d, const 
                                                 void* workspace, int64_t workspace_bytes, void* stream) {
   return mrssm_bwd_cluster_launch(d, w, io, workspace, workspace_bytes < 0 ? 0 : (size_t)workspace_bytes, static_cast<hipStream_t>(stream));
 }
+MTRSSM_API int mtrssm_mrssm_wide_supported(const MtrssmMrssmDims* d, int32_t pieces) { return mrssm_wide_supported(d, pieces); }
+MTRSSM_API int64_t mtrssm_mrssm_wide_workspace_bytes(const MtrssmMrssmDims* d, int32_t pieces) { return (int64_t)mrssm_wide_workspace_bytes(d, pieces); }
+MTRSSM_API int64_t mtrssm_mrssm_wide_bwd_workspace_bytes(const MtrssmMrssmDims* d, int32_t pieces) {
+  return (int64_t)mrssm_wide_bwd_workspace_bytes(d, pieces);
+}
+MTRSSM_API int mtrssm_mrssm_rollout_fwd_wide(const MtrssmMrssmDims* d, const MtrssmMrssmClusterWeights* w, const MtrssmMrssmFwdIO* io, int32_t pieces,
+                                             void* workspace, int64_t workspace_bytes, void* stream) {
+  return mrssm_wide_fwd_launch(d, w, io, pieces, workspace, workspace_bytes < 0 ? 0 : (size_t)workspace_bytes, static_cast<hipStream_t>(stream));
+}
+MTRSSM_API int mtrssm_mrssm_rollout_bwd_wide(const MtrssmMrssmDims* d, const MtrssmMrssmClusterWeights* w, const MtrssmMrssmBwdIO* io, int32_t pieces,
+                                             void* workspace, int64_t workspace_bytes, void* stream) {
+  return mrssm_wide_bwd_launch(d, w, io, pieces, workspace, workspace_bytes < 0 ? 0 : (size_t)workspace_bytes, static_cast<hipStream_t>(stream));
+}
 MTRSSM_API int mtrssm_gemm(const MtrssmGemm* g, void* stream) { return gemm_launch(g, static_cast<hipStream_t>(stream)); }
 MTRSSM_API int mtrssm_clear(void* p, int64_t bytes, void* stream) {
   return clear_async(p, bytes < 0 ? 0 : (size_t)bytes, static_cast<hipStream_t>(stream));
 }
-MTRSSM_API int mtrssm_adamw_prepare(const float* grad, int64_t n, float* sumsq, float* state, float beta1, float beta2, void* stream) {
-  return adamw_prepare_launch(grad, n, sumsq, state, beta1, beta2, static_cast<hipStream_t>(stream));
+MTRSSM_API int mtrssm_adamw_prepare(const float* grad, int64_t n, float* sumsq, float* state, const int32_t* status, float beta1, float beta2,
+                                    void* stream) {
+  return adamw_prepare_launch(grad, n, sumsq, state, status, beta1, beta2, static_cast<hipStream_t>(stream));
 }
 MTRSSM_API int mtrssm_adamw_apply(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const uint8_t* active, int64_t n,
-                                  const float* sumsq, const float* state, float clip_norm, float grad_scale, float beta1, float beta2,
-                                  float eps, float weight_decay, void* stream) {
-  return adamw_apply_launch(param, grad, exp_avg, exp_avg_sq, active, n, sumsq, state, clip_norm, grad_scale, beta1, beta2, eps,
+                                  const float* sumsq, const float* state, const int32_t* status, float clip_norm, float grad_scale, float beta1,
+                                  float beta2, float eps, float weight_decay, void* stream) {
+  return adamw_apply_launch(param, grad, exp_avg, exp_avg_sq, active, n, sumsq, state, status, clip_norm, grad_scale, beta1, beta2, eps,
                             weight_decay, static_cast<hipStream_t>(stream));
 }
 MTRSSM_API int mtrssm_conv_gather_gemm(const MtrssmConvGeom* g, const float* src, const float* src2, const float* wp, const uint16_t* wq,
@@ -147,8 +180,14 @@ MTRSSM_API int mtrssm_pack_conv_weights(const int64_t* table, int32_t count, int
   return pack_conv_weights_launch(table, count, blocks_per_weight, static_cast<hipStream_t>(stream));
 }
 MTRSSM_API int mtrssm_conv_weight_grad(const MtrssmConvGeom* g, const float* a, const float* src, const float* src2, int32_t pre_act_a,
-                                       float* dwp, float* dbias, void* stream) {
-  return conv_weight_grad_launch(g, a, src, src2, pre_act_a, dwp, dbias, static_cast<hipStream_t>(stream));
+                                       float* dwp, float* dbias, void* workspace, int64_t workspace_bytes, void* stream) {
+  return conv_weight_grad_launch(g, a, src, src2, pre_act_a, dwp, dbias, workspace, workspace_bytes < 0 ? 0 : (size_t)workspace_bytes, nullptr,
+                                 static_cast<hipStream_t>(stream));
+}
+MTRSSM_API int64_t mtrssm_conv_weight_grad_workspace_bytes(const MtrssmConvGeom* g, int32_t pre_act_a) {
+  size_t need = 0;
+  if (conv_weight_grad_launch(g, nullptr, nullptr, nullptr, pre_act_a, nullptr, nullptr, nullptr, 0, &need, nullptr) != MTRSSM_OK) return -1;
+  return (int64_t)need;
 }
 MTRSSM_API int mtrssm_channel_sum(const float* x, int32_t N, int32_t C, int32_t HW, float* out, void* stream) {
   return channel_sum_launch(x, N, C, HW, out, static_cast<hipStream_t>(stream));

@@ -1487,34 +1487,30 @@ static bool wgrad_partials_enabled() {
   static const bool on = [] { const char* e = getenv("MTRSSM_WGRAD_PARTIALS"); return !(e && e[0] == '0'); }();
   return on;
 }
-// Scratch for the partial tile sets of the staged weight-gradient kernels: one buffer per stream (launches of a stream reuse
-// it in order), grown on demand, kept for the life of the process (~38 MB at the bench shapes).  NULL when it cannot be
-// provided -- the stream is being captured and the buffer is not there yet, or the allocation fails -- and the caller
-// falls back to atomics.
-static float* wgrad_scratch(hipStream_t stream, size_t bytes) {
-  static std::mutex mu;
-  static std::unordered_map<hipStream_t, std::pair<float*, size_t>> tab;
-  std::lock_guard<std::mutex> lk(mu);
-  auto& e = tab[stream];
-  if (e.second >= bytes) return e.first;
-  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
-  float* p = nullptr;
-  if (hipMalloc(reinterpret_cast<void**>(&p), bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-  // the outgrown buffer is NOT freed: a captured graph of this stream may hold its address (replays would write freed
-  // memory); it stays allocated for the life of the process like the current one (sizes only grow, a few steps at most)
-  e = {p, bytes};
-  return p;
-}
+// Partial tile sets of the staged weight-gradient kernels live in the CALLER's workspace (the library allocates nothing).  In
+// query mode the launch function reports the size and returns before any launch.
+#define MTRSSM_WGRAD_PART(bytes_expr)                                                                                              \
+  float* part = nullptr;                                                                                                         \
+  {                                                                                                                              \
+    const size_t need_ = (bytes_expr);                                                                                           \
+    if (query) { *query = wgrad_partials_enabled() ? need_ : 0; return MTRSSM_OK; }                                              \
+    if (wgrad_partials_enabled() && workspace && workspace_bytes >= need_) part = static_cast<float*>(workspace);                \
+  }
+#define MTRSSM_WGRAD_NO_PART \
+  if (query) { *query = 0; return MTRSSM_OK; }
 static bool no_direct_wgrad() {
   static const bool off = getenv("MTRSSM_NO_DIRECT_WGRAD") != nullptr;
   return off;
 }
 
+// workspace: caller-owned device memory for the partial tile sets of the staged kernels (mtrssm_conv_weight_grad_workspace_bytes);
+// too small / NULL = the atomics form of the same kernels.  query != NULL: store the bytes this geometry's kernel wants (0 for
+// the kernels without partial sets) and return WITHOUT launching anything.
 int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float* src, const float* src2, int pre_act_a,
-                            float* dwp, float* dbias, hipStream_t stream) {
+                            float* dwp, float* dbias, void* workspace, size_t workspace_bytes, size_t* query, hipStream_t stream) {
   if (int rc = check_geom(g, "conv_weight_grad")) return rc;
-  if (!a || !src || !dwp || (g->C2 > 0 && !src2)) { set_error("conv_weight_grad: null pointer"); return MTRSSM_EINVAL; }
+  if (!query && (!a || !src || !dwp || (g->C2 > 0 && !src2))) { set_error("conv_weight_grad: null pointer"); return MTRSSM_EINVAL; }
+  if (workspace && ((uintptr_t)workspace & 255)) { set_error("conv_weight_grad: workspace must be 256-byte aligned"); return MTRSSM_EINVAL; }
   if (dbias && pre_act_a) { set_error("conv_weight_grad: the fused bias gradient sums the RAW a tensor; pass dbias only with pre_act_a = 0"); return MTRSSM_EINVAL; }
   if (g->OS != 1 || g->QY != 0 || g->QX != 0 || g->KH * g->KW <= 0) { set_error("conv_weight_grad: needs a plain (OS=1) geometry with taps"); return MTRSSM_EINVAL; }
   const long ptot = (long)g->N * g->Hq * g->Wq;
@@ -1531,7 +1527,7 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
     if (wgs > g->N) wgs = g->N;
     const int per = (g->N + wgs - 1) / wgs;
     const dim3 grid((unsigned)((g->N + per - 1) / per), cogroups);
-    float* const part = wgrad_partials_enabled() ? wgrad_scratch(stream, (size_t)grid.x * cogroups * kWg1x1SetFloats * sizeof(float)) : nullptr;
+    MTRSSM_WGRAD_PART((size_t)grid.x * cogroups * kWg1x1SetFloats * sizeof(float))
 #define MTRSSM_WG1_LAUNCH(SP_, C_)                                                                                              \
   {                                                                                                                             \
     static bool attr_done = false; /* once per instantiation: never while another stream may be running the kernel */       \
@@ -1560,6 +1556,7 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
       (g->Hq * g->Wq) % 16 == 0 && g->Cout <= 128 && g->C <= 128 && g->C >= 8 && !((uintptr_t)a & 15) && !((uintptr_t)src & 15) &&
       ptot < (1L << 31)) {
     // 1x1 layers: both operands straight from HBM into MFMA registers (conv_split.h: conv1x1_weight_grad_split_kernel)
+    MTRSSM_WGRAD_NO_PART
     const int tiles_co = (g->Cout + 31) / 32, tiles_ci = (g->C + 31) / 32;
     const int total = (int)(ptot / 16);
     int splits = 256;  // one workgroup per CU (one wave per SIMD: the conversion VALU work fills it); more partial tiles = more atomics (36 / 44 / 50 us at 256 / 512 / 1024)
@@ -1587,7 +1584,7 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
     const int per = (g->N + wgs - 1) / wgs;
     const dim3 grid((unsigned)((g->N + per - 1) / per), cogroups);
     const size_t set_floats = (size_t)wgres_set_floats(g->C);
-    float* const part = wgrad_partials_enabled() ? wgrad_scratch(stream, (size_t)grid.x * cogroups * set_floats * sizeof(float)) : nullptr;
+    MTRSSM_WGRAD_PART((size_t)grid.x * cogroups * set_floats * sizeof(float))
 #define MTRSSM_WGRES_LAUNCH(SP_, C_, W_)                                                                                         \
   {                                                                                                                             \
     static bool attr_done = false; /* once per instantiation: never while another stream may be running the kernel */       \
@@ -1621,6 +1618,7 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
       g->Hs == g->Hq && g->Ws == g->Wq && (g->Wq == 8 || g->Wq == 4) && (g->Hq * g->Wq) % 16 == 0 && g->C <= 64 && g->C >= 8 &&
       g->Cout <= 65535 * 64 && !((uintptr_t)a & 15) && !((uintptr_t)src & 15) && ptot < (1L << 31) && !no_direct_wgrad()) {
     // 3x3 layers of the residual stacks: register-direct (conv_split.h: conv3x3_weight_grad_split_kernel)
+    MTRSSM_WGRAD_NO_PART
     const int cogroups = (g->Cout + 63) / 64;
     const int tiles_co = g->Cout > 32 ? 2 : 1, tiles_ci = (g->C + 31) / 32;
     const int nt = tiles_co * tiles_ci;
@@ -1651,7 +1649,7 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
     if (wgs > g->N) wgs = g->N;
     const int per = (g->N + wgs - 1) / wgs;
     const dim3 grid((unsigned)((g->N + per - 1) / per));
-    float* const part = wgrad_partials_enabled() ? wgrad_scratch(stream, (size_t)grid.x * kWgThinSetFloats * sizeof(float)) : nullptr;
+    MTRSSM_WGRAD_PART((size_t)grid.x * kWgThinSetFloats * sizeof(float))
 #define MTRSSM_WGTHIN_LAUNCH(SP_, W_)                                                                                            \
   {                                                                                                                             \
     static bool attr_done = false; /* once per instantiation: never while another stream may be running the kernel */       \
@@ -1682,7 +1680,7 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
     if (wgs > g->N) wgs = g->N;
     const int per = (g->N + wgs - 1) / wgs;
     const dim3 grid((unsigned)((g->N + per - 1) / per));
-    float* const part = wgrad_partials_enabled() ? wgrad_scratch(stream, (size_t)grid.x * kWgThinTSetFloats * sizeof(float)) : nullptr;
+    MTRSSM_WGRAD_PART((size_t)grid.x * kWgThinTSetFloats * sizeof(float))
 #define MTRSSM_WGTHINT_LAUNCH(SP_, W_)                                                                                           \
   {                                                                                                                             \
     static bool attr_done = false; /* once per instantiation: never while another stream may be running the kernel */       \
@@ -1707,6 +1705,7 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
   if (g->mfma_split >= 1 && g->Cout <= 32 && taps * ctot <= 32 && g->Wq >= 8 && (g->Wq & (g->Wq - 1)) == 0 && (g->Hq * g->Wq) % 16 == 0 &&
       !((uintptr_t)a & 15) && ptot < (1L << 31) && (long)g->N * g->C * g->Hs * g->Ws < (1L << 40) && !no_direct_wgrad()) {
     // thin strided layers: one MFMA tile, A straight from HBM, B gathered per lane (conv_split.h: conv_weight_grad_thin_split_kernel)
+    MTRSSM_WGRAD_NO_PART
     int log2_wq = 0;
     while ((1 << log2_wq) < g->Wq) ++log2_wq;
     const int total = (int)(ptot / 16);
@@ -1731,7 +1730,7 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
     if (wgs > g->N) wgs = g->N;
     const int per = (g->N + wgs - 1) / wgs;
     const dim3 grid((unsigned)((g->N + per - 1) / per));
-    float* const part = wgrad_partials_enabled() ? wgrad_scratch(stream, (size_t)grid.x * kWgS2SetFloats * sizeof(float)) : nullptr;
+    MTRSSM_WGRAD_PART((size_t)grid.x * kWgS2SetFloats * sizeof(float))
 #define MTRSSM_WGS2_LAUNCH(SP_, W_)                                                                                              \
   {                                                                                                                             \
     static bool attr_done = false; /* once per instantiation: never while another stream may be running the kernel */       \
@@ -1762,7 +1761,7 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
     if (wgs > g->N) wgs = g->N;
     const int per = (g->N + wgs - 1) / wgs;
     const dim3 grid((unsigned)((g->N + per - 1) / per));
-    float* const part = wgrad_partials_enabled() ? wgrad_scratch(stream, (size_t)grid.x * kWgT4SetFloats * sizeof(float)) : nullptr;
+    MTRSSM_WGRAD_PART((size_t)grid.x * kWgT4SetFloats * sizeof(float))
 #define MTRSSM_WGT4_LAUNCH(SP_, W_)                                                                                              \
   {                                                                                                                             \
     static bool attr_done = false; /* once per instantiation: never while another stream may be running the kernel */       \
@@ -1793,7 +1792,7 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
     if (wgs > g->N) wgs = g->N;
     const int per = (g->N + wgs - 1) / wgs;
     const dim3 grid((unsigned)((g->N + per - 1) / per));
-    float* const part = wgrad_partials_enabled() ? wgrad_scratch(stream, (size_t)grid.x * kWgT4bSetFloats * sizeof(float)) : nullptr;
+    MTRSSM_WGRAD_PART((size_t)grid.x * kWgT4bSetFloats * sizeof(float))
 #define MTRSSM_WGT4B_LAUNCH(SP_, W_)                                                                                             \
   {                                                                                                                             \
     static bool attr_done = false; /* once per instantiation: never while another stream may be running the kernel */       \
@@ -1824,7 +1823,7 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
     if (wgs > g->N) wgs = g->N;
     const int per = (g->N + wgs - 1) / wgs;
     const dim3 grid((unsigned)((g->N + per - 1) / per));
-    float* const part = wgrad_partials_enabled() ? wgrad_scratch(stream, (size_t)grid.x * kWgS2cSetFloats * sizeof(float)) : nullptr;
+    MTRSSM_WGRAD_PART((size_t)grid.x * kWgS2cSetFloats * sizeof(float))
 #define MTRSSM_WGS2C_LAUNCH(SP_, W_)                                                                                             \
   {                                                                                                                             \
     set_last_kernel("mtrssm::conv3x3s2c_wgrad_staged_kernel<" #SP_ ", " #W_ ">");                                                \
@@ -1839,6 +1838,7 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
       hipLaunchKernelGGL(wgrad_reduce_partials_s2c_kernel, dim3(dbias ? 161 : 160), dim3(256), 0, stream, reinterpret_cast<const float4*>(part), (int)grid.x, g->Cpad, dwp, dbias);
     return launched("conv_weight_grad(3x3 s2 staged, 16 -> 32)");
   }
+  MTRSSM_WGRAD_NO_PART
   // ---- patch-staged kernel when the 64-pixel groups tile the frames exactly
   if (g->TS == 1 && g->Wq <= kGP && kGP % g->Wq == 0) {
     const PatchGeom pg(*g, kGP);

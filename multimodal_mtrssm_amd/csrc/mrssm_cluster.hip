@@ -30,6 +30,7 @@ namespace mtrssm {
 
 void set_error(const char* fmt, ...);
 void set_last_kernel(const char* name);
+int device_cu_count();
 
 constexpr int kClu = 4;            // workgroups (CUs) per row
 constexpr int kCluThreads = 256;   // one wave per SIMD: 512 registers per thread
@@ -778,7 +779,8 @@ int mrssm_bwd_cluster_launch(const MtrssmMrssmDims* d, const MtrssmMrssmClusterW
   const int grid = ((nclusters + 7) / 8) * 32;
   const size_t lds = cluster_bwd_lds_floats(d->D, d->K * d->C) * sizeof(float);
   if (lds > 160 * 1024) { set_error("mrssm_rollout_bwd_cluster: %zu bytes of LDS", lds); return MTRSSM_ELDS; }
-  if (int rc = clear_async(workspace, mrssm_cluster_bwd_workspace_bytes(d), stream)) return rc;
+  // granules zeroed every launch (first node of the launch under a graph); the status word in front of them is sticky
+  if (int rc = clear_async(static_cast<char*>(workspace) + 16, mrssm_cluster_bwd_workspace_bytes(d) - 16, stream)) return rc;
   hipError_t e = hipSuccess;
   int* status = reinterpret_cast<int*>(workspace);
   unsigned long long* gran = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(workspace) + 16);
@@ -842,6 +844,10 @@ int mrssm_cluster_supported(const MtrssmMrssmDims* d) {
   if (3 * S > kCluThreads || H / kClu > 64 || 3 * H / kClu > kCluThreads || d->K > 64) return 0;  // logit rows / head units: one thread each
   if (D > 4 * kWave || kClu * 3 * S > 6 * kWave) return 0;  // granules per gather (wave_gather<4> / <6>)
   if (cluster_lds_floats(D, H, S) * sizeof(float) > 160 * 1024) return 0;
+  // every workgroup takes a whole CU's LDS and spins on its partners: the grid must fit the device's CUs (a partitioned or
+  // CU-masked device reports fewer than 256)
+  const int nclusters = d->B < 64 ? d->B : 64;
+  if (device_cu_count() < ((nclusters + 7) / 8) * 32) return 0;
   return 1;
 }
 
@@ -866,8 +872,9 @@ int mrssm_fwd_cluster_launch(const MtrssmMrssmDims* d, const MtrssmMrssmClusterW
   const int groups = (nclusters + 7) / 8;            // 8 clusters per 32 consecutive blocks
   const int grid = groups * 32;
   const size_t lds = cluster_lds_floats(d->D, d->H, d->K * d->C) * sizeof(float);
-  // status word + granules: zeroed every launch (first node of the launch under a graph)
-  if (int rc = clear_async(workspace, mrssm_cluster_workspace_bytes(d), stream)) return rc;
+  // granules zeroed every launch (first node of the launch under a graph); the status word in front of them is STICKY: the
+  // caller zeroes it when allocating, a failed exchange sets it, nothing clears it
+  if (int rc = clear_async(static_cast<char*>(workspace) + 16, mrssm_cluster_workspace_bytes(d) - 16, stream)) return rc;
   hipError_t e = hipSuccess;
   int* status = reinterpret_cast<int*>(workspace);
   unsigned long long* gran = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(workspace) + 16);

@@ -122,9 +122,9 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
 // received a gradient: torch.optim.AdamW skips parameters whose .grad is None (no decay, no moments) -- MMTRSSM's
 // l_posterior and dummy transition (mmtrssm/mopoe_mmtrssm/core.py:143-151,188).
 __global__ void sumsq_tick_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out, float* __restrict__ state,
-                                  float b1, float b2) {
+                                  const int* __restrict__ status, float b1, float b2) {
   __shared__ float red[kThreads / kWave];
-  if (blockIdx.x == 0 && threadIdx.x == 0 && state) {  // one optimizer step = one launch of this kernel
+  if (blockIdx.x == 0 && threadIdx.x == 0 && state && !(status && *status)) {  // one optimizer step = one launch of this kernel
     const float step = state[1] + 1.f;
     state[1] = step;
     state[2] = 1.f - powf(b1, step);
@@ -145,8 +145,11 @@ __global__ void sumsq_tick_kernel(const float* __restrict__ x, int64_t n, float*
 
 __global__ void adamw_masked_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                     const unsigned char* __restrict__ active, int64_t n, const float* __restrict__ sumsq,
-                                    const float* __restrict__ state, float clip, float gscale, float b1, float b2, float eps,
-                                    float wd) {
+                                    const float* __restrict__ state, const int* __restrict__ status, float clip, float gscale, float b1,
+                                    float b2, float eps, float wd) {
+  // a cooperative scan kernel of this step gave up on an exchange (sticky status word of its workspace): its outputs, hence
+  // these gradients, are invalid -- leave the parameters and the moments alone; the host raises at its next status poll
+  if (status && *status) return;
   const float lr = state[0], bc1 = state[2], bc2_sqrt = state[3];
   float coef = gscale;
   if (clip > 0.f && sumsq) {
@@ -241,20 +244,20 @@ int adamw_launch(float* p, const float* g, float* m, float* v, int64_t n, const 
   return check_launch("adamw_step");
 }
 
-int adamw_prepare_launch(const float* g, int64_t n, float* sumsq, float* state, float b1, float b2, hipStream_t s) {
+int adamw_prepare_launch(const float* g, int64_t n, float* sumsq, float* state, const int* status, float b1, float b2, hipStream_t s) {
   if (!g || !sumsq || !state || n <= 0) { set_error("adamw_prepare: bad argument"); return MTRSSM_EINVAL; }
   if ((uintptr_t)g & 15) { set_error("adamw_prepare: grad must be 16-byte aligned"); return MTRSSM_EINVAL; }
   if (int rc = clear_async(sumsq, sizeof(float), s)) return rc;
   set_last_kernel("mtrssm::sumsq_tick_kernel");
-  hipLaunchKernelGGL(sumsq_tick_kernel, dim3(grid_for(n / 4)), dim3(kThreads), 0, s, g, n, sumsq, state, b1, b2);
+  hipLaunchKernelGGL(sumsq_tick_kernel, dim3(grid_for(n / 4)), dim3(kThreads), 0, s, g, n, sumsq, state, status, b1, b2);
   return check_launch("adamw_prepare");
 }
 
 int adamw_apply_launch(float* p, const float* g, float* m, float* v, const unsigned char* active, int64_t n, const float* sumsq,
-                       const float* state, float clip, float gscale, float b1, float b2, float eps, float wd, hipStream_t s) {
+                       const float* state, const int* status, float clip, float gscale, float b1, float b2, float eps, float wd, hipStream_t s) {
   if (!p || !g || !m || !v || !state || n <= 0) { set_error("adamw_apply: bad argument"); return MTRSSM_EINVAL; }
   set_last_kernel("mtrssm::adamw_masked_kernel");
-  hipLaunchKernelGGL(adamw_masked_kernel, dim3(grid_for(n)), dim3(kThreads), 0, s, p, g, m, v, active, n, sumsq, state, clip, gscale,
+  hipLaunchKernelGGL(adamw_masked_kernel, dim3(grid_for(n)), dim3(kThreads), 0, s, p, g, m, v, active, n, sumsq, state, status, clip, gscale,
                      b1, b2, eps, wd);
   return check_launch("adamw_apply");
 }

@@ -1,0 +1,173 @@
+// Shared pieces of the chip-wide ("wide") scan kernels (mrssm_wide.hip): gfx950, wave64.
+//
+// Regime: D, H >= 256 (BASELINE configs[4] "Large": D = H = 1024, S = 128).  One CU re-streaming the step's 42 MB of weights
+// per row (mrssm_scan.hip) takes 500 us per timestep there.  Here ALL workgroups of the chip (one per CU) work on the same
+// tile of 32 batch rows: every matrix product of the step is cut by OUTPUT column into 16-column tiles, a tile's weights are
+// streamed by exactly one CU per step (as bf16 pieces in the MFMA A-operand order, packed once per launch), the 32 batch rows
+// are the MFMA N dimension (v_mfma_f32_16x16x32_bf16, two row tiles), and the products of consecutive layers meet through an
+// exchange buffer in L2 / MALL followed by a grid-wide barrier (all workgroups resident: grid <= CU count).
+//
+// Arithmetic: an fp32 value is the sum of P bf16 pieces (P = 3: exact to 2^-24, six MFMA products per k-block -- fp32-grade,
+// the default; P = 2: 16 significant bits, three products), fp32 accumulation in the MFMA.
+#pragma once
+#include "scan_common.h"
+
+namespace mtrssm {
+
+constexpr int kWT = 256;                 // threads per workgroup: one wave per SIMD (512 registers each), the K range of a tile split over them
+constexpr int kWW = kWT / kWave;
+constexpr int kWRows = 32;               // batch rows per pass: two 16-row MFMA tiles
+constexpr unsigned kWideSpinLimit = 1u << 22;
+
+using wbf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using wf32x4 = __attribute__((ext_vector_type(4))) float;
+
+// ---- packed weights: matrix W(n, k), n < N outputs, k < K inputs  ->  [n / 16][k / 32][piece][lane] of 16 bytes:
+// lane l holds W(16 nt + (l & 15), 32 ks + 8 (l >> 4) + j), j = 0..7 -- the A operand of v_mfma_f32_16x16x32_bf16, so a
+// wave's fragment is ONE contiguous 1 KiB load.  Zero padded.
+struct WidePackJob {
+  const float* src;
+  long sn, sk;       // element strides of n and k in src
+  int N, K;
+  int NT, KS;        // ceil(N / 16), ceil(K / 32)
+  uint4* dst;
+};
+constexpr int kWideMaxJobs = 8;
+struct WidePackJobs {
+  WidePackJob j[kWideMaxJobs];
+  int count;
+};
+
+__host__ __device__ inline size_t wide_pack_uint4(int N, int K, int P) {
+  return (size_t)((N + 15) / 16) * ((K + 31) / 32) * P * 64;
+}
+// ---- exchange vectors: x[row < 32][k < K] as bf16 pieces in the MFMA B-operand order: [piece][k / 32][row][32 k] -- lane l
+// of row tile rt reads the 16 bytes at uint4 index ((p KS + ks) 32 + 16 rt + (l & 15)) 4 + (l >> 4): 1 KiB contiguous per wave.
+__host__ __device__ inline size_t wide_x_uint4(int K, int P) { return (size_t)P * ((K + 31) / 32) * kWRows * 4; }
+
+template <int P>
+__device__ __forceinline__ void wide_split4(const float (&v)[4], uint2 (&o)[P]) {
+  float r[4] = {v[0], v[1], v[2], v[3]};
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    unsigned short h[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const __bf16 b = (__bf16)r[i];
+      h[i] = __builtin_bit_cast(unsigned short, b);
+      r[i] -= (float)b;
+    }
+    o[p] = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+  }
+}
+
+// Write-through (sc1) 8-byte store: the exchange payload needs no release fence (cdna_hip_programming.md Guideline 16, R1).
+__device__ __forceinline__ void wide_store_u2(void* p, uint2 v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), ((unsigned long long)v.y << 32) | v.x, __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void wide_store_f2(float* p, float a, float b) {
+  wide_store_u2(p, make_uint2(__float_as_uint(a), __float_as_uint(b)));
+}
+
+// four consecutive k (k % 4 == 0) of one row into an exchange vector
+template <int P>
+__device__ __forceinline__ void wide_x_store4(uint4* xb, int KS, int row, int k, const float (&v)[4]) {
+  uint2 o[P];
+  wide_split4<P>(v, o);
+  char* base = reinterpret_cast<char*>(xb);
+#pragma unroll
+  for (int p = 0; p < P; ++p)
+    wide_store_u2(base + ((size_t)((p * KS + (k >> 5)) * kWRows + row) * 64 + (size_t)(k & 31) * 2), o[p]);
+}
+
+// acc[nt][rt] += W_tile[nt] (16 outputs x K) . x (K x 16 rows of row tile rt) over this wave's k-blocks [ks0, ks1).
+// wt[nt]: the tile's fragment array ([ks][piece][lane]); xb: exchange vector.  Loads of block ks + 1 are issued before the
+// MFMAs of block ks.  Products: piece pairs (a, b) with a + b < P, smallest terms first.
+template <int NT, int P>
+__device__ __forceinline__ void wide_mfma_stream(wf32x4 (&acc)[NT][2], const uint4* const (&wt)[NT], const uint4* __restrict__ xb, int KS,
+                                                 int ks0, int ks1, int lane) {
+  if (ks0 >= ks1) return;
+  const int xlane = (lane & 15) * 4 + (lane >> 4);
+  uint4 a[2][NT][P], b[2][2][P];
+  auto load = [&](int buf, int ks) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int p = 0; p < P; ++p) a[buf][nt][p] = wt[nt][((size_t)ks * P + p) * 64 + lane];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int p = 0; p < P; ++p) b[buf][rt][p] = xb[(size_t)((p * KS + ks) * kWRows + 16 * rt) * 4 + xlane];
+  };
+  auto compute = [&](int buf) {
+#pragma unroll
+    for (int ord = P - 1; ord >= 0; --ord)
+#pragma unroll
+      for (int pa = 0; pa <= ord; ++pa)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt)
+            acc[nt][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wbf16x8, a[buf][nt][pa]),
+                                                                  __builtin_bit_cast(wbf16x8, b[buf][rt][ord - pa]), acc[nt][rt], 0, 0, 0);
+  };
+  load(0, ks0);
+  int ks = ks0;
+  for (; ks + 2 <= ks1; ks += 2) {   // two blocks per trip: the register buffers keep static indices
+    load(1, ks + 1);
+    compute(0);
+    if (ks + 2 < ks1) load(0, ks + 2);
+    compute(1);
+  }
+  if (ks < ks1) compute(0);
+}
+
+// Cross-wave reduction through LDS: red[(wave NTOT + tile) 2 + rt][lane] (float4 each).
+template <int NTOT>
+__device__ __forceinline__ void wide_red_store(wf32x4* red, int wave, int tile, int lane, const wf32x4 (&acc)[2]) {
+  red[((wave * NTOT + tile) * 2 + 0) * kWave + lane] = acc[0];
+  red[((wave * NTOT + tile) * 2 + 1) * kWave + lane] = acc[1];
+}
+template <int NTOT>
+__device__ __forceinline__ wf32x4 wide_red_sum(const wf32x4* red, int tile, int rt, int slot) {
+  wf32x4 s = red[((0 * NTOT + tile) * 2 + rt) * kWave + slot];
+#pragma unroll
+  for (int w = 1; w < kWW; ++w) s += red[((w * NTOT + tile) * 2 + rt) * kWave + slot];
+  return s;
+}
+
+// Grid-wide barrier over `nblk` resident workgroups: one monotonic counter (zeroed by the launch), every storing wave drains
+// its stores, one lane arrives (agent-scope add) and polls with sc1 loads, then ONE agent acquire (drops this CU's L1 lines)
+// before the workgroup goes on to plain loads of what the others published with write-through stores.  Bounded: a poll that
+// gives up sets the sticky status word and the LDS abort flag; the caller leaves the kernel.
+struct WideBarrier {
+  unsigned* counter;
+  int* status;
+  int* abort_flag;  // LDS
+  unsigned target;
+  unsigned nblk;
+  __device__ __forceinline__ bool sync(int code) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    target += nblk;
+    if (threadIdx.x == 0) {
+      __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      bool ok = true;
+      for (unsigned spins = 0; __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; ++spins) {
+        if (spins > kWideSpinLimit) { ok = false; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (!ok) {
+        *abort_flag = 1;
+        atomicExch(status, code);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    return *abort_flag == 0;
+  }
+};
+
+}  // namespace mtrssm

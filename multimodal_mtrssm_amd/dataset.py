@@ -145,8 +145,9 @@ class DeviceEpisodeLoader:
     """Iterable of 6-tuple batches over device-resident episodes (what ``train_dataloader`` / ``val_dataloader`` return).
 
     ``shuffle`` draws a fresh permutation per epoch from a CPU generator seeded ``seed + epoch`` -- the SAME order on every
-    data-parallel rank -- and ``rank`` / ``world`` give each rank a disjoint slice of every global batch (the rows
-    ``FlatDataParallel.shard`` would cut).  All ranks yield the same number of equally sized batches: a batch whose size
+    data-parallel rank -- and ``rank`` / ``world`` give each rank the contiguous block ``[rank * B / world, (rank + 1) * B / world)``
+    of every global batch: exactly the rows ``FlatDataParallel.shard`` cuts and ``GlobalRowNoise.draw`` keys its uniforms by, so
+    global row g meets the same noise whatever the number of ranks.  All ranks yield the same number of equally sized batches: a batch whose size
     is not a multiple of ``world`` is padded by wrapping to the head of the epoch's order (``DistributedSampler``'s rule),
     so the per-step all-reduce never waits for a rank that ran out of rows.  With one rank the last batch may be short
     (the reference's DataLoader keeps it too)."""
@@ -186,7 +187,8 @@ class DeviceEpisodeLoader:
                 pad = (-rows.numel()) % self.world
                 if pad:
                     rows = torch.cat([rows, order[torch.arange(pad, device=dev) % self.n]])
-                rows = rows[self.rank:: self.world]
+                per = rows.numel() // self.world  # the CONTIGUOUS block FlatDataParallel.shard / GlobalRowNoise.draw give this rank
+                rows = rows[self.rank * per: (self.rank + 1) * per]
             yield rows.contiguous()
 
     def __iter__(self) -> Iterator[tuple[Tensor, ...]]:

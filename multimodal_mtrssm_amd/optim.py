@@ -22,7 +22,7 @@ from __future__ import annotations
 import torch
 from torch import Tensor, nn
 
-from multimodal_mtrssm_amd import _lib, conv, linear
+from multimodal_mtrssm_amd import _lib, conv, linear, scan
 
 
 class FlatParameters:
@@ -105,6 +105,7 @@ class FlatParameters:
         """One launch over the flat gradient buffer (+ tail).  On the GPU a plain kernel (``mtrssm_clear``), not a memset:
         inside a captured train step a 16 MB memset node came back with foreign bytes at the buffer's head on replay."""
         g = self.grad_full
+        conv.discard_pending_grads()  # packed conv weight gradients of a backward that raised belong to the sums being cleared
         if g.is_cuda:
             _lib.check(_lib.load().mtrssm_clear(_lib.ptr(g), g.numel() * 4, _lib.stream_ptr(g.device)), "mtrssm_clear")
         else:
@@ -161,24 +162,34 @@ class FlatAdamW:
         """Clip by global norm (after ``grad_scale``), then AdamW.  Returns the device scalar sum(g^2).
 
         Two launches (+ one 4-byte memset), no host-side scalar in either: safe inside a hipGraph capture (call
-        ``sync_lr()`` before replays when a scheduler may have changed the rate; ``check`` then has to be False)."""
-        lib = _lib.load()
+        ``sync_lr()`` before replays when a scheduler may have changed the rate; ``check`` then has to be False).
+
+        The step's cooperative scan kernels (``scan.py``) leave a sticky status word when an exchange between their workgroups
+        gave up: both launches are handed that word and skip the update on the device when it is set, and (``check``) the
+        host raises ``MtrssmLibraryError`` here as soon as the asynchronous copy posted by an earlier step shows it --
+        without synchronising."""
         f = self.flat
         if check:
+            scan.STATUS.poll()  # raises if a scan launch of an EARLIER step failed (its update was skipped on the device)
+            conv.flush_pending_grads()  # a backward that raised half-way left conv weight gradients in their packed buffers
             f.check_views()
             self.sync_lr()
+        lib = _lib.load()
         stream = _lib.stream_ptr(f.param.device)
         self.steps += 1
         mask = self.active_mask()
+        status = scan.status_word(f.param.device)
         _lib.check(_lib.TIMERS.call("mtrssm_adamw_prepare", lib.mtrssm_adamw_prepare, _lib.ptr(f.grad), f.numel, _lib.ptr(self.sumsq),
-                                    _lib.ptr(self.state), self.betas[0], self.betas[1], stream, nbytes=4.0 * f.numel),
+                                    _lib.ptr(self.state), _lib.raw_ptr(status), self.betas[0], self.betas[1], stream, nbytes=4.0 * f.numel),
                    "mtrssm_adamw_prepare")
         _lib.check(_lib.TIMERS.call(
             "mtrssm_adamw_apply", lib.mtrssm_adamw_apply, _lib.ptr(f.param), _lib.ptr(f.grad), _lib.ptr(self.exp_avg),
-            _lib.ptr(self.exp_avg_sq), _lib.raw_ptr(mask), f.numel, _lib.ptr(self.sumsq), _lib.ptr(self.state), float(self.clip_norm),
-            float(grad_scale), self.betas[0], self.betas[1], self.eps, self.weight_decay, stream, nbytes=28.0 * f.numel),
-            "mtrssm_adamw_apply")
+            _lib.ptr(self.exp_avg_sq), _lib.raw_ptr(mask), f.numel, _lib.ptr(self.sumsq), _lib.ptr(self.state), _lib.raw_ptr(status),
+            float(self.clip_norm), float(grad_scale), self.betas[0], self.betas[1], self.eps, self.weight_decay, stream,
+            nbytes=28.0 * f.numel), "mtrssm_adamw_apply")
         conv.invalidate_packs()  # the parameters changed behind autograd's version counters
+        if check:
+            scan.STATUS.post()  # asynchronous copy of the status words; read by the next step's poll
         return self.sumsq
 
     def state_dict(self) -> dict[str, object]:

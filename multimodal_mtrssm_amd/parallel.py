@@ -95,6 +95,7 @@ class FlatDataParallel:
     @torch.no_grad()
     def reduce(self) -> None:
         """THE exchange of the step: one all-reduce (SUM, left un-normalised) over gradients + tail."""
+        conv.flush_pending_grads()  # (only after a backward that raised: the sink's callback never ran)
         if self.active:  # also with one rank: same code path, the collective is then a no-op copy
             dist.all_reduce(self.flat.grad_full, op=dist.ReduceOp.SUM, group=self.group)
 

@@ -44,23 +44,113 @@ class ScanConfig:
 
 KERNEL_TIMERS = _lib.TIMERS
 
-# The posterior rollout of square, mid-sized models (D = H in {32, 64, 128, 200}: BASELINE configs[1]) runs one batch row on a
-# CLUSTER of four CUs with all weights resident (csrc/mrssm_cluster.hip) instead of one CU streaming them from L2 every
-# step.  Its workgroups wait for each other, so they must be co-resident: a GPU shared with another process must switch it
-# off (MTRSSM_SCAN_CLUSTER=0).  Each launch leaves a status word (0 = fine) in its workspace: `check_cluster_status()`.
+# Two families of COOPERATIVE scan kernels (their workgroups wait for each other inside one launch, so every workgroup must be
+# resident: a GPU shared with another process must switch them off):
+# * square, mid-sized models (D = H in {32, 64, 128, 200}: BASELINE configs[1]): one batch row on a CLUSTER of four CUs with all
+#   weights resident (csrc/mrssm_cluster.hip) -- MTRSSM_SCAN_CLUSTER=0 switches it off;
+# * large models (D or H >= 256: BASELINE configs[4]): ALL CUs on one tile of 32 batch rows, MFMA products, a grid barrier
+#   between the layers of a timestep (csrc/mrssm_wide.hip) -- MTRSSM_SCAN_WIDE=0 switches it off, MTRSSM_WIDE_PIECES = 2 | 3
+#   picks the bf16 pieces per fp32 operand (3 = fp32-grade, the default).
+# Otherwise one CU per row streams the weights from L2 every step (csrc/mrssm_scan.hip).
+# Every cooperative launch takes its workspace from `_workspace()`: ONE buffer per (device, stream) whose first int32 is a
+# STICKY status word -- a launch whose exchange gave up stores a non-zero code there, no launch clears it.  The fused AdamW
+# step is handed that word and skips the update when it is set (`status_word`), and `STATUS.poll()` -- called by
+# FlatAdamW.step / CapturedTrainStep.step with the previous step's asynchronously copied value, and by
+# `check_cluster_status()` synchronously -- raises.
 import os as _os  # noqa: E402
 
 CLUSTER_SCAN = _os.environ.get("MTRSSM_SCAN_CLUSTER", "1") != "0"
-_CLUSTER_WS: dict[tuple, Tensor] = {}
+WIDE_SCAN = _os.environ.get("MTRSSM_SCAN_WIDE", "1") != "0"
+WIDE_BWD = _os.environ.get("MTRSSM_SCAN_WIDE_BWD", "1") != "0"
+WIDE_PIECES = int(_os.environ.get("MTRSSM_WIDE_PIECES", "3"))
+_WS: dict[tuple, Tensor] = {}
+_WS_RETIRED: list[Tensor] = []
+
+
+def _workspace(device: torch.device, nbytes: int) -> Tensor:
+    """The cooperative kernels' workspace of the current stream of ``device`` (int64 words, >= nbytes, 256-byte aligned),
+    grown on demand; the sticky status word at its head survives the growth."""
+    key = (torch.device(device).index or 0, _lib.stream_ptr(device))
+    ws = _WS.get(key)
+    if ws is None or ws.numel() * 8 < nbytes:
+        new = torch.zeros((nbytes + 7) // 8 + 32, device=device, dtype=torch.int64)
+        if ws is not None:
+            new[:2].copy_(ws[:2])
+            _WS_RETIRED.append(ws)  # a captured hipGraph may still hold the old address
+        ws = _WS[key] = new
+        STATUS.watch(key, ws)
+    return ws
+
+
+def status_word(device: torch.device) -> Tensor | None:
+    """int32[1] view of the sticky status word of the current stream's workspace (None: no cooperative launch was made yet)."""
+    ws = _WS.get((torch.device(device).index or 0, _lib.stream_ptr(device)))
+    return None if ws is None else ws[:1].view(torch.int32)[:1]
+
+
+class StatusMonitor:
+    """Host side of the sticky status words.  ``post()`` starts an asynchronous copy of every watched word into pinned host
+    memory (no synchronisation); ``poll()`` raises if a copy that has COMPLETED shows a non-zero word -- so a failure surfaces
+    one ``opt.step()`` late, without ever stalling the enqueueing host (the device already skipped the update on its own);
+    ``check()`` synchronises and raises right away."""
+
+    def __init__(self) -> None:
+        self._words: dict[tuple, Tensor] = {}
+        self._pending: list[tuple[tuple, Tensor, object]] = []
+
+    def watch(self, key: tuple, ws: Tensor) -> None:
+        self._words[key] = ws
+
+    @staticmethod
+    def _raise(key: tuple, code: int) -> None:
+        msg = (f"cooperative scan kernel (workspace {key}): an exchange between workgroups timed out (status {code}); the results of "
+               "that step are invalid and the optimizer skipped its update.  The GPU was probably shared, partitioned or CU-masked: "
+               "set MTRSSM_SCAN_CLUSTER=0 MTRSSM_SCAN_WIDE=0")
+        raise _lib.MtrssmLibraryError(msg)
+
+    def post(self) -> None:
+        for key, ws in self._words.items():
+            word = ws[:1].view(torch.int32)[:1]
+            if word.is_cuda:
+                host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+                host.copy_(word, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(word.device))
+            else:  # CPU tensors stand in for the device words in the host-logic tests
+                host, ev = word.clone(), None
+            self._pending.append((key, host, ev))
+
+    def poll(self) -> None:
+        keep = []
+        for key, host, ev in self._pending:
+            if ev is not None and not ev.query():
+                keep.append((key, host, ev))
+                continue
+            code = int(host[0])
+            if code:
+                self._pending = []
+                self._raise(key, code)
+        self._pending = keep
+
+    def check(self) -> None:
+        for key, ws in self._words.items():
+            code = int(ws[:1].view(torch.int32)[0].item())
+            if code:
+                self._raise(key, code)
+
+    def reset(self) -> None:
+        """Clear every status word (after the caller dealt with a reported failure)."""
+        for ws in self._words.values():
+            ws[:1].zero_()
+        self._pending = []
+
+
+STATUS = StatusMonitor()
 
 
 def check_cluster_status() -> None:
-    """Synchronises and raises if a cluster-scan launch gave up on an exchange (its outputs are then invalid)."""
-    for key, ws in _CLUSTER_WS.items():
-        code = int(ws[:1].view(torch.int32)[0].item()) if ws.dtype == torch.int64 else 0
-        if code:
-            msg = f"cluster scan {key}: an exchange timed out (status {code}); the GPU was probably shared -- set MTRSSM_SCAN_CLUSTER=0"
-            raise _lib.MtrssmLibraryError(msg)
+    """Synchronises and raises if any cooperative scan launch so far gave up on an exchange (its outputs are then invalid)."""
+    STATUS.check()
 
 
 def _c(t: Tensor) -> Tensor:
@@ -176,8 +266,11 @@ class _MrssmScan(torch.autograd.Function):
         # S-wide rows, kl and (training) the saved activations; FLOPs = 2 x every weight element touched per row-step
         per_bt = 3 * H + 2 * K + D + 3 * S + 1 + (2 * H + 4 * D + 3 * H + 2 * S if need_grad else 0)
         macs = S * H + H * H + 3 * D * H + 3 * D * D + 3 * H * D + 3 * S * H
-        cluster = (CLUSTER_SCAN and cfg.rows_per_block == 0 and cfg.threads == 0 and bool(lib.mtrssm_mrssm_cluster_supported(C.byref(dims))))
-        if cluster:
+        plain = cfg.rows_per_block == 0 and cfg.threads == 0
+        cluster = CLUSTER_SCAN and plain and bool(lib.mtrssm_mrssm_cluster_supported(C.byref(dims)))
+        wide = WIDE_SCAN and plain and not cluster and bool(lib.mtrssm_mrssm_wide_supported(C.byref(dims), WIDE_PIECES))
+        ctx.scan_kind = "cluster" if cluster else ("wide" if wide else None)
+        if cluster or wide:
             # fused GRU input path: gi = (W_ih W2) h1 + (W_ih b2 + b_ih); two small GEMMs per launch (weights change every step)
             wf_t = _new(xa, H, 3 * D)
             gemm(w2, wih, wf_t, a_rmajor=True, b_rmajor=False)            # wf_t[k][j] = sum_h W2[h][k] W_ih[j][h]
@@ -185,15 +278,18 @@ class _MrssmScan(torch.autograd.Function):
             gemm(b2.reshape(1, H), wih, bf, a_rmajor=False, b_rmajor=False, bias=_c(bih))
             cw = _lib.fill(_lib.MrssmClusterWeights(), w1s_t=w1s_t, wf_t=wf_t, bf=bf.reshape(-1), whh_t=fw._refs["whh_t"], bhh=_c(bhh),  # noqa: SLF001
                            wh1_t=fw._refs["wh1_t"], b3=_c(b3), w4=_c(w4), b4=_c(b4), wa2=_c(wa2), ba2=_c(ba2), wv2=_c(wv2), bv2=_c(bv2))  # noqa: SLF001
-            nbytes_ws = int(lib.mtrssm_mrssm_cluster_workspace_bytes(C.byref(dims)))
-            key = (xa.device, _lib.stream_ptr(xa.device), B, D, S)
-            ws = _CLUSTER_WS.get(key)
-            if ws is None or ws.numel() * 8 < nbytes_ws:
-                ws = _CLUSTER_WS[key] = torch.zeros((nbytes_ws + 7) // 8, device=xa.device, dtype=torch.int64)
             io.sv_h2 = None  # not produced on this path: recomputed in the backward where dW_ih needs it
-            _lib.check(_lib.TIMERS.call("mtrssm_mrssm_rollout_fwd_cluster", lib.mtrssm_mrssm_rollout_fwd_cluster, C.byref(dims), C.byref(cw),
-                                        C.byref(io), _lib.raw_ptr(ws), ws.numel() * 8, _lib.stream_ptr(xa.device),
-                                        flops=2.0 * B * T * macs, nbytes=4.0 * B * T * per_bt), "mtrssm_mrssm_rollout_fwd_cluster")
+            stream = _lib.stream_ptr(xa.device)
+            if cluster:
+                ws = _workspace(xa.device, int(lib.mtrssm_mrssm_cluster_workspace_bytes(C.byref(dims))))
+                _lib.check(_lib.TIMERS.call("mtrssm_mrssm_rollout_fwd_cluster", lib.mtrssm_mrssm_rollout_fwd_cluster, C.byref(dims), C.byref(cw),
+                                            C.byref(io), _lib.raw_ptr(ws), ws.numel() * 8, stream,
+                                            flops=2.0 * B * T * macs, nbytes=4.0 * B * T * per_bt), "mtrssm_mrssm_rollout_fwd_cluster")
+            else:
+                ws = _workspace(xa.device, int(lib.mtrssm_mrssm_wide_workspace_bytes(C.byref(dims), WIDE_PIECES)))
+                _lib.check(_lib.TIMERS.call("mtrssm_mrssm_rollout_fwd_wide", lib.mtrssm_mrssm_rollout_fwd_wide, C.byref(dims), C.byref(cw),
+                                            C.byref(io), WIDE_PIECES, _lib.raw_ptr(ws), ws.numel() * 8, stream,
+                                            flops=2.0 * B * T * macs, nbytes=4.0 * B * T * per_bt), "mtrssm_mrssm_rollout_fwd_wide")
             sv["sv_h2"] = None
             ctx.cluster_w = (wf_t, fw._refs["whh_t"], fw._refs["wh1_t"])  # noqa: SLF001
         else:
@@ -244,18 +340,24 @@ class _MrssmScan(torch.autograd.Function):
         per_bt = (2 * H + 4 * D + 3 * H + 2 * S) + D + 2 * S + (D + S + 1) + 2 * H + 6 * D + 3 * H + 3 * S
         macs = S * H + H * H + 3 * D * H + 3 * D * D + 3 * H * D + 3 * S * H
         cw3 = getattr(ctx, "cluster_w", None)
-        if cw3 is not None and CLUSTER_SCAN and cfg.classes * cfg.cats <= 32:  # noqa: PLR2004
-            # the forward ran on four-CU clusters: so does the reverse scan (same resident-weight layout, csrc/mrssm_cluster.hip)
+        kind = getattr(ctx, "scan_kind", None)
+        use_cluster = kind == "cluster" and CLUSTER_SCAN and cfg.classes * cfg.cats <= 32  # noqa: PLR2004
+        use_wide = kind == "wide" and WIDE_SCAN and WIDE_BWD
+        if cw3 is not None and (use_cluster or use_wide):
+            # the forward ran cooperatively: so does the reverse scan (same fused input path, csrc/mrssm_cluster.hip / mrssm_wide.hip)
             wf_t, whh_t, wh1_t = cw3
             cw = _lib.fill(_lib.MrssmClusterWeights(), w1s_t=w1s_t, wf_t=wf_t, whh_t=whh_t, wh1_t=wh1_t, w4=_c(w4), wa2=_c(wa2), wv2=_c(wv2))
-            nbytes_ws = int(lib.mtrssm_mrssm_cluster_bwd_workspace_bytes(C.byref(dims)))
-            key = ("bwd", deter.device, _lib.stream_ptr(deter.device), B, D, S)
-            ws = _CLUSTER_WS.get(key)
-            if ws is None or ws.numel() * 8 < nbytes_ws:
-                ws = _CLUSTER_WS[key] = torch.zeros((nbytes_ws + 7) // 8, device=deter.device, dtype=torch.int64)
-            _lib.check(_lib.TIMERS.call("mtrssm_mrssm_rollout_bwd_cluster", lib.mtrssm_mrssm_rollout_bwd_cluster, C.byref(dims), C.byref(cw),
-                                        C.byref(io), _lib.raw_ptr(ws), ws.numel() * 8, _lib.stream_ptr(deter.device),
-                                        flops=2.0 * B * T * macs, nbytes=4.0 * B * T * per_bt), "mtrssm_mrssm_rollout_bwd_cluster")
+            stream = _lib.stream_ptr(deter.device)
+            if use_cluster:
+                ws = _workspace(deter.device, int(lib.mtrssm_mrssm_cluster_bwd_workspace_bytes(C.byref(dims))))
+                _lib.check(_lib.TIMERS.call("mtrssm_mrssm_rollout_bwd_cluster", lib.mtrssm_mrssm_rollout_bwd_cluster, C.byref(dims), C.byref(cw),
+                                            C.byref(io), _lib.raw_ptr(ws), ws.numel() * 8, stream,
+                                            flops=2.0 * B * T * macs, nbytes=4.0 * B * T * per_bt), "mtrssm_mrssm_rollout_bwd_cluster")
+            else:
+                ws = _workspace(deter.device, int(lib.mtrssm_mrssm_wide_bwd_workspace_bytes(C.byref(dims), WIDE_PIECES)))
+                _lib.check(_lib.TIMERS.call("mtrssm_mrssm_rollout_bwd_wide", lib.mtrssm_mrssm_rollout_bwd_wide, C.byref(dims), C.byref(cw),
+                                            C.byref(io), WIDE_PIECES, _lib.raw_ptr(ws), ws.numel() * 8, stream,
+                                            flops=2.0 * B * T * macs, nbytes=4.0 * B * T * per_bt), "mtrssm_mrssm_rollout_bwd_wide")
             # d_h2 = d_gi . W_ih for all (b, t) at once (the fused input path has no h2 inside the scan)
             gemm(_flat2(d_gi), wih, _flat2(d_h2), a_rmajor=False, b_rmajor=True)
         else:

@@ -34,11 +34,11 @@ class RemoveDim:
 
     def __init__(self, axis: int, indices_to_remove: list[int]) -> None:
         self.axis = axis
-        self.remove = indices_to_remove
+        self.dropped = frozenset(int(i) for i in indices_to_remove)
 
     def __call__(self, data: Tensor) -> Tensor:
-        keep = [i for i in range(data.size(self.axis)) if i not in self.remove]
-        return torch.index_select(data, self.axis, torch.tensor(keep, device=data.device))
+        kept = torch.tensor([i for i in range(data.size(self.axis)) if i not in self.dropped], device=data.device, dtype=torch.long)
+        return data.index_select(self.axis, kept)
 
 
 class TakeFirstN:
@@ -62,26 +62,22 @@ class GaussianNoise:
 
 
 class NormalizeVisionImage:
-    """[0, 255] -> [-1, 1]: ``x / 255 * 2 - 1`` on a copy (``transform.py:75-98``)."""
+    """[0, 255] -> [-1, 1]: ``x / 255 * 2 - 1``, never in place (``transform.py:75-98``)."""
 
     def __call__(self, data: Tensor) -> Tensor:
-        copy_data = data.detach().clone()
-        copy_data /= 255.0
-        return copy_data * 2.0 - 1.0
+        return (data.detach() / 255.0) * 2.0 - 1.0
 
 
 class NormalizeAudioMelSpectrogram:
-    """[min, max] -> [-1, 1]: ``(x - min) / (max - min) * 2 - 1`` on a copy (``transform.py:101-132``)."""
+    """[min, max] -> [-1, 1]: ``(x - min) / (max - min) * 2 - 1``, never in place (``transform.py:101-132``)."""
 
     def __init__(self, min_value: float = -80.0, max_value: float = 0.1) -> None:
         self.min_value = min_value
         self.max_value = max_value
-        self.range = max_value - min_value
 
     def __call__(self, data: Tensor) -> Tensor:
-        copy_data = data.detach().clone()
-        copy_data -= self.min_value
-        return (copy_data / self.range) * 2.0 - 1.0
+        span = self.max_value - self.min_value
+        return ((data.detach() - self.min_value) / span) * 2.0 - 1.0
 
 
 def fused_chain(transform: Transform | None) -> tuple[int | None, float | None] | None:

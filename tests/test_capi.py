@@ -73,9 +73,9 @@ def test_invalid_arguments_are_rejected_without_a_launch() -> None:
     assert lib.mtrssm_sumsq(None, 10, None, None) == -1
     assert lib.mtrssm_gaussian_nll_fwd(None, None, 1, 1, 0, None, None) == -1
     assert lib.mtrssm_gemm(C.byref(_lib.Gemm()), None) == -1 and b"gemm" in lib.mtrssm_last_error()
-    assert lib.mtrssm_adamw_prepare(None, 10, None, None, 0.9, 0.999, None) == -1
+    assert lib.mtrssm_adamw_prepare(None, 10, None, None, None, 0.9, 0.999, None) == -1
     assert lib.mtrssm_clear(None, 16, None) == -1
-    assert lib.mtrssm_adamw_apply(None, None, None, None, None, 10, None, None, 1.0, 1.0, 0.9, 0.999, 1e-8, 1e-2, None) == -1
+    assert lib.mtrssm_adamw_apply(None, None, None, None, None, 10, None, None, None, 1.0, 1.0, 0.9, 0.999, 1e-8, 1e-2, None) == -1
     # round-2 entries: argument errors are reported before anything is launched
     assert lib.mtrssm_conv_tgather_thin(1, 16, 8, 8, 9, 3, 3, 2, 1, 16, 16, None, None, None, 0, 0, None, None, None, None) == -1  # Cout > 8
     assert b"tgather" in lib.mtrssm_last_error()

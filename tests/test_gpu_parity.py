@@ -244,6 +244,51 @@ def test_cluster_scan_matches_single_cu_scan(name: str, batch: int, steps: int, 
 
 
 # ---------------------------------------------------------------------------------------------
+# wide scan (all CUs on one tile of 32 batch rows, MFMA products, grid barriers) against the single-CU scan
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize(("pieces", "batch", "steps"), [(3, 3, 4), (3, 37, 3), (2, 5, 6)])
+def test_wide_scan_matches_single_cu_scan(pieces: int, batch: int, steps: int, lib_loaded: None) -> None:
+    """csrc/mrssm_wide.hip (default for D or H >= 256: BASELINE configs[4] dims, D = H = 1024, S = 16 x 8) vs csrc/mrssm_scan.hip on
+    the same inputs, forward and BPTT: same samples, deter / probabilities to 5e-6 (three bf16 pieces per operand; the fused
+    W_ih W2 product rounds differently), losses to 5e-6, gradients to 2e-5 of the tensor's max (two pieces: 16 significant bits
+    per operand, tolerances x 20).  37 rows = two row tiles, the second one ragged; 3 and 5 rows = a partly filled MFMA tile."""
+    from multimodal_mtrssm_amd import scan
+
+    case = with_sizes(CASES["mrssm_large"], batch, steps)
+    oracle = build_model(case)
+    batch_t = tuple(b.to(DEV) for b in build_batch(case))
+    noise = _to(build_noise(case), DEV)
+    runs = {}
+    saved = (scan.WIDE_SCAN, scan.WIDE_PIECES)
+    for wide in (False, True):
+        scan.WIDE_SCAN, scan.WIDE_PIECES = wide, pieces
+        try:
+            model = product_from_case(case, oracle, DEV)
+            with torch.no_grad():
+                state0 = model.initial_state((batch_t[1][:, 0], batch_t[2][:, 0]), noise)
+                post, prior = model.rollout_representation(actions=batch_t[0], observations=(batch_t[1], batch_t[2]), prev_state=state0,
+                                                           noise=noise)
+            out = model.shared_step(batch_t, noise)
+            out["loss"].backward()
+            scan.check_cluster_status()
+            runs[wide] = (post, prior, {k: float(v) for k, v in out.items()},
+                          {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+        finally:
+            scan.WIDE_SCAN, scan.WIDE_PIECES = saved
+    (p0, q0, l0, g0), (p1, q1, l1, g1) = runs[False], runs[True]
+    loose = 1.0 if pieces == 3 else 20.0
+    assert torch.equal(p0.stoch, p1.stoch) and torch.equal(q0.stoch, q1.stoch)
+    np.testing.assert_allclose(_np(p1.deter), _np(p0.deter), atol=5e-6 * loose)
+    np.testing.assert_allclose(_np(p1.distribution.probs), _np(p0.distribution.probs), atol=5e-6 * loose)
+    np.testing.assert_allclose(_np(q1.distribution.probs), _np(q0.distribution.probs), atol=5e-6 * loose)
+    np.testing.assert_allclose(_np(p1.kl_per_step), _np(p0.kl_per_step), rtol=1e-4 * loose, atol=2e-6 * loose)
+    for k in l0:
+        np.testing.assert_allclose(l1[k], l0[k], rtol=5e-6 * loose, err_msg=k)
+    for k, g in g0.items():
+        np.testing.assert_allclose(_np(g1[k]), _np(g), rtol=1e-3, atol=2e-5 * loose * (float(g.abs().max()) + 1e-9), err_msg=k)
+
+
+# ---------------------------------------------------------------------------------------------
 # row-tile variants and ragged batches: every tiling gives the same answer
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name", ["mrssm_nonsquare", "mmtrssm_default"])
