@@ -59,9 +59,18 @@ static int launch_pack(const WidePackJobs& jobs, int pieces, hipStream_t stream)
   return MTRSSM_OK;
 }
 
+// Development aid (tools/wide_probe.py): when set, lane 0 of EVERY workgroup stamps s_memrealtime (100 MHz) at the phase
+// boundaries of timesteps 8..11 of the first row tile into this buffer: [workgroup][step - 8][16 stamps].  Null in normal use.
+__device__ unsigned long long* g_wide_prof = nullptr;
+#define MTRSSM_WIDE_STAMP(i)                                                                                              \
+  do {                                                                                                                    \
+    if (prof && tstamp >= 8 && tstamp < 12) prof[((size_t)blockIdx.x * 4 + (tstamp - 8)) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
+constexpr int kNS1 = 4, kNS3 = 2;   // register stages of the operand ring: one-tile units / the GRU's three-tile units
 constexpr int kAQ = 4;   // float4 columns of h1 per thread in the row phase: H <= 16 kWT
 
 struct WideFwdArgs {
@@ -92,6 +101,7 @@ __global__ __launch_bounds__(kWT) void mrssm_wide_fwd_kernel(const WideFwdArgs a
   float* rowv = lds + kWW * 4 * 2 * kWave * 4;
   float* Llp = rowv, *Lla = Llp + Sp, *Llv = Lla + Sp, *Lmx = Llv + Sp, *Ls = Lmx + Sp, *Lu = Ls + Sp;   // Lu: [2][64] uniforms
   int* abort_flag = reinterpret_cast<int*>(Lu + 128);
+  int* Lidx = abort_flag + 4;   // [64] flat index of the sampled class of each categorical
   if (tid == 0) *abort_flag = 0;
   __syncthreads();
   WideBarrier bar{a.bar, a.status, abort_flag, 0u, (unsigned)nblk};
@@ -137,8 +147,11 @@ __global__ __launch_bounds__(kWT) void mrssm_wide_fwd_kernel(const WideFwdArgs a
       dprev[0] = q.x; dprev[1] = q.y; dprev[2] = q.z; dprev[3] = q.w;
     }
     int cur = 0;
+    unsigned long long* const prof = (tid == 0 && rb == 0) ? g_wide_prof : nullptr;
 
     for (int t = 0; t <= T; ++t) {
+      const int tstamp = t;
+      MTRSSM_WIDE_STAMP(0);
       // ============ phase A: one workgroup per batch row (the last workgroups of the grid) ============
       for (int r = nblk - 1 - blk; r < nrows; r += nblk) {
         const size_t b = (size_t)(rb + r);
@@ -184,8 +197,16 @@ __global__ __launch_bounds__(kWT) void mrssm_wide_fwd_kernel(const WideFwdArgs a
           lds_barrier();
         }
         if (t < T) {
-          // h1 = act(xa + W1s s): fp32.  t > 0: s is one-hot per categorical -> the sum of K rows of w1s_t; t = 0: stoch0 is
-          // whatever the caller passed: dense.
+          // h1 = act(xa + W1s s): fp32.  t > 0: s is one-hot per categorical -> the sum of K rows of w1s_t (row indices from the
+          // sample, the K loads of a thread issued eight at a time); t = 0: stoch0 is whatever the caller passed: dense.
+          if (t > 0) {
+            if (tid < K) {
+              int idx = 0;
+              for (int c = 1; c < C; ++c) idx = Ls[tid * C + c] != 0.f ? c : idx;
+              Lidx[tid] = tid * C + idx;
+            }
+            lds_barrier();
+          }
 #pragma unroll
           for (int i = 0; i < kAQ; ++i) {
             const int c4 = tid + i * kWT;
@@ -193,11 +214,13 @@ __global__ __launch_bounds__(kWT) void mrssm_wide_fwd_kernel(const WideFwdArgs a
               float acc[4] = {xa4[i].x, xa4[i].y, xa4[i].z, xa4[i].w};
               const float* wc = w.w1s_t + (size_t)c4 * 4;
               if (t > 0) {
-                for (int k = 0; k < K; ++k) {
-                  int idx = 0;
-                  for (int c = 1; c < C; ++c) idx = Ls[k * C + c] != 0.f ? c : idx;
-                  const float4 q4 = *reinterpret_cast<const float4*>(wc + (size_t)(k * C + idx) * H);
-                  acc[0] += q4.x; acc[1] += q4.y; acc[2] += q4.z; acc[3] += q4.w;
+                for (int k0 = 0; k0 < K; k0 += 8) {
+                  float4 q4[8];
+#pragma unroll
+                  for (int j = 0; j < 8; ++j) q4[j] = *reinterpret_cast<const float4*>(wc + (size_t)Lidx[k0 + j < K ? k0 + j : K - 1] * H);
+#pragma unroll
+                  for (int j = 0; j < 8; ++j)
+                    if (k0 + j < K) { acc[0] += q4[j].x; acc[1] += q4[j].y; acc[2] += q4[j].z; acc[3] += q4[j].w; }
                 }
               } else {
                 for (int s2 = 0; s2 < S; ++s2) {
@@ -217,7 +240,9 @@ __global__ __launch_bounds__(kWT) void mrssm_wide_fwd_kernel(const WideFwdArgs a
         lds_barrier();
       }
       if (t == T) break;
+      MTRSSM_WIDE_STAMP(1);
       if (!bar.sync(1 + 4 * t)) return;
+      MTRSSM_WIDE_STAMP(2);
 
       // ============ phase B: GRU, one workgroup per 16 deter columns ============
       for (int u = blk; u < NTD; u += nblk) {
@@ -228,8 +253,8 @@ __global__ __launch_bounds__(kWT) void mrssm_wide_fwd_kernel(const WideFwdArgs a
           for (int rt = 0; rt < 2; ++rt) { accA[g][rt] = wf32x4{0.f, 0.f, 0.f, 0.f}; accB[g][rt] = wf32x4{0.f, 0.f, 0.f, 0.f}; }
         const uint4* const wtA[3] = {a.pk_wf + (size_t)u * tileH, a.pk_wf + (size_t)(NTD + u) * tileH, a.pk_wf + (size_t)(2 * NTD + u) * tileH};
         const uint4* const wtB[3] = {a.pk_whh + (size_t)u * tileD, a.pk_whh + (size_t)(NTD + u) * tileD, a.pk_whh + (size_t)(2 * NTD + u) * tileD};
-        wide_mfma_stream<3, P>(accB, wtB, a.x_d[cur], KSD, ks0d, ks1d, lane);   // gh first: its operand has been there longest
-        wide_mfma_stream<3, P>(accA, wtA, a.x_h1, KSH, ks0h, ks1h, lane);
+        wide_mfma_stream<3, P, kNS3>(accB, wtB, a.x_d[cur], KSD, ks0d, ks1d, lane);   // gh first: its operand has been there longest
+        wide_mfma_stream<3, P, kNS3>(accA, wtA, a.x_h1, KSH, ks0h, ks1h, lane);
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) { accA[0][rt] += accB[0][rt]; accA[1][rt] += accB[1][rt]; }
         wide_red_store<4>(red, wave, 0, lane, accA[0]);
@@ -269,7 +294,9 @@ __global__ __launch_bounds__(kWT) void mrssm_wide_fwd_kernel(const WideFwdArgs a
         lds_barrier();
       }
       cur ^= 1;
+      MTRSSM_WIDE_STAMP(3);
       if (!bar.sync(2 + 4 * t)) return;
+      MTRSSM_WIDE_STAMP(4);
 
       // ============ phase C: head layer 0 on the new deter, one workgroup per 16 of the 3H columns ============
       for (int u = blk; u < 3 * NTH; u += nblk) {
@@ -281,7 +308,7 @@ __global__ __launch_bounds__(kWT) void mrssm_wide_fwd_kernel(const WideFwdArgs a
         }
         wf32x4 acc[1][2] = {{wf32x4{0.f, 0.f, 0.f, 0.f}, wf32x4{0.f, 0.f, 0.f, 0.f}}};
         const uint4* const wt[1] = {a.pk_wh1 + (size_t)u * tileD};
-        wide_mfma_stream<1, P>(acc, wt, a.x_d[cur], KSD, ks0d, ks1d, lane);
+        wide_mfma_stream<1, P, kNS1>(acc, wt, a.x_d[cur], KSD, ks0d, ks1d, lane);
         wide_red_store<1>(red, wave, 0, lane, acc[0]);
         lds_barrier();
         if (e_valid) {
@@ -292,14 +319,16 @@ __global__ __launch_bounds__(kWT) void mrssm_wide_fwd_kernel(const WideFwdArgs a
         }
         lds_barrier();
       }
+      MTRSSM_WIDE_STAMP(5);
       if (!bar.sync(3 + 4 * t)) return;
+      MTRSSM_WIDE_STAMP(6);
 
       // ============ phase D: head layer 1, one workgroup per 16 logits ============
       for (int u = blk; u < 3 * NTS; u += nblk) {
         const int which = u / NTS, st = u - which * NTS;
         wf32x4 acc[1][2] = {{wf32x4{0.f, 0.f, 0.f, 0.f}, wf32x4{0.f, 0.f, 0.f, 0.f}}};
         const uint4* const wt[1] = {a.pk_h2[which] + (size_t)st * tileH};
-        wide_mfma_stream<1, P>(acc, wt, a.x_hd[which], KSH, ks0h, ks1h, lane);
+        wide_mfma_stream<1, P, kNS1>(acc, wt, a.x_hd[which], KSH, ks0h, ks1h, lane);
         wide_red_store<1>(red, wave, 0, lane, acc[0]);
         lds_barrier();
         if (e_valid) {
@@ -310,7 +339,9 @@ __global__ __launch_bounds__(kWT) void mrssm_wide_fwd_kernel(const WideFwdArgs a
         }
         lds_barrier();
       }
+      MTRSSM_WIDE_STAMP(7);
       if (!bar.sync(4 + 4 * t)) return;
+      MTRSSM_WIDE_STAMP(8);
     }
     if (!bar.sync(0x40000000)) return;   // the next tile's set-up overwrites the exchange vectors
   }
@@ -347,8 +378,8 @@ __global__ __launch_bounds__(kWT) void mrssm_wide_bwd_kernel(const WideBwdArgs a
   wf32x4* red = reinterpret_cast<wf32x4*>(lds);   // 4 waves x 1 tile x 2 row tiles x 64 lanes x 16 B = 8 KiB
   float* rowv = lds + kWW * 1 * 2 * kWave * 4;
   float* Lla = rowv, *Llv = Lla + Sp, *Lmx = Llv + Sp, *Llp = Lmx + Sp, *Ldmx = Llp + Sp, *Ldlp = Ldmx + Sp, *Ldla = Ldlp + Sp, *Ldlv = Ldla + Sp;
-  float* Lcs = Ldlv + Sp;
-  int* abort_flag = reinterpret_cast<int*>(Lcs + Sp);
+  float* Lcs = Ldlv + Sp, *Lgps = Lcs + Sp;
+  int* abort_flag = reinterpret_cast<int*>(Lgps + Sp);
   if (tid == 0) *abort_flag = 0;
   __syncthreads();
   WideBarrier bar{a.bar, a.status, abort_flag, 0u, (unsigned)nblk};
@@ -386,8 +417,11 @@ __global__ __launch_bounds__(kWT) void mrssm_wide_bwd_kernel(const WideBwdArgs a
     }
     float cd[4] = {0.f, 0.f, 0.f, 0.f};    // carry into d_{t-1}: owned by the workgroup of these 16 deter columns (phases R2, R3)
     float ddz[4] = {0.f, 0.f, 0.f, 0.f};
+    unsigned long long* const prof = (tid == 0 && rb == 0) ? g_wide_prof : nullptr;
 
     for (int t = T - 1; t >= 0; --t) {
+      const int tstamp = T - 1 - t;
+      MTRSSM_WIDE_STAMP(0);
       // ============ R0: categorical block + MoPoE mix backward, one workgroup per batch row ============
       for (int r = nblk - 1 - blk; r < nrows; r += nblk) {
         const size_t q = (size_t)(rb + r) * T + t;
@@ -397,14 +431,15 @@ __global__ __launch_bounds__(kWT) void mrssm_wide_bwd_kernel(const WideBwdArgs a
           Lmx[s2] = io.post_logits[q * S + s2];
           Llp[s2] = io.prior_logits[q * S + s2];
           Lcs[s2] = t == T - 1 ? 0.f : a.cs[(size_t)r * Sp + s2];
+          Lgps[s2] = io.g_post_stoch ? io.g_post_stoch[q * S + s2] : 0.f;   // (read twice per class by one lane: from LDS, not L2)
         }
         lds_barrier();
         if (wave == 0) {
           const float gk = io.g_kl ? io.g_kl[q] : 0.f;
-          cat_block_bwd(Lmx, Llp, K, C, lane, io.g_post_stoch ? io.g_post_stoch + q * S : nullptr, Lcs,
+          cat_block_bwd<true>(Lmx, Llp, K, C, lane, Lgps, Lcs,
                         io.g_prior_stoch ? io.g_prior_stoch + q * S : nullptr, io.g_post_logits ? io.g_post_logits + q * S : nullptr,
                         io.g_prior_logits ? io.g_prior_logits + q * S : nullptr, gk, a.dm.kl_w_post, a.dm.kl_w_prior, Ldmx, Ldlp);
-          wave_mopoe_mix_bwd(Lla, Llv, Lmx, Ldmx, Ldla, Ldlv, S, lane);
+          wave_mopoe_mix_bwd<true>(Lla, Llv, Lmx, Ldmx, Ldla, Ldlv, S, lane);
         }
         lds_barrier();
         for (int i = tid; i < 3 * (Sp / 4); i += kWT) {
@@ -421,7 +456,9 @@ __global__ __launch_bounds__(kWT) void mrssm_wide_bwd_kernel(const WideBwdArgs a
         }
         lds_barrier();
       }
+      MTRSSM_WIDE_STAMP(1);
       if (!bar.sync(1 + 5 * t)) return;
+      MTRSSM_WIDE_STAMP(2);
 
       // ============ R1: dzh = act'(hd) * (W2nd^T dl), one workgroup per 16 of the 3H head units ============
       for (int u = blk; u < 3 * NTH; u += nblk) {
@@ -432,7 +469,7 @@ __global__ __launch_bounds__(kWT) void mrssm_wide_bwd_kernel(const WideBwdArgs a
         krange(KSS, k0, k1);
         wf32x4 acc[1][2] = {{wf32x4{0.f, 0.f, 0.f, 0.f}, wf32x4{0.f, 0.f, 0.f, 0.f}}};
         const uint4* const wt[1] = {a.pk_h2t[which] + (size_t)(u - which * NTH) * tileS};
-        wide_mfma_stream<1, P>(acc, wt, a.x_dl[which], KSS, k0, k1, lane);
+        wide_mfma_stream<1, P, kNS1>(acc, wt, a.x_dl[which], KSS, k0, k1, lane);
         wide_red_store<1>(red, wave, 0, lane, acc[0]);
         lds_barrier();
         if (e_valid) {
@@ -444,7 +481,9 @@ __global__ __launch_bounds__(kWT) void mrssm_wide_bwd_kernel(const WideBwdArgs a
         }
         lds_barrier();
       }
+      MTRSSM_WIDE_STAMP(3);
       if (!bar.sync(2 + 5 * t)) return;
+      MTRSSM_WIDE_STAMP(4);
 
       // ============ R2: dd = g_deter + carry + Wh1^T dzh, GRU gate gradients; one workgroup per 16 deter columns ============
       for (int u = blk; u < NTD; u += nblk) {
@@ -464,7 +503,7 @@ __global__ __launch_bounds__(kWT) void mrssm_wide_bwd_kernel(const WideBwdArgs a
         krange(KS3H, k0, k1);
         wf32x4 acc[1][2] = {{wf32x4{0.f, 0.f, 0.f, 0.f}, wf32x4{0.f, 0.f, 0.f, 0.f}}};
         const uint4* const wt[1] = {a.pk_wh1t + (size_t)u * tile3H};
-        wide_mfma_stream<1, P>(acc, wt, a.x_dzh, KS3H, k0, k1, lane);
+        wide_mfma_stream<1, P, kNS1>(acc, wt, a.x_dzh, KS3H, k0, k1, lane);
         wide_red_store<1>(red, wave, 0, lane, acc[0]);
         lds_barrier();
         if (e_valid) {
@@ -496,7 +535,9 @@ __global__ __launch_bounds__(kWT) void mrssm_wide_bwd_kernel(const WideBwdArgs a
         }
         lds_barrier();
       }
+      MTRSSM_WIDE_STAMP(5);
       if (!bar.sync(3 + 5 * t)) return;
+      MTRSSM_WIDE_STAMP(6);
 
       // ============ R3: carry_d = dd z + W_hh^T dgh (the workgroups of R2)  |  dz1 = act'(h1) (W_ih W2)^T dgi ============
       for (int u = blk; u < NTD + NTH; u += nblk) {
@@ -508,7 +549,7 @@ __global__ __launch_bounds__(kWT) void mrssm_wide_bwd_kernel(const WideBwdArgs a
         krange(KS3D, k0, k1);
         wf32x4 acc[1][2] = {{wf32x4{0.f, 0.f, 0.f, 0.f}, wf32x4{0.f, 0.f, 0.f, 0.f}}};
         const uint4* const wt[1] = {is_cd ? a.pk_whht + (size_t)u * tile3D : a.pk_wft + (size_t)(u - NTD) * tile3D};
-        wide_mfma_stream<1, P>(acc, wt, is_cd ? a.x_dgh : a.x_dgi, KS3D, k0, k1, lane);
+        wide_mfma_stream<1, P, kNS1>(acc, wt, is_cd ? a.x_dgh : a.x_dgi, KS3D, k0, k1, lane);
         wide_red_store<1>(red, wave, 0, lane, acc[0]);
         lds_barrier();
         if (e_valid) {
@@ -526,7 +567,9 @@ __global__ __launch_bounds__(kWT) void mrssm_wide_bwd_kernel(const WideBwdArgs a
         }
         lds_barrier();
       }
+      MTRSSM_WIDE_STAMP(7);
       if (!bar.sync(4 + 5 * t)) return;
+      MTRSSM_WIDE_STAMP(8);
 
       // ============ R4: carry_s = W1s^T dz1, one workgroup per 16 stochastic units ============
       for (int u = blk; u < NTS; u += nblk) {
@@ -534,7 +577,7 @@ __global__ __launch_bounds__(kWT) void mrssm_wide_bwd_kernel(const WideBwdArgs a
         krange(KSH, k0, k1);
         wf32x4 acc[1][2] = {{wf32x4{0.f, 0.f, 0.f, 0.f}, wf32x4{0.f, 0.f, 0.f, 0.f}}};
         const uint4* const wt[1] = {a.pk_w1s + (size_t)u * tileH};
-        wide_mfma_stream<1, P>(acc, wt, a.x_dz1, KSH, k0, k1, lane);
+        wide_mfma_stream<1, P, kNS1>(acc, wt, a.x_dz1, KSH, k0, k1, lane);
         wide_red_store<1>(red, wave, 0, lane, acc[0]);
         lds_barrier();
         if (e_valid) {
@@ -551,7 +594,9 @@ __global__ __launch_bounds__(kWT) void mrssm_wide_bwd_kernel(const WideBwdArgs a
         }
         lds_barrier();
       }
+      MTRSSM_WIDE_STAMP(9);
       if (!bar.sync(5 + 5 * t)) return;
+      MTRSSM_WIDE_STAMP(10);
     }
   }
 }
@@ -559,6 +604,11 @@ __global__ __launch_bounds__(kWT) void mrssm_wide_bwd_kernel(const WideBwdArgs a
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+int debug_set_wide_profile(void* buf) {
+  unsigned long long* p = static_cast<unsigned long long*>(buf);
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_wide_prof), &p, sizeof(p)) == hipSuccess ? MTRSSM_OK : MTRSSM_ELAUNCH;
+}
+
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 constexpr size_t kWideCtl = 256;   // [0] sticky status word (never cleared by a launch), [64] barrier counter
 
@@ -640,12 +690,12 @@ static int wide_grid(const MtrssmMrssmDims* d) {
 
 static size_t wide_fwd_lds(const MtrssmMrssmDims* d) {
   const int Sp = (d->K * d->C + 15) / 16 * 16;
-  size_t need = (size_t)kWW * 4 * 2 * kWave * 16 + ((size_t)5 * Sp + 128 + 4) * sizeof(float);
+  size_t need = (size_t)kWW * 4 * 2 * kWave * 16 + ((size_t)5 * Sp + 128 + 4 + 64) * sizeof(float);
   return need < 84 * 1024 ? 84 * 1024 : need;    // > 80 KiB: never two workgroups on one CU
 }
 static size_t wide_bwd_lds(const MtrssmMrssmDims* d) {
   const int Sp = (d->K * d->C + 15) / 16 * 16;
-  size_t need = (size_t)kWW * 1 * 2 * kWave * 16 + ((size_t)9 * Sp + 4) * sizeof(float);
+  size_t need = (size_t)kWW * 1 * 2 * kWave * 16 + ((size_t)10 * Sp + 4) * sizeof(float);
   return need < 84 * 1024 ? 84 * 1024 : need;
 }
 

@@ -374,6 +374,7 @@ __device__ __forceinline__ float cat_block_fwd_fast8(const float* q_logits, cons
 // (kl balancing: w_post = 1-alpha, w_prior = alpha; distribution_extension.kl_divergence restated
 //  in oracle/ref_dists.py).  Global gradient row pointers may be null (= zero).
 // ---------------------------------------------------------------------------------------
+template <bool FAST = false>
 __device__ __forceinline__ void cat_block_bwd(const float* q_logits, const float* p_logits, int K, int C, int lane,
                                               const float* g_post_stoch, const float* carry_s,
                                               const float* g_prior_stoch, const float* g_post_logits,
@@ -383,22 +384,23 @@ __device__ __forceinline__ void cat_block_bwd(const float* q_logits, const float
     const float* ql = q_logits + k * C;
     const float* pl = p_logits + k * C;
     float qm, qs, pm, ps;
-    cat_stats(ql, C, qm, qs);
-    cat_stats(pl, C, pm, ps);
-    const float lqs = logf(qs), lps = logf(ps);
+    cat_stats<FAST>(ql, C, qm, qs);
+    cat_stats<FAST>(pl, C, pm, ps);
+    const float lqs = clog<FAST>(qs), lps = clog<FAST>(ps);
+    const float rq = 1.f / qs, rp = 1.f / ps;
     float dot = 0.f, klk = 0.f, pdot = 0.f;
     for (int c = 0; c < C; ++c) {
       const int s = k * C + c;
-      const float qc = expf(ql[c] - qm) / qs;
+      const float qc = FAST ? cexp<FAST>(ql[c] - qm) * rq : expf(ql[c] - qm) / qs;
       const float gq = (g_post_stoch ? g_post_stoch[s] : 0.f) + carry_s[s];
       dot += qc * gq;
       klk += qc * (((ql[c] - qm) - lqs) - ((pl[c] - pm) - lps));
-      if (g_prior_stoch) pdot += (expf(pl[c] - pm) / ps) * g_prior_stoch[s];
+      if (g_prior_stoch) pdot += (FAST ? cexp<FAST>(pl[c] - pm) * rp : expf(pl[c] - pm) / ps) * g_prior_stoch[s];
     }
     for (int c = 0; c < C; ++c) {
       const int s = k * C + c;
-      const float qc = expf(ql[c] - qm) / qs;
-      const float pc = expf(pl[c] - pm) / ps;
+      const float qc = FAST ? cexp<FAST>(ql[c] - qm) * rq : expf(ql[c] - qm) / qs;
+      const float pc = FAST ? cexp<FAST>(pl[c] - pm) * rp : expf(pl[c] - pm) / ps;
       const float gq = (g_post_stoch ? g_post_stoch[s] : 0.f) + carry_s[s];
       const float diff = ((ql[c] - qm) - lqs) - ((pl[c] - pm) - lps);
       float a = qc * (gq - dot) + gk * w_post * qc * (diff - klk);
@@ -413,17 +415,18 @@ __device__ __forceinline__ void cat_block_bwd(const float* q_logits, const float
 }
 
 // Backward of wave_mopoe_mix: given d mixed (dmx, LDS) and the saved expert logits, writes d la / d lv (LDS).
+template <bool FAST = false>
 __device__ __forceinline__ void wave_mopoe_mix_bwd(const float* la, const float* lv, const float* mixed, const float* dmx,
                                                    float* dla, float* dlv, int S, int lane) {
   float ma, lsa, mv, lsv;
-  wave_flat_lse(la, S, lane, ma, lsa);
-  wave_flat_lse(lv, S, lane, mv, lsv);
+  wave_flat_lse<FAST>(la, S, lane, ma, lsa);
+  wave_flat_lse<FAST>(lv, S, lane, mv, lsv);
   float suma = 0.f, sumv = 0.f;
   for (int s = lane; s < S; s += kWave) {
     const float a = (la[s] - ma) - lsa;
     const float v = (lv[s] - mv) - lsv;
     const float mx = mixed[s];
-    const float wa = expf(kLogThird + a - mx), wv = expf(kLogThird + v - mx), wf = expf(kLogThird + a + v - mx);
+    const float wa = cexp<FAST>(kLogThird + a - mx), wv = cexp<FAST>(kLogThird + v - mx), wf = cexp<FAST>(kLogThird + a + v - mx);
     const float g = dmx[s];
     const float da = g * (wa + wf), dv = g * (wv + wf);
     dla[s] = da;
@@ -434,8 +437,8 @@ __device__ __forceinline__ void wave_mopoe_mix_bwd(const float* la, const float*
   suma = wave_sum(suma);
   sumv = wave_sum(sumv);
   for (int s = lane; s < S; s += kWave) {
-    dla[s] -= expf((la[s] - ma) - lsa) * suma;
-    dlv[s] -= expf((lv[s] - mv) - lsv) * sumv;
+    dla[s] -= cexp<FAST>((la[s] - ma) - lsa) * suma;
+    dlv[s] -= cexp<FAST>((lv[s] - mv) - lsv) * sumv;
   }
 }
 

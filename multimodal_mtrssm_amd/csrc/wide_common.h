@@ -82,25 +82,27 @@ __device__ __forceinline__ void wide_x_store4(uint4* xb, int KS, int row, int k,
 }
 
 // acc[nt][rt] += W_tile[nt] (16 outputs x K) . x (K x 16 rows of row tile rt) over this wave's k-blocks [ks0, ks1).
-// wt[nt]: the tile's fragment array ([ks][piece][lane]); xb: exchange vector.  Loads of block ks + 1 are issued before the
-// MFMAs of block ks.  Products: piece pairs (a, b) with a + b < P, smallest terms first.
-template <int NT, int P>
+// wt[nt]: the tile's fragment array ([ks][piece][lane]); xb: exchange vector.  A CU streams these operands from L2 / MALL at
+// the rate its loads in flight allow (measured with two k-blocks in flight per wave: 61 GB/s per CU, the latency-bound
+// "handed-off payload" rate of the guide), so the loop keeps NS - 1 k-blocks (NS (NT + 2) P KiB per wave) requested ahead of
+// the MFMAs in a ring of register stages with static indices.  Products: piece pairs (a, b) with a + b < P, smallest first.
+template <int NT, int P, int NS>
 __device__ __forceinline__ void wide_mfma_stream(wf32x4 (&acc)[NT][2], const uint4* const (&wt)[NT], const uint4* __restrict__ xb, int KS,
                                                  int ks0, int ks1, int lane) {
   if (ks0 >= ks1) return;
   const int xlane = (lane & 15) * 4 + (lane >> 4);
-  uint4 a[2][NT][P], b[2][2][P];
-  auto load = [&](int buf, int ks) {
+  uint4 a[NS][NT][P], b[NS][2][P];
+  auto load = [&](int st, int ks) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int p = 0; p < P; ++p) a[buf][nt][p] = wt[nt][((size_t)ks * P + p) * 64 + lane];
+      for (int p = 0; p < P; ++p) a[st][nt][p] = wt[nt][((size_t)ks * P + p) * 64 + lane];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-      for (int p = 0; p < P; ++p) b[buf][rt][p] = xb[(size_t)((p * KS + ks) * kWRows + 16 * rt) * 4 + xlane];
+      for (int p = 0; p < P; ++p) b[st][rt][p] = xb[(size_t)((p * KS + ks) * kWRows + 16 * rt) * 4 + xlane];
   };
-  auto compute = [&](int buf) {
+  auto compute = [&](int st) {
 #pragma unroll
     for (int ord = P - 1; ord >= 0; --ord)
 #pragma unroll
@@ -109,18 +111,21 @@ __device__ __forceinline__ void wide_mfma_stream(wf32x4 (&acc)[NT][2], const uin
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
           for (int rt = 0; rt < 2; ++rt)
-            acc[nt][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wbf16x8, a[buf][nt][pa]),
-                                                                  __builtin_bit_cast(wbf16x8, b[buf][rt][ord - pa]), acc[nt][rt], 0, 0, 0);
+            acc[nt][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wbf16x8, a[st][nt][pa]),
+                                                                  __builtin_bit_cast(wbf16x8, b[st][rt][ord - pa]), acc[nt][rt], 0, 0, 0);
   };
-  load(0, ks0);
-  int ks = ks0;
-  for (; ks + 2 <= ks1; ks += 2) {   // two blocks per trip: the register buffers keep static indices
-    load(1, ks + 1);
-    compute(0);
-    if (ks + 2 < ks1) load(0, ks + 2);
-    compute(1);
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (ks0 + s < ks1) load(s, ks0 + s);
+  for (int ks = ks0; ks < ks1; ks += NS) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {   // static stage indices: block ks + s sits in stage s
+      if (ks + s < ks1) {
+        if (ks + s + NS - 1 < ks1) load((s + NS - 1) % NS, ks + s + NS - 1);
+        compute(s);
+      }
+    }
   }
-  if (ks < ks1) compute(0);
 }
 
 // Cross-wave reduction through LDS: red[(wave NTOT + tile) 2 + rt][lane] (float4 each).

@@ -1,0 +1,52 @@
+"""Phase timing of the wide scan (profiling helper): s_memrealtime stamps (100 MHz) of EVERY workgroup at the phase boundaries
+of timesteps 8..11 (csrc/mrssm_wide.hip: MTRSSM_WIDE_STAMP).  Usage on the GPU box: python tools/wide_probe.py [fwd|bwd]
+
+Per phase it prints, over the workgroups that had work in it, the median / maximum span of the work itself and, over all
+workgroups, the span of the barrier that follows (arrival of the LAST workgroup -> everybody released)."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from multimodal_mtrssm_amd import _lib
+
+which = sys.argv[1] if len(sys.argv) > 1 else "fwd"
+bench.WORKLOAD = bench.WORKLOADS["large"]
+dev = "cuda:0"
+model = bench.build_model(dev, "large")
+batch = bench.synthetic_batch(32, dev, 1)
+lib = _lib.load()
+nblk = torch.cuda.get_device_properties(0).multi_processor_count
+buf = torch.zeros(nblk * 4 * 16, dtype=torch.int64, device=dev)
+fn = lib.mtrssm_debug_set_wide_profile
+fn.argtypes, fn.restype = [ctypes.c_void_p], ctypes.c_int
+names = {"fwd": ["A row: cat + h1", "B gru", "C heads0", "D logits"], "bwd": ["R0 row: cat bwd", "R1 dzh", "R2 gates", "R3 carry/dz1", "R4 carry_s"]}[which]
+for it in range(3):
+    if which == "fwd":
+        assert fn(buf.data_ptr()) == 0
+        with torch.no_grad():
+            model.shared_step(batch, None)
+        torch.cuda.synchronize()
+        assert fn(None) == 0
+    else:
+        out = model.shared_step(batch, None)
+        torch.cuda.synchronize()
+        buf.zero_()
+        assert fn(buf.data_ptr()) == 0
+        out["loss"].backward()
+        torch.cuda.synchronize()
+        assert fn(None) == 0
+    st = buf.cpu().view(nblk, 4, 16).double() * 0.01  # microseconds
+    n = len(names)
+    for step in (1, 2):
+        s = st[:, step]
+        t0 = s[:, 0].min()
+        print(f"iter {it} step {8 + step}: whole step {float(s[:, 2 * n].max() - t0):7.2f} us")
+        for p, name in enumerate(names):
+            work = s[:, 2 * p + 1] - s[:, 2 * p]          # phase start -> own arrival at the barrier
+            busy = work[work > 0.3]
+            last_arrival = s[:, 2 * p + 1].max()
+            release = s[:, 2 * p + 2]
+            print(f"   {name:18s} work: {busy.numel():3d} wgs median {float(busy.median()) if busy.numel() else 0:6.2f} max {float(work.max()):6.2f} us"
+                  f" | phase start spread {float(s[:, 2 * p].max() - s[:, 2 * p].min()):5.2f}"
+                  f" | barrier: last arrival -> release median {float((release - last_arrival).median()):5.2f} max {float((release - last_arrival).max()):5.2f} us"
+                  f" | phase wall {float(release.max() - s[:, 2 * p].min()):6.2f}")
