@@ -558,9 +558,14 @@ __global__ __launch_bounds__(kCluThreads) void mrssm_bwd_cluster_kernel(const Mt
 
       // (b) categorical block: straight-through sample, KL, per-categorical softmax, MoE/PoE, flat log-softmax (one wave)
       if (wave == 3) {
-        cat_block_bwd<true>(lds + Lmx, lds + Llp, K, C, lane, lds + Lgps, lds + Lcs, io.g_prior_stoch ? io.g_prior_stoch + bt * S : nullptr,
-                      io.g_post_logits ? io.g_post_logits + bt * S : nullptr, io.g_prior_logits ? io.g_prior_logits + bt * S : nullptr,
-                      *gk_lds, dm.kl_w_post, dm.kl_w_prior, lds + Ldmx, lds + Ldlp);
+        if (C <= 8)
+          cat_block_bwd_fast8(lds + Lmx, lds + Llp, K, C, lane, lds + Lgps, lds + Lcs, io.g_prior_stoch ? io.g_prior_stoch + bt * S : nullptr,
+                              io.g_post_logits ? io.g_post_logits + bt * S : nullptr, io.g_prior_logits ? io.g_prior_logits + bt * S : nullptr,
+                              *gk_lds, dm.kl_w_post, dm.kl_w_prior, lds + Ldmx, lds + Ldlp);
+        else
+          cat_block_bwd<true>(lds + Lmx, lds + Llp, K, C, lane, lds + Lgps, lds + Lcs, io.g_prior_stoch ? io.g_prior_stoch + bt * S : nullptr,
+                              io.g_post_logits ? io.g_post_logits + bt * S : nullptr, io.g_prior_logits ? io.g_prior_logits + bt * S : nullptr,
+                              *gk_lds, dm.kl_w_post, dm.kl_w_prior, lds + Ldmx, lds + Ldlp);
         wave_mopoe_mix_bwd<true>(lds + Lla, lds + Llv, lds + Lmx, lds + Ldmx, lds + Ldla, lds + Ldlv, S, lane);
         if (member == 0) {
           for (int s2 = lane; s2 < S; s2 += kWave) {

@@ -13,6 +13,8 @@
 // R2 dd = g + carry + Wh1^T dzh and the gate gradients; R3 carry_d += W_hh^T dgh | dz1 = act'(h1) (W_ih W2)^T dgi;
 // R4 carry_s = W1s^T dz1.  As in the four-CU cluster kernels the GRU input path is fused (wf_t = (W_ih W2)^T, sv_h2 / d_h2
 // are not produced: the caller forms them as batched GEMMs).
+#include <cstdlib>
+
 #include "wide_common.h"
 
 namespace mtrssm {
@@ -80,9 +82,10 @@ struct WideFwdArgs {
   const uint4 *pk_wf, *pk_whh, *pk_wh1, *pk_h2[3];   // packed weights (pk_h2: prior / audio / vision second layers)
   uint4 *x_h1, *x_d[2], *x_hd[3];                     // exchange vectors
   float* lg;                                          // [32][3][Sp] raw logits of the step (without bias)
-  unsigned* bar;
+  void* ctl;                                           // control block (barrier words)
   int* status;
   int nblk;
+  int acquire;                                         // 1: an agent acquire fence after every barrier (A/B switch)
 };
 
 template <int P>
@@ -104,7 +107,8 @@ __global__ __launch_bounds__(kWT) void mrssm_wide_fwd_kernel(const WideFwdArgs a
   int* Lidx = abort_flag + 4;   // [64] flat index of the sampled class of each categorical
   if (tid == 0) *abort_flag = 0;
   __syncthreads();
-  WideBarrier bar{a.bar, a.status, abort_flag, 0u, (unsigned)nblk};
+  WideBarrier bar;
+  bar.init(a.ctl, a.status, abort_flag, nblk, blk, a.acquire != 0);
 
   const int ks0h = KSH * wave / kWW, ks1h = KSH * (wave + 1) / kWW;
   const int ks0d = KSD * wave / kWW, ks1d = KSD * (wave + 1) / kWW;
@@ -172,11 +176,13 @@ __global__ __launch_bounds__(kWT) void mrssm_wide_fwd_kernel(const WideFwdArgs a
           for (int i = tid; i < 3 * S; i += kWT) {
             const int which = i / S, s2 = i - which * S;
             const float bias = (which == 0 ? w.b4 : (which == 1 ? w.ba2 : w.bv2))[s2];
-            (which == 0 ? Llp : (which == 1 ? Lla : Llv))[s2] = a.lg[((size_t)r * 3 + which) * Sp + s2] + bias;
+            (which == 0 ? Llp : (which == 1 ? Lla : Llv))[s2] = wide_load_f(a.lg + ((size_t)r * 3 + which) * Sp + s2) + bias;
           }
           lds_barrier();
+          MTRSSM_WIDE_STAMP(10);
           if (wave == 0) {
             wave_mopoe_mix<true>(Lla, Llv, Lmx, S, lane);
+            MTRSSM_WIDE_STAMP(11);
             for (int s2 = lane; s2 < S; s2 += kWave) {
               io.prior_logits[q * S + s2] = Llp[s2];
               io.post_logits[q * S + s2] = Lmx[s2];
@@ -190,6 +196,7 @@ __global__ __launch_bounds__(kWT) void mrssm_wide_fwd_kernel(const WideFwdArgs a
               kl = wave_sum(kl);
               if (lane == 0) io.kl[q] = kl;
             }
+            MTRSSM_WIDE_STAMP(12);
           }
           lds_barrier();
         } else {
@@ -360,9 +367,10 @@ struct WideBwdArgs {
   const uint4 *pk_w1s;        // N = S, K = H
   uint4 *x_dl[3], *x_dzh, *x_dgi, *x_dgh, *x_dz1;
   float* cs;                  // [32][Sp] carry_s of the step
-  unsigned* bar;
+  void* ctl;                                           // control block (barrier words)
   int* status;
   int nblk;
+  int acquire;                                         // 1: an agent acquire fence after every barrier (A/B switch)
 };
 
 template <int P>
@@ -382,7 +390,8 @@ __global__ __launch_bounds__(kWT) void mrssm_wide_bwd_kernel(const WideBwdArgs a
   int* abort_flag = reinterpret_cast<int*>(Lgps + Sp);
   if (tid == 0) *abort_flag = 0;
   __syncthreads();
-  WideBarrier bar{a.bar, a.status, abort_flag, 0u, (unsigned)nblk};
+  WideBarrier bar;
+  bar.init(a.ctl, a.status, abort_flag, nblk, blk, a.acquire != 0);
 
   auto krange = [&](int KS, int& k0, int& k1) { k0 = KS * wave / kWW; k1 = KS * (wave + 1) / kWW; };
   const size_t tileS = (size_t)KSS * P * 64, tile3H = (size_t)KS3H * P * 64, tile3D = (size_t)KS3D * P * 64, tileH = (size_t)KSH * P * 64;
@@ -430,16 +439,24 @@ __global__ __launch_bounds__(kWT) void mrssm_wide_bwd_kernel(const WideBwdArgs a
           Llv[s2] = io.sv_lv[q * S + s2];
           Lmx[s2] = io.post_logits[q * S + s2];
           Llp[s2] = io.prior_logits[q * S + s2];
-          Lcs[s2] = t == T - 1 ? 0.f : a.cs[(size_t)r * Sp + s2];
+          Lcs[s2] = t == T - 1 ? 0.f : wide_load_f(a.cs + (size_t)r * Sp + s2);
           Lgps[s2] = io.g_post_stoch ? io.g_post_stoch[q * S + s2] : 0.f;   // (read twice per class by one lane: from LDS, not L2)
         }
         lds_barrier();
+        MTRSSM_WIDE_STAMP(11);
         if (wave == 0) {
           const float gk = io.g_kl ? io.g_kl[q] : 0.f;
-          cat_block_bwd<true>(Lmx, Llp, K, C, lane, Lgps, Lcs,
-                        io.g_prior_stoch ? io.g_prior_stoch + q * S : nullptr, io.g_post_logits ? io.g_post_logits + q * S : nullptr,
-                        io.g_prior_logits ? io.g_prior_logits + q * S : nullptr, gk, a.dm.kl_w_post, a.dm.kl_w_prior, Ldmx, Ldlp);
+          if (C <= 8)
+            cat_block_bwd_fast8(Lmx, Llp, K, C, lane, Lgps, Lcs, io.g_prior_stoch ? io.g_prior_stoch + q * S : nullptr,
+                                io.g_post_logits ? io.g_post_logits + q * S : nullptr, io.g_prior_logits ? io.g_prior_logits + q * S : nullptr,
+                                gk, a.dm.kl_w_post, a.dm.kl_w_prior, Ldmx, Ldlp);
+          else
+            cat_block_bwd<true>(Lmx, Llp, K, C, lane, Lgps, Lcs, io.g_prior_stoch ? io.g_prior_stoch + q * S : nullptr,
+                                io.g_post_logits ? io.g_post_logits + q * S : nullptr, io.g_prior_logits ? io.g_prior_logits + q * S : nullptr,
+                                gk, a.dm.kl_w_post, a.dm.kl_w_prior, Ldmx, Ldlp);
+          MTRSSM_WIDE_STAMP(12);
           wave_mopoe_mix_bwd<true>(Lla, Llv, Lmx, Ldmx, Ldla, Ldlv, S, lane);
+          MTRSSM_WIDE_STAMP(13);
         }
         lds_barrier();
         for (int i = tid; i < 3 * (Sp / 4); i += kWT) {
@@ -610,7 +627,6 @@ int debug_set_wide_profile(void* buf) {
 }
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
-constexpr size_t kWideCtl = 256;   // [0] sticky status word (never cleared by a launch), [64] barrier counter
 
 static bool wide_dims_ok(const MtrssmMrssmDims* d) {
   if (!d || d->B <= 0 || d->T <= 0 || d->D <= 0 || d->H <= 0 || d->K <= 0 || d->C <= 0 || !d->post) return false;
@@ -683,6 +699,12 @@ size_t mrssm_wide_bwd_workspace_bytes(const MtrssmMrssmDims* d, int pieces) {
   return wide_bwd_layout(d, pieces).total;
 }
 
+// MTRSSM_WIDE_ACQUIRE=1: an agent-scope acquire fence after every grid barrier on top of the sc1 loads (A/B runs)
+static int wide_acquire_fence() {
+  static const int on = [] { const char* e = getenv("MTRSSM_WIDE_ACQUIRE"); return (e && e[0] == '1') ? 1 : 0; }();
+  return on;
+}
+
 static int wide_grid(const MtrssmMrssmDims* d) {
   (void)d;
   return device_cu_count();   // one workgroup per CU (each asks for more than half a CU's LDS)
@@ -744,8 +766,9 @@ int mrssm_wide_fwd_launch(const MtrssmMrssmDims* d, const MtrssmMrssmClusterWeig
   a.x_d[1] = reinterpret_cast<uint4*>(ws + L.x_d[1]);
   a.lg = reinterpret_cast<float*>(ws + L.lg);
   a.status = reinterpret_cast<int*>(ws);
-  a.bar = reinterpret_cast<unsigned*>(ws + 64);
+  a.ctl = ws;
   a.nblk = wide_grid(d);
+  a.acquire = wide_acquire_fence();
   const size_t lds = wide_fwd_lds(d);
   if (lds > 160 * 1024) { set_error("mrssm_rollout_fwd_wide: %zu bytes of LDS", lds); return MTRSSM_ELDS; }
   hipError_t e;
@@ -810,8 +833,9 @@ int mrssm_wide_bwd_launch(const MtrssmMrssmDims* d, const MtrssmMrssmClusterWeig
   a.x_dz1 = reinterpret_cast<uint4*>(ws + L.x_dz1);
   a.cs = reinterpret_cast<float*>(ws + L.cs);
   a.status = reinterpret_cast<int*>(ws);
-  a.bar = reinterpret_cast<unsigned*>(ws + 64);
+  a.ctl = ws;
   a.nblk = wide_grid(d);
+  a.acquire = wide_acquire_fence();
   const size_t lds = wide_bwd_lds(d);
   if (lds > 160 * 1024) { set_error("mrssm_rollout_bwd_wide: %zu bytes of LDS", lds); return MTRSSM_ELDS; }
   hipError_t e;

@@ -86,12 +86,23 @@ __device__ __forceinline__ void wide_x_store4(uint4* xb, int KS, int row, int k,
 // the rate its loads in flight allow (measured with two k-blocks in flight per wave: 61 GB/s per CU, the latency-bound
 // "handed-off payload" rate of the guide), so the loop keeps NS - 1 k-blocks (NS (NT + 2) P KiB per wave) requested ahead of
 // the MFMAs in a ring of register stages with static indices.  Products: piece pairs (a, b) with a + b < P, smallest first.
+using wu32x4 = __attribute__((ext_vector_type(4))) unsigned;
+// Exchange vectors are written by OTHER workgroups of the same launch (write-through stores): every load of them is an sc1
+// buffer load (served by L2 / the fabric, never by this CU's L1), which is what lets the grid barrier go without an acquire
+// fence (MI355X_MICROARCH.md, "Valid forms": sc1 payload stores drained before the arrival add, sc1 poll, sc1 loads).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wide_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ float wide_load_f(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 template <int NT, int P, int NS>
-__device__ __forceinline__ void wide_mfma_stream(wf32x4 (&acc)[NT][2], const uint4* const (&wt)[NT], const uint4* __restrict__ xb, int KS,
+__device__ __forceinline__ void wide_mfma_stream(wf32x4 (&acc)[NT][2], const uint4* const (&wt)[NT], const uint4* __restrict__ xbase, int KS,
                                                  int ks0, int ks1, int lane) {
   if (ks0 >= ks1) return;
   const int xlane = (lane & 15) * 4 + (lane >> 4);
-  uint4 a[NS][NT][P], b[NS][2][P];
+  const __amdgpu_buffer_rsrc_t xb = wide_rsrc(xbase);
+  uint4 a[NS][NT][P];
+  wu32x4 b[NS][2][P];
   auto load = [&](int st, int ks) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -100,7 +111,8 @@ __device__ __forceinline__ void wide_mfma_stream(wf32x4 (&acc)[NT][2], const uin
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-      for (int p = 0; p < P; ++p) b[st][rt][p] = xb[(size_t)((p * KS + ks) * kWRows + 16 * rt) * 4 + xlane];
+      for (int p = 0; p < P; ++p)
+        b[st][rt][p] = __builtin_amdgcn_raw_buffer_load_b128(xb, (((p * KS + ks) * kWRows + 16 * rt) * 4 + xlane) * 16, 0, 16);   // aux 16 = sc1
   };
   auto compute = [&](int st) {
 #pragma unroll
@@ -142,24 +154,51 @@ __device__ __forceinline__ wf32x4 wide_red_sum(const wf32x4* red, int tile, int 
   return s;
 }
 
-// Grid-wide barrier over `nblk` resident workgroups: one monotonic counter (zeroed by the launch), every storing wave drains
-// its stores, one lane arrives (agent-scope add) and polls with sc1 loads, then ONE agent acquire (drops this CU's L1 lines)
-// before the workgroup goes on to plain loads of what the others published with write-through stores.  Bounded: a poll that
-// gives up sets the sticky status word and the LDS abort flag; the caller leaves the kernel.
+// Grid-wide barrier over `nblk` resident workgroups, two levels: the workgroups with equal blockIdx % 8 (one XCD under the
+// observed round-robin placement: speed only, nothing depends on it) arrive at their group's counter; the last of a group
+// arrives at the top counter; the last group releases everybody by storing the epoch into each group's generation word, which is
+// what a group's workgroups poll (32 pollers per word instead of 256 on one: the flat form cost 8 us after a short phase).
+// Every storing wave drains its write-through stores before its workgroup arrives; everything another workgroup wrote is read
+// with sc1 loads afterwards, so no acquire fence is needed (`acquire` adds it: an A/B switch).  Words live on 128-byte lines of
+// their own in the control block: [+128] top, [+256 + 128 g] arrivals of group g, [+1280 + 128 g] generation of group g.
+// Bounded: a poll that gives up sets the sticky status word and the LDS abort flag; the caller leaves the kernel.
+constexpr int kWideGroups = 8;
+constexpr size_t kWideCtl = 2560;   // control block bytes: [0] sticky status word (never cleared by a launch), then the barrier words
 struct WideBarrier {
-  unsigned* counter;
+  unsigned* ctl;      // control block + 128
   int* status;
-  int* abort_flag;  // LDS
-  unsigned target;
-  unsigned nblk;
+  int* abort_flag;    // LDS
+  unsigned epoch;
+  unsigned group, group_size, groups;
+  bool acquire;
+  __device__ __forceinline__ void init(void* control, int* status_, int* abort_, int nblk, int blk, bool acquire_) {
+    ctl = reinterpret_cast<unsigned*>(static_cast<char*>(control) + 128);
+    status = status_;
+    abort_flag = abort_;
+    epoch = 0;
+    group = blk % kWideGroups;
+    group_size = (nblk - (int)group + kWideGroups - 1) / kWideGroups;
+    groups = nblk < kWideGroups ? nblk : kWideGroups;
+    acquire = acquire_;
+  }
   __device__ __forceinline__ bool sync(int code) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    target += nblk;
+    ++epoch;
     if (threadIdx.x == 0) {
-      __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned* const top = ctl;
+      unsigned* const arrive = ctl + 32 * (1 + group);
+      unsigned* const gen = ctl + 32 * (1 + kWideGroups + group);
+      const unsigned a = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a + 1 == group_size * epoch) {
+        const unsigned t = __hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t + 1 == groups * epoch) {
+          for (unsigned g = 0; g < groups; ++g)
+            __hip_atomic_store(ctl + 32 * (1 + kWideGroups + g), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
       bool ok = true;
-      for (unsigned spins = 0; __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; ++spins) {
+      for (unsigned spins = 0; __hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch; ++spins) {
         if (spins > kWideSpinLimit) { ok = false; break; }
         __builtin_amdgcn_s_sleep(1);
       }
@@ -167,8 +206,10 @@ struct WideBarrier {
         *abort_flag = 1;
         atomicExch(status, code);
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (acquire) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
     }
     __syncthreads();
     return *abort_flag == 0;

@@ -50,3 +50,10 @@ for it in range(3):
                   f" | phase start spread {float(s[:, 2 * p].max() - s[:, 2 * p].min()):5.2f}"
                   f" | barrier: last arrival -> release median {float((release - last_arrival).median()):5.2f} max {float((release - last_arrival).max()):5.2f} us"
                   f" | phase wall {float(release.max() - s[:, 2 * p].min()):6.2f}")
+        rows = s[-32:]  # the row workgroups are the last ones of the grid
+        if which == "fwd":
+            d = lambda a, b: float((rows[:, b] - rows[:, a]).median())
+            print(f"      row workgroups (median): logits -> LDS {d(0, 10):5.2f}, mix {d(10, 11):5.2f}, cat block + outputs {d(11, 12):5.2f}, gather + h1 {d(12, 1):5.2f} us")
+        else:
+            d = lambda a, b: float((rows[:, b] - rows[:, a]).median())
+            print(f"      row workgroups (median): staging {d(0, 11):5.2f}, cat bwd {d(11, 12):5.2f}, mix bwd {d(12, 13):5.2f}, outputs + exchange {d(13, 1):5.2f} us")
