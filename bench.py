@@ -211,6 +211,42 @@ def feed_benchmark(device: str, batches: int = 20) -> dict[str, object]:
             "what": f"6-tuple batch B={b} T={t} from {n} HBM-resident episodes x {t_full} steps; gather + TakeFirstN + GaussianNoise fused (mtrssm_episode_gather) + torch.randn"}
 
 
+class _StubModel(torch.nn.Module):
+    """``--device cpu`` rehearsal only (tests/test_parallel_gloo.py): a CPU module with the model's bench-facing surface
+    (``shared_step(batch, noise)`` -> loss dict, ``noise_shapes``), so that THIS file's argument parsing, self-launch, sharded
+    step, barriers, MAX-over-ranks timing and JSON line run end to end on a box without a GPU.  Never a measurement."""
+
+    def __init__(self) -> None:
+        super().__init__()
+        self.body = torch.nn.Linear(4, 8)
+        self.head = torch.nn.Linear(8, 1)
+        self.dead = torch.nn.Linear(3, 3)  # never called: like MMTRSSM's l_posterior / dummy transition
+
+    @staticmethod
+    def noise_shapes(batch: int, steps: int) -> dict[str, tuple[int, ...]]:
+        return {"u_init": (batch, 2), "u_post": (batch, steps, 2)}
+
+    def shared_step(self, batch: tuple[torch.Tensor, ...], noise: dict[str, torch.Tensor]) -> dict[str, torch.Tensor]:
+        h = torch.tanh(self.body(batch[0]) + noise["u_post"].mean(-1, keepdim=True))
+        recon = (self.head(h).squeeze(-1) - batch[3][..., 0]).square().mean()
+        kl = noise["u_init"].mean() * 0.0 + h.square().mean()
+        return {"recon": recon, "kl": kl, "loss": recon + kl}
+
+
+class _StubOptimizer:
+    """SGD over the flat buffer with FlatAdamW's call surface (the fused AdamW is a HIP kernel: there is none on the CPU)."""
+
+    def __init__(self, flat) -> None:  # noqa: ANN001
+        self.flat = flat
+
+    def zero_grad(self) -> None:
+        self.flat.zero_grad()
+
+    @torch.no_grad()
+    def step(self, grad_scale: float = 1.0) -> None:
+        self.flat.param.sub_(1e-3 * grad_scale * self.flat.grad)
+
+
 def _free_port() -> int:
     import socket
 
@@ -250,6 +286,9 @@ def parse_args() -> argparse.Namespace:
                     help="nccl = RCCL over xGMI (the product path); gloo only to rehearse the launcher and the sharded step on a box with fewer GPUs")
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (needs --backend gloo: RCCL refuses two ranks on one GPU)")
+    ap.add_argument("--device", choices=("cuda", "cpu"), default="cuda",
+                    help="cpu = REHEARSAL of this file's launch / sharding / timing / JSON path with a stub model over gloo on a box "
+                         "without a GPU (tests/test_parallel_gloo.py); its line says data = 'stub' and is never a measurement")
     ap.add_argument("--graph", choices=("on", "off"), default="off",
                     help="on: the train step (zero_grad, forward, backward, and with one rank the optimizer) is captured once in a "
                          "hipGraph and replayed (graph.CapturedTrainStep); off: every launch enqueued by the host each step")
@@ -282,11 +321,21 @@ def main() -> None:  # noqa: PLR0914, PLR0915
     if args.share_device:  # two processes on one GPU: the cluster scan's workgroups could not all be resident
         os.environ["MTRSSM_SCAN_CLUSTER"] = "0"
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    dev_index = 0 if args.share_device else local_rank
-    torch.cuda.set_device(dev_index)
-    device = f"cuda:{dev_index}"
+    cpu = args.device == "cpu"
+    if cpu:
+        args.backend, args.no_cpu_baseline, args.no_elbo_check = "gloo", True, True
+        device = "cpu"
+    else:
+        dev_index = 0 if args.share_device else local_rank
+        torch.cuda.set_device(dev_index)
+        device = f"cuda:{dev_index}"
+
+    def sync() -> None:
+        if not cpu:
+            torch.cuda.synchronize()
+
     use_dist = world > 1 or args.force_dist
-    rccl_ranks = 0
+    rccl_ranks = collective_ranks = 0
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -302,9 +351,10 @@ def main() -> None:  # noqa: PLR0914, PLR0915
                 dist.init_process_group("gloo", rank=rank, world_size=world)
             warm = torch.ones(1, device=device)
             dist.all_reduce(warm)
-            torch.cuda.synchronize()
-            rccl_ranks = int(warm.item()) if args.backend == "nccl" else 0  # ranks that took part in a real RCCL all-reduce
-            assert int(warm.item()) == dist.get_world_size()
+            sync()
+            collective_ranks = int(warm.item())  # ranks that took part in a real all-reduce of the chosen backend
+            rccl_ranks = collective_ranks if args.backend == "nccl" else 0
+            assert collective_ranks == dist.get_world_size()
         finally:
             sys.stdout.flush()
             os.dup2(saved_fd, 1)
@@ -317,13 +367,25 @@ def main() -> None:  # noqa: PLR0914, PLR0915
     conv.set_mfma_mode(args.conv_mfma)
 
     w = WORKLOAD
-    model = build_model(device, args.model)
+    if cpu:
+        w = dict(w, batch_per_gpu=4, steps=6, vision=(1, 2, 2), audio=(1, 2, 2))
+        torch.manual_seed(42)
+        model = _StubModel()
+        die = os.environ.get("MTRSSM_BENCH_REHEARSAL_DIE_RANK")  # the launcher must turn a dead rank into a non-zero exit
+        if die is not None and int(die) == rank:
+            os._exit(3)  # noqa: SLF001
+    else:
+        model = build_model(device, args.model)
     flat = FlatParameters(model, extra=8)
     dp = mt.FlatDataParallel(flat)
     dp.broadcast_parameters(0)
-    opt = mt.FlatAdamW(flat, lr=1e-3, clip_norm=10.0)
+    opt = _StubOptimizer(flat) if cpu else mt.FlatAdamW(flat, lr=1e-3, clip_norm=10.0)
     b, t = w["batch_per_gpu"], w["steps"]
-    batch = synthetic_batch(b, device, seed=1000 + rank)  # each rank owns its own 64 sequences (weak scaling)
+    if cpu:
+        g0 = torch.Generator().manual_seed(1000 + rank)
+        batch = tuple(torch.randn(b, t, n, generator=g0) for n in (4, 4, 4, 4, 4, 4))
+    else:
+        batch = synthetic_batch(b, device, seed=1000 + rank)  # each rank owns its own 64 sequences (weak scaling)
     # sampling uniforms keyed by GLOBAL batch row: the same generator state on every rank, the whole
     # global batch drawn, this rank's rows kept -- a row's trajectory does not depend on the number of ranks
     noise_source = dp.noise_source(seed=7)
@@ -348,11 +410,18 @@ def main() -> None:  # noqa: PLR0914, PLR0915
     def barrier() -> None:
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
+
+    class _HostMark:  # --device cpu: wall-clock marks with torch.cuda.Event's two methods
+        def record(self) -> None:
+            self.t = time.perf_counter()
+
+        def elapsed_time(self, other: "_HostMark") -> float:
+            return (other.t - self.t) * 1e3
 
     for _ in range(args.warmup):
         train_step()
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]  # one event per STEP (none per launch)
+    marks = [_HostMark() if cpu else torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]  # one per STEP (none per launch)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -368,12 +437,12 @@ def main() -> None:  # noqa: PLR0914, PLR0915
     # with an event pair around each library launch, on the launch stream (agrees with rocprofv3 --kernel-trace --stats
     # of this command, profiles/).
     kernel_ms: dict[str, dict[str, float]] = {}
-    if rank == 0:
+    if rank == 0 and not cpu:
         scan.KERNEL_TIMERS.enable()
     for _ in range(3):  # EVERY rank takes these steps (each holds an all-reduce); only rank 0 times its launches
         eager_step()  # never the captured graph: events cannot be recorded into a replay
-    torch.cuda.synchronize()
-    if rank == 0:
+    sync()
+    if rank == 0 and not cpu:
         kernel_ms = scan.KERNEL_TIMERS.summary()
         scan.KERNEL_TIMERS.disable()
     tt = torch.tensor([elapsed, median_ms], device=device, dtype=torch.float64)
@@ -420,6 +489,45 @@ def main() -> None:  # noqa: PLR0914, PLR0915
                         algorithmic_flops_per_launch=row["flops"] / row["launches"],
                         algorithmic_bytes_per_launch=row["bytes"] / row["launches"],
                         share_of_step=row["total_ms"] / n_steps / ms)
+        # ---- the step against the machine (never a substitute for the dominant-kernel entry above, which may be latency-bound):
+        # every library launch states its algorithmic FLOPs and bytes (conv.py / scan.py / linear.py); their sums per step,
+        # the end-to-end algorithmic I/O of SURVEY section 8d (103 KB fp32 per seq-step: inputs, targets, states, once) and the
+        # MFMA ceiling of the operand format (dense bf16 peak / products per multiply-add block)
+        products = MFMA_PRODUCTS[args.conv_mfma]
+        ceiling = MFMA_BF16_PEAK_TFLOPS / products if args.conv_mfma != "f32" else MFMA_F32_PEAK_TFLOPS
+        step_s = ms * 1e-3
+        flops_step = sum(v["flops"] for v in kernel_ms.values()) / n_steps
+        bytes_step = sum(v["bytes"] for v in kernel_ms.values()) / n_steps
+        io_step = 103.0e3 * b * t
+        roof["step"] = {
+            "algorithmic_flops": flops_step, "achieved_TFLOPs": flops_step / step_s / 1e12, "mfma_ceiling_TFLOPs": ceiling,
+            "frac_of_mfma_ceiling": flops_step / step_s / 1e12 / ceiling, "frac_of_raw_bf16_peak": flops_step / step_s / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+            "sum_of_kernel_algorithmic_bytes": bytes_step, "its_GBps": bytes_step / step_s / 1e9,
+            "its_frac_of_hbm": bytes_step / step_s / 1e9 / HBM_PEAK_GBS,
+            "end_to_end_algorithmic_bytes": io_step, "end_to_end_GBps": io_step / step_s / 1e9,
+            "inter_kernel_traffic_ratio": bytes_step / io_step,
+            "library_launches_per_step": sum(v["launches"] for v in kernel_ms.values()) / n_steps,
+            "library_kernel_ms_per_step": sum(v["total_ms"] for v in kernel_ms.values()) / n_steps,
+        }
+        # the largest kernel that a pipe bounds (the dominant one above may be the latency-bound recurrence)
+        best = None
+        for k, v in kernel_ms.items():
+            if "conv" not in k or "thin" in k or not v["flops"] or not v["total_ms"]:
+                continue
+            split = any(tag in k for tag in ("split_kernel", "resident_kernel", "stream_kernel", "staged_kernel"))
+            peak = MFMA_BF16_PEAK_TFLOPS / (products if split else 1) if split else MFMA_F32_PEAK_TFLOPS
+            secs = v["total_ms"] * 1e-3
+            tf, gbs = v["flops"] / secs / 1e12, v["bytes"] / secs / 1e9
+            ridge = peak * 1e12 / (HBM_PEAK_GBS * 1e9)
+            bound_mfma = v["flops"] / max(v["bytes"], 1.0) >= ridge
+            frac = tf / peak if bound_mfma else gbs / HBM_PEAK_GBS
+            if best is None or v["total_ms"] > best[1]["total_ms"]:
+                best = (k, v, "mfma" if bound_mfma else "hbm", tf, gbs, peak, frac)
+        if best is not None:
+            k, v, bound, tf, gbs, peak, frac = best
+            roof["largest_pipe_bound"] = {"kernel": k, "bound": bound, "ms_per_step": v["total_ms"] / n_steps, "avg_us": v["avg_ms"] * 1e3,
+                                          "achieved_TFLOPs": tf, "achieved_GBps": gbs, "peak": peak if bound == "mfma" else HBM_PEAK_GBS,
+                                          "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": frac, "traffic": measured_traffic(k)}
         roof["kernels"] = {k: {"launches_per_step": v["launches"] / 3, "avg_us": round(v["avg_ms"] * 1e3, 1),
                                "ms_per_step": round(v["total_ms"] / 3, 3),
                                "tflops": round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 2) if v["total_ms"] else None,
@@ -439,7 +547,7 @@ def main() -> None:  # noqa: PLR0914, PLR0915
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": DTYPE_LABEL[args.conv_mfma],
-            "data": "synthetic",
+            "data": "stub model on the CPU: a rehearsal of the launch / sharding / JSON path, NOT a measurement" if cpu else "synthetic",
             "config": {
                 "workload": {"mrssm": "BASELINE configs[1]: MoPoE-MRSSM train step, B=64/GPU T=50 deter=200 stoch=30, vision 1x64x64 + audio 1x128x32 + action 4",
                              "mmtrssm": "BASELINE configs[2]: MoPoE-MMTRSSM (MTState, tau 2/4) train step, B=64/GPU T=50 ld=hd=200 ls=hs=30, same frames",
@@ -450,7 +558,7 @@ def main() -> None:  # noqa: PLR0914, PLR0915
                 "enc_channels": [8, 16, 32], "dec_channels": [32, 16, 1], "residual_blocks": 3, "activation": "ELU",
                 "optimizer": "AdamW lr 1e-3 + clip 10 (fused HIP)", "params": flat.numel, "streams": 1,
                 "launch": "one hipGraph replay per step" if args.graph == "on" else "eager (host enqueues every launch)",
-                "backend": (args.backend if use_dist else "none"), "rccl_ranks": rccl_ranks,
+                "backend": (args.backend if use_dist else "none"), "rccl_ranks": rccl_ranks, "collective_ranks": collective_ranks,
                 "noise": "uniforms keyed by global batch row (parallel.GlobalRowNoise)",
                 "conv_mfma": {"bf16x3": "fp32 tensors; conv MFMA operands as 3 bf16 pieces, 6 bf16-MFMA products, fp32 accumulate (~2^-24 per product)",
                               "bf16x2": "fp32 tensors; conv MFMA operands as 2 bf16 pieces (16 significant bits), 3 bf16-MFMA products, fp32 "
@@ -467,7 +575,7 @@ def main() -> None:  # noqa: PLR0914, PLR0915
             delta = elbo_delta(model, batch, args.model)
             line["elbo_rel_delta"] = delta["loss"]
             line["elbo_check"] = delta
-        if world == 1:
+        if world == 1 and not cpu:
             line["data_feed"] = feed_benchmark(device)
         if not args.no_cpu_baseline and world == 1 and args.model != "large":  # (Large: one CPU step takes minutes)
             base = cpu_baseline(args.model)

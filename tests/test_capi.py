@@ -86,6 +86,20 @@ def test_invalid_arguments_are_rejected_without_a_launch() -> None:
     g = _lib.Gemm()
     g.mfma_split = 1  # only 0 (fp32 MFMA) and 2 (two bf16 pieces) exist
     assert lib.mtrssm_gemm(C.byref(g), None) == -1
+    # round-3 entries
+    assert lib.mtrssm_conv_weight_grad_workspace_bytes(C.byref(_lib.ConvGeom()), 0) == -1  # all-zero geometry
+    assert lib.mtrssm_conv_weight_grad(C.byref(_lib.ConvGeom()), None, None, None, 0, None, None, None, 0, None) == -1
+    large = _lib.MrssmDims(32, 100, 1024, 1024, 16, 8, 2, 1, 0.2, 0.8, 0, 0)
+    assert lib.mtrssm_mrssm_wide_supported(C.byref(large), 3) == 0  # no device here: the grid cannot be sized
+    assert lib.mtrssm_mrssm_wide_workspace_bytes(C.byref(large), 3) > 60e6  # six bytes per weight of the ~10 M scan weights
+    assert lib.mtrssm_mrssm_wide_bwd_workspace_bytes(C.byref(large), 2) > 40e6
+    assert lib.mtrssm_mrssm_wide_workspace_bytes(C.byref(large), 4) == 0  # pieces: 2 or 3
+    odd = _lib.MrssmDims(32, 100, 1000, 1024, 16, 8, 2, 1, 0.2, 0.8, 0, 0)  # D not a multiple of 16
+    assert lib.mtrssm_mrssm_wide_workspace_bytes(C.byref(odd), 3) == 0
+    assert lib.mtrssm_mrssm_rollout_fwd_wide(C.byref(large), C.byref(_lib.MrssmClusterWeights()), C.byref(_lib.MrssmFwdIO()), 3, None, 0, None) == -1
+    assert b"wide" in lib.mtrssm_last_error()
+    assert lib.mtrssm_mrssm_rollout_bwd_wide(C.byref(large), C.byref(_lib.MrssmClusterWeights()), C.byref(_lib.MrssmBwdIO()), 3, None, 0, None) == -1
+    assert lib.mtrssm_mrssm_cluster_supported(C.byref(_lib.MrssmDims(64, 50, 200, 200, 6, 5, 2, 1, 0.2, 0.8, 0, 0))) == 0  # no CUs to count
 
 
 def test_missing_library_fails_loudly(monkeypatch: pytest.MonkeyPatch, tmp_path: Path) -> None:

@@ -171,6 +171,14 @@ def test_data_parallel_loader_shards_are_disjoint_and_equal() -> None:
         assert not torch.equal(a, b) or n <= 2
     one = ds.DeviceEpisodeLoader(streams, 5, shuffle=False)
     assert [int(b.numel()) for b in one.index_batches()] == [5, 5, 2]  # single rank keeps the short tail (reference DataLoader)
+    # ADVICE r2 (dataset.py:189): a rank's rows are the CONTIGUOUS block FlatDataParallel.shard cuts and GlobalRowNoise.draw keys its
+    # uniforms by -- the ranks' blocks, in rank order, ARE the one-rank batch (row g of the global batch meets the same noise)
+    streams12 = tuple(ds._Stream(torch.arange(12, dtype=torch.float32).reshape(12, 1, 1).expand(12, 3, w).contiguous(), tr.Compose([]), tr.Compose([]))  # noqa: SLF001
+                      for w in (4, 2, 2))
+    whole = list(ds.DeviceEpisodeLoader(streams12, 4, shuffle=True, seed=3).index_batches())
+    halves = [list(ds.DeviceEpisodeLoader(streams12, 4, shuffle=True, rank=r, world=2, seed=3).index_batches()) for r in range(2)]
+    for step, rows in enumerate(whole):
+        assert torch.equal(torch.cat([halves[0][step], halves[1][step]]), rows)
 
 
 # ---------------------------------------------------------------------------------------------

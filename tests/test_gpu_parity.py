@@ -1109,6 +1109,80 @@ def test_captured_train_step_matches_eager(name: str, lib_loaded: None) -> None:
     assert float(diff.max()) < 2e-4 and float(diff.mean()) < 2e-7, (float(diff.max()), float(diff.mean()))
 
 
+def test_set_status_word_stops_the_optimizer_and_raises(lib_loaded: None) -> None:
+    """A cooperative scan launch that gave up leaves its STICKY status word set: the fused AdamW launches of that step see it on
+    the device and leave parameters, moments and the step count alone; the host raises at the next poll (one step later: the
+    copy is asynchronous) and `check_cluster_status` raises at once.  After `STATUS.reset()` training goes on."""
+    import multimodal_mtrssm_amd as mt
+    from multimodal_mtrssm_amd import scan
+    from multimodal_mtrssm_amd.optim import FlatParameters
+
+    case = with_sizes(CASES["mrssm_default"], 3, 5)  # D = H = 32: the four-CU cluster scan (a cooperative kernel with a workspace)
+    model = product_from_case(case, build_model(case), DEV)
+    flat = FlatParameters(model, extra=8)
+    opt = mt.FlatAdamW(flat, lr=1e-3)
+    batch = tuple(b.to(DEV) for b in build_batch(case))
+    noise = _to(build_noise(case), DEV)
+
+    def step() -> None:
+        opt.zero_grad()
+        model.shared_step(batch, noise)["loss"].backward()
+        opt.step()
+
+    step()
+    torch.cuda.synchronize()
+    word = scan.status_word(torch.device(DEV))
+    assert word is not None and int(word.item()) == 0
+    before, m_before, count = flat.param.clone(), opt.exp_avg.clone(), float(opt.state[1])
+    word.fill_(7)  # what a timed-out exchange would have stored
+    try:
+        step()  # the device skips the update; this step's post() carries the bad word to the host
+        torch.cuda.synchronize()
+        assert torch.equal(flat.param, before) and torch.equal(opt.exp_avg, m_before) and float(opt.state[1]) == count
+        with pytest.raises(mt._lib.MtrssmLibraryError, match="status 7"):  # noqa: SLF001
+            scan.check_cluster_status()
+        with pytest.raises(mt._lib.MtrssmLibraryError, match="optimizer skipped its update"):  # noqa: SLF001
+            step()
+    finally:
+        scan.STATUS.reset()
+    step()
+    torch.cuda.synchronize()
+    assert not torch.equal(flat.param, before) and float(opt.state[1]) == count + 1
+    scan.check_cluster_status()
+
+
+def test_backward_that_raises_does_not_break_later_conv_gradients(lib_loaded: None) -> None:
+    """ADVICE r2 (conv.py:440): a backward that raises half-way leaves the conv gradient sink armed and partly filled; the next
+    step must produce exactly the gradients of a clean run."""
+    from multimodal_mtrssm_amd.optim import FlatParameters
+
+    case = with_sizes(CASES["mrssm_nonsquare"], 3, 4)
+    oracle = build_model(case)
+    batch = tuple(b.to(DEV) for b in build_batch(case))
+    noise = _to(build_noise(case), DEV)
+    grads = {}
+    for broken in (False, True):
+        model = product_from_case(case, oracle, DEV)
+        flat = FlatParameters(model, extra=8)
+        if broken:
+            out = model.shared_step(batch, noise)
+
+            def boom(_g: torch.Tensor) -> torch.Tensor:
+                raise RuntimeError("injected failure in the middle of backward")
+
+            handle = out["kl"].register_hook(boom)  # recon's branch (decoders: conv weight gradients) runs, then this raises
+            with pytest.raises(RuntimeError, match="injected failure"):
+                out["loss"].backward()
+            handle.remove()
+        flat.zero_grad()
+        out = model.shared_step(batch, noise)
+        out["loss"].backward()
+        torch.cuda.synchronize()
+        grads[broken] = flat.grad.clone()
+    diff = (grads[True] - grads[False]).abs().max()
+    assert float(diff) <= 1e-5 * float(grads[False].abs().max()), float(diff)
+
+
 def test_cpu_tensors_are_refused(lib_loaded: None) -> None:
     """No silent fallback: the product path raises on CPU inputs."""
     import multimodal_mtrssm_amd as mt

@@ -130,3 +130,29 @@ def test_shard_rejects_uneven_batches() -> None:
     (x,) = dp.shard((torch.zeros(5, 6),))
     assert x.shape[0] == 5
     assert dp.sync({"loss": torch.tensor(3.0)})["loss"].item() == 3.0
+
+
+def test_bench_main_runs_two_ranks_end_to_end_and_fails_when_a_rank_dies() -> None:
+    """the REAL ``bench.py`` entry -- argument parsing, self-launch of ``torch.distributed.run`` on 127.0.0.1,
+    process-group warm-up all-reduce, sharded steps through FlatParameters / FlatDataParallel / GlobalRowNoise, barriers, the
+    MAX-over-ranks timing and the one JSON line -- with ``--device cpu`` (a stub model and gloo in place of the HIP model and
+    RCCL: a rehearsal, its line says so).  Exactly one JSON line on stdout, n_gpus 2, both ranks in the warm-up all-reduce; a
+    rank that dies makes the whole command exit non-zero."""
+    import json
+    import subprocess
+
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--device", "cpu", "--steps", "3", "--warmup", "1"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    run = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300, check=False)
+    assert run.returncode == 0, run.stderr[-2000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, run.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["config"]["backend"] == "gloo" and line["config"]["collective_ranks"] == 2 and line["config"]["parallelism"] == "dp2"
+    assert line["config"]["global_batch"] == 2 * 4 and line["value"] > 0 and line["higher_is_better"] is True
+    assert "rehearsal" in line["data"] and line["vs_baseline"] is None
+    assert abs(line["value"] - line["config"]["global_batch"] * line["config"]["seq_len"] / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+    dead = subprocess.run(cmd, capture_output=True, text=True, env=dict(env, MTRSSM_BENCH_REHEARSAL_DIE_RANK="1"), timeout=300, check=False)
+    assert dead.returncode != 0
+    assert not [ln for ln in dead.stdout.splitlines() if ln.startswith("{")]
