@@ -378,6 +378,20 @@ typedef struct MtrssmMmtrssmBwdIO {
 int mtrssm_mmtrssm_rollout_bwd(const MtrssmMmtrssmDims* dims, const MtrssmMmtrssmBwdWeights* w,
                                const MtrssmMmtrssmBwdIO* io, void* stream);
 
+/* The same two scans on ALL compute units (csrc/mmtrssm_wide.hip; regime of mtrssm_mrssm_rollout_*_wide above): up to 64 batch rows
+ * per pass as the MFMA N dimension, every product of a timestep cut into 16-column output tiles streamed by one CU each, four grid
+ * barriers per timestep in either direction (one-CU form at ld = hd = H = 200: 38 / 46 us per timestep).  Weights, io and results
+ * exactly as for mtrssm_mmtrssm_rollout_fwd / _bwd (posterior rollout, post = 1); pieces / workspace / sticky status word /
+ * co-residency as for the MRSSM wide calls.  mtrssm_mmtrssm_wide_supported() = 1 when dims and device fit (LD, HD, H multiples of 4,
+ * LD or HD >= 128, KL, KH <= 64, (LD + HD + LS + HS) / 16 column tiles <= CU count). */
+int mtrssm_mmtrssm_wide_supported(const MtrssmMmtrssmDims* dims, int32_t pieces);
+int64_t mtrssm_mmtrssm_wide_workspace_bytes(const MtrssmMmtrssmDims* dims, int32_t pieces);
+int64_t mtrssm_mmtrssm_wide_bwd_workspace_bytes(const MtrssmMmtrssmDims* dims, int32_t pieces);
+int mtrssm_mmtrssm_rollout_fwd_wide(const MtrssmMmtrssmDims* dims, const MtrssmMmtrssmFwdWeights* w, const MtrssmMmtrssmFwdIO* io,
+                                    int32_t pieces, void* workspace, int64_t workspace_bytes, void* stream);
+int mtrssm_mmtrssm_rollout_bwd_wide(const MtrssmMmtrssmDims* dims, const MtrssmMmtrssmBwdWeights* w, const MtrssmMmtrssmBwdIO* io,
+                                    int32_t pieces, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Conv encoder / decoder kernels (fp32 MFMA implicit GEMM, NCHW).  Replace the layers of the
  * `cnn.Encoder` / `cnn.Decoder` stacks the reference YAML instantiates
@@ -583,6 +597,11 @@ typedef struct MtrssmGemm {
                          large Linear layers inside the conv stacks (cnn.Encoder head, cnn.Decoder stem) */
 } MtrssmGemm;
 int mtrssm_gemm(const MtrssmGemm* g, void* stream);
+/* `count` INDEPENDENT problems (no output of one is an operand or the output of another; mfma_split = 0) in as few launches as
+ * their operand layouts allow -- problems with equal (a_rmajor, b_rmajor) share one grid.  The weight gradients of the scan
+ * (scan.py: ten to fifteen [out, B*T] x [B*T, in] GEMMs per backward, each a latency-bound launch of its own before) go
+ * through this call.  Per problem exactly the arithmetic of mtrssm_gemm. */
+int mtrssm_gemm_group(const MtrssmGemm* problems, int32_t count, void* stream);
 
 #ifdef __cplusplus
 }

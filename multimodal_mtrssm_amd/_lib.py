@@ -101,6 +101,11 @@ SYMBOLS: dict[str, tuple[type | None, list[type]]] = {
     "mtrssm_mrssm_rollout_bwd": (C.c_int, [C.POINTER(MrssmDims), C.POINTER(MrssmBwdWeights), C.POINTER(MrssmBwdIO), _p]),
     "mtrssm_mmtrssm_rollout_fwd": (C.c_int, [C.POINTER(MmtrssmDims), C.POINTER(MmtrssmFwdWeights), C.POINTER(MmtrssmFwdIO), _p]),
     "mtrssm_mmtrssm_rollout_bwd": (C.c_int, [C.POINTER(MmtrssmDims), C.POINTER(MmtrssmBwdWeights), C.POINTER(MmtrssmBwdIO), _p]),
+    "mtrssm_mmtrssm_wide_supported": (C.c_int, [C.POINTER(MmtrssmDims), _i]),
+    "mtrssm_mmtrssm_wide_workspace_bytes": (C.c_int64, [C.POINTER(MmtrssmDims), _i]),
+    "mtrssm_mmtrssm_wide_bwd_workspace_bytes": (C.c_int64, [C.POINTER(MmtrssmDims), _i]),
+    "mtrssm_mmtrssm_rollout_fwd_wide": (C.c_int, [C.POINTER(MmtrssmDims), C.POINTER(MmtrssmFwdWeights), C.POINTER(MmtrssmFwdIO), _i, _p, C.c_int64, _p]),
+    "mtrssm_mmtrssm_rollout_bwd_wide": (C.c_int, [C.POINTER(MmtrssmDims), C.POINTER(MmtrssmBwdWeights), C.POINTER(MmtrssmBwdIO), _i, _p, C.c_int64, _p]),
     "mtrssm_conv_gather_gemm": (C.c_int, [C.POINTER(ConvGeom), _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "mtrssm_conv_gather_gemm_pair": (C.c_int, [C.POINTER(ConvGeom), _p, _p, _p, _p, _p, _p, _p, _p,
                                                C.POINTER(ConvGeom), _p, _p, _p, _p, _p, _p, _p, _p, _p]),
@@ -122,6 +127,7 @@ SYMBOLS: dict[str, tuple[type | None, list[type]]] = {
     "mtrssm_sumsq": (C.c_int, [_p, C.c_int64, _p, _p]),
     "mtrssm_adamw_step": (C.c_int, [_p, _p, _p, _p, C.c_int64, _p, _f, _f, _f, _f, _f, _f, _f, _i, _p]),
     "mtrssm_gemm": (C.c_int, [C.POINTER(Gemm), _p]),
+    "mtrssm_gemm_group": (C.c_int, [C.POINTER(Gemm), _i, _p]),
     "mtrssm_clear": (C.c_int, [_p, C.c_int64, _p]),
     "mtrssm_adamw_prepare": (C.c_int, [_p, C.c_int64, _p, _p, _p, _f, _f, _p]),
     "mtrssm_adamw_apply": (C.c_int, [_p, _p, _p, _p, _p, C.c_int64, _p, _p, _p, _f, _f, _f, _f, _f, _f, _p]),

@@ -42,6 +42,7 @@ int nll_bwd_launch(const float*, const float*, const float*, int64_t, int64_t, i
 int sumsq_launch(const float*, int64_t, float*, hipStream_t);
 int adamw_launch(float*, const float*, float*, float*, int64_t, const float*, float, float, float, float, float, float, float, int, hipStream_t);
 int gemm_launch(const MtrssmGemm*, hipStream_t);
+int gemm_group_launch(const MtrssmGemm*, int, hipStream_t);
 int debug_set_cluster_profile(void*);
 int debug_set_resident_profile(void*);
 int debug_set_wide_profile(void*);
@@ -62,6 +63,12 @@ int adamw_apply_launch(float*, const float*, float*, float*, const unsigned char
 
 // Compute units of the calling thread's current device (0 when there is no device): the kernels whose workgroups wait for each
 // other size their grids by it.  A cache of an immutable device property, not state.
+int mmtrssm_wide_supported(const MtrssmMmtrssmDims*, int);
+size_t mmtrssm_wide_workspace_bytes(const MtrssmMmtrssmDims*, int);
+size_t mmtrssm_wide_bwd_workspace_bytes(const MtrssmMmtrssmDims*, int);
+int mmtrssm_wide_fwd_launch(const MtrssmMmtrssmDims*, const MtrssmMmtrssmFwdWeights*, const MtrssmMmtrssmFwdIO*, int, void*, size_t, hipStream_t);
+int mmtrssm_wide_bwd_launch(const MtrssmMmtrssmDims*, const MtrssmMmtrssmBwdWeights*, const MtrssmMmtrssmBwdIO*, int, void*, size_t, hipStream_t);
+
 int device_cu_count() {
   static int cached[64] = {0};
   int dev = 0;
@@ -142,7 +149,23 @@ MTRSSM_API int mtrssm_mrssm_rollout_bwd_wide(const MtrssmMrssmDims* d, const Mtr
                                              void* workspace, int64_t workspace_bytes, void* stream) {
   return mrssm_wide_bwd_launch(d, w, io, pieces, workspace, workspace_bytes < 0 ? 0 : (size_t)workspace_bytes, static_cast<hipStream_t>(stream));
 }
+MTRSSM_API int mtrssm_mmtrssm_wide_supported(const MtrssmMmtrssmDims* d, int32_t pieces) { return mmtrssm_wide_supported(d, pieces); }
+MTRSSM_API int64_t mtrssm_mmtrssm_wide_workspace_bytes(const MtrssmMmtrssmDims* d, int32_t pieces) { return (int64_t)mmtrssm_wide_workspace_bytes(d, pieces); }
+MTRSSM_API int64_t mtrssm_mmtrssm_wide_bwd_workspace_bytes(const MtrssmMmtrssmDims* d, int32_t pieces) {
+  return (int64_t)mmtrssm_wide_bwd_workspace_bytes(d, pieces);
+}
+MTRSSM_API int mtrssm_mmtrssm_rollout_fwd_wide(const MtrssmMmtrssmDims* d, const MtrssmMmtrssmFwdWeights* w, const MtrssmMmtrssmFwdIO* io, int32_t pieces,
+                                               void* workspace, int64_t workspace_bytes, void* stream) {
+  return mmtrssm_wide_fwd_launch(d, w, io, pieces, workspace, workspace_bytes < 0 ? 0 : (size_t)workspace_bytes, static_cast<hipStream_t>(stream));
+}
+MTRSSM_API int mtrssm_mmtrssm_rollout_bwd_wide(const MtrssmMmtrssmDims* d, const MtrssmMmtrssmBwdWeights* w, const MtrssmMmtrssmBwdIO* io, int32_t pieces,
+                                               void* workspace, int64_t workspace_bytes, void* stream) {
+  return mmtrssm_wide_bwd_launch(d, w, io, pieces, workspace, workspace_bytes < 0 ? 0 : (size_t)workspace_bytes, static_cast<hipStream_t>(stream));
+}
 MTRSSM_API int mtrssm_gemm(const MtrssmGemm* g, void* stream) { return gemm_launch(g, static_cast<hipStream_t>(stream)); }
+MTRSSM_API int mtrssm_gemm_group(const MtrssmGemm* problems, int32_t count, void* stream) {
+  return gemm_group_launch(problems, count, static_cast<hipStream_t>(stream));
+}
 MTRSSM_API int mtrssm_clear(void* p, int64_t bytes, void* stream) {
   return clear_async(p, bytes < 0 ? 0 : (size_t)bytes, static_cast<hipStream_t>(stream));
 }

@@ -160,20 +160,20 @@ __device__ __forceinline__ float image_at(const float* img, int row, int r) {
 // k-step the general form spent ~3000 cycles of address arithmetic, clamps, masks and their waits around 1100 cycles of
 // MFMAs (stamped, one workgroup per CU) -- the MFMA pipe idled 3/4 of the time on the 3200 x 4096 x 256 head GEMMs.
 template <bool AR, bool BR, bool FAST>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
+__device__ __forceinline__ void gemm_f32_body(const GemmArgs& g, const int bx, const int by, const int bz, const int tiles_x) {
   __shared__ __attribute__((aligned(16))) float lds[2][2][kImage];  // [buffer][operand][image]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  const int i0 = blockIdx.y * kTile, j0 = blockIdx.x * kTile;
+  const int i0 = by * kTile, j0 = bx * kTile;
   // this workgroup's share of the reduction (multiples of kStep)
   const int steps = (g.R + kStep - 1) / kStep;
   const int per = (steps + g.splits - 1) / g.splits;
-  const int s_lo = blockIdx.z * per, s_hi = min(steps, s_lo + per);
+  const int s_lo = bz * per, s_hi = min(steps, s_lo + per);
   if (s_lo >= s_hi) return;
   const int r_end = min(g.R, s_hi * kStep);
   const bool vec_a = ((g.lda & 3) == 0) && (((uintptr_t)g.A & 15) == 0);
   const bool vec_b = ((g.ldb & 3) == 0) && (((uintptr_t)g.B & 15) == 0);
-  const bool want_colsum = g.colsum && blockIdx.x == 0;
+  const bool want_colsum = g.colsum && bx == 0;
   float csum = 0.f;
 
   f32x16 acc;
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
   // are the result (bias by slice 0).
   const bool finalize = atomic && g.tickets != nullptr;
   if (atomic) {
-    const float bias0 = (g.bias && !finalize && blockIdx.z == 0) ? g.bias[jc] : 0.f;
+    const float bias0 = (g.bias && !finalize && bz == 0) ? g.bias[jc] : 0.f;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
       const int i = ibase + (reg & 3) + 8 * (reg >> 2);
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
     __shared__ int last_flag;
     __threadfence();
     __syncthreads();
-    if (tid == 0) last_flag = atomicAdd(g.tickets + blockIdx.y * gridDim.x + blockIdx.x, 1) == g.splits - 1;
+    if (tid == 0) last_flag = atomicAdd(g.tickets + by * tiles_x + bx, 1) == g.splits - 1;
     __syncthreads();
     if (!last_flag) {
       if (want_colsum && tid < kTile && i0 + tid < g.M) atomicAdd(g.colsum + i0 + tid, csum);
@@ -322,6 +322,31 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
     if (i < g.M && okj) g.C[(size_t)i * g.ldc + j] = v;
   }
   if (want_colsum && tid < kTile && i0 + tid < g.M) atomicAdd(g.colsum + i0 + tid, csum);
+}
+
+template <bool AR, bool BR, bool FAST>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
+  gemm_f32_body<AR, BR, FAST>(g, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x);
+}
+
+// Several INDEPENDENT problems of one layout in one launch (mtrssm_gemm_group): the scan's ten to fifteen weight-gradient GEMMs
+// ([out, B*T] x [B*T, in], 0.02-0.8 GFLOP each) are latency-bound launches of 15-35 us one by one -- a few k-steps behind a
+// load round trip each, on a fraction of the chip -- and independent of each other: side by side they cost one such latency.
+// A 1-D grid; first[p] = first workgroup of problem p, whose grid is (tiles_x, tiles_y, splits) linearised x-fastest.
+constexpr int kGroupMax = 24;
+struct GemmGroup {
+  int count;
+  int first[kGroupMax + 1];
+  GemmArgs g[kGroupMax];
+};
+template <bool AR, bool BR, bool FAST>
+__global__ __launch_bounds__(256) void gemm_f32_group_kernel(const GemmGroup grp) {
+  int p = 0;
+  while (p + 1 < grp.count && (int)blockIdx.x >= grp.first[p + 1]) ++p;
+  const GemmArgs& g = grp.g[p];
+  const int local = blockIdx.x - grp.first[p];
+  const int tx = (g.N + kTile - 1) / kTile, ty = (g.M + kTile - 1) / kTile;
+  gemm_f32_body<AR, BR, FAST>(g, local % tx, (local / tx) % ty, local / (tx * ty), tx);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -553,7 +578,9 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs g) {
   if (colsum_now) atomicAdd(g.colsum + i0 + tid, csum);
 }
 
-int gemm_launch(const MtrssmGemm* p, hipStream_t stream) {
+// Validation, split choice and the clears a problem needs before its kernel; fills `g`, the grid and whether the FAST
+// (full-tile) instantiation applies.
+static int gemm_prepare(const MtrssmGemm* p, GemmArgs& g, dim3& grid, bool& fast, hipStream_t stream, int fill_target = 768) {
   if (!p || !p->A || !p->B || !p->C || p->M <= 0 || p->N <= 0 || p->R <= 0) {
     set_error("gemm: null operand or non-positive extent");
     return MTRSSM_EINVAL;
@@ -569,7 +596,6 @@ int gemm_launch(const MtrssmGemm* p, hipStream_t stream) {
       set_error("gemm: unknown activation id %d", a);
       return MTRSSM_EINVAL;
     }
-  GemmArgs g;
   g.A = p->A; g.B = p->B; g.C = p->C; g.bias = p->bias; g.zgrad = p->zgrad; g.colsum = p->colsum;
   g.M = p->M; g.N = p->N; g.R = p->R; g.lda = p->lda; g.ldb = p->ldb; g.ldc = p->ldc; g.ldz = p->ldz;
   g.a_rmajor = p->a_rmajor; g.b_rmajor = p->b_rmajor; g.act_a = p->act_a; g.act_b = p->act_b; g.act_out = p->act_out;
@@ -593,7 +619,7 @@ int gemm_launch(const MtrssmGemm* p, hipStream_t stream) {
     // gradient) then needs the ticket words for its last-arriver pass.
     splits = 1;
     if ((plain_epilogue && (p->accumulate || dense_c)) || (!plain_epilogue && can_finalize))
-      while (ti * tj * splits < 768 && steps / (splits * 2) >= 4) splits *= 2;
+      while (ti * tj * splits < fill_target && steps / (splits * 2) >= 4) splits *= 2;
   }
   bool finalize = false;
   if (splits > 1 && !plain_epilogue) {
@@ -614,8 +640,19 @@ int gemm_launch(const MtrssmGemm* p, hipStream_t stream) {
   }
   g.tickets = finalize ? p->tickets : nullptr;
   g.splits = splits;
-  const dim3 grid(tj, ti, splits);
-  if (split_mfma) {
+  grid = dim3(tj, ti, splits);
+  const int per_slice = (steps + splits - 1) / splits;
+  fast = !split_mfma && p->M % kTile == 0 && p->N % kTile == 0 && p->R % kStep == 0 && steps % splits == 0 && per_slice >= 1 &&
+         (p->lda & 3) == 0 && (p->ldb & 3) == 0 && ((uintptr_t)p->A & 15) == 0 && ((uintptr_t)p->B & 15) == 0;
+  return MTRSSM_OK;
+}
+
+int gemm_launch(const MtrssmGemm* p, hipStream_t stream) {
+  GemmArgs g;
+  dim3 grid;
+  bool fast = false;
+  if (int rc = gemm_prepare(p, g, grid, fast, stream)) return rc;
+  if (p->mfma_split == 2) {
     if (p->a_rmajor && p->b_rmajor) {
       set_last_kernel("mtrssm::gemm_split_kernel<true, true>");
       hipLaunchKernelGGL((gemm_split_kernel<true, true>), grid, dim3(256), 0, stream, g);
@@ -630,9 +667,6 @@ int gemm_launch(const MtrssmGemm* p, hipStream_t stream) {
       hipLaunchKernelGGL((gemm_split_kernel<true, false>), grid, dim3(256), 0, stream, g);
     }
   } else {
-    const int per_slice = (steps + splits - 1) / splits;
-    const bool fast = p->M % kTile == 0 && p->N % kTile == 0 && p->R % kStep == 0 && steps % splits == 0 && per_slice >= 1 &&
-                      (p->lda & 3) == 0 && (p->ldb & 3) == 0 && ((uintptr_t)p->A & 15) == 0 && ((uintptr_t)p->B & 15) == 0;
 #define MTRSSM_GEMM_LAUNCH(AR_, BR_)                                                                                  \
   {                                                                                                                   \
     set_last_kernel("mtrssm::gemm_f32_kernel<" #AR_ ", " #BR_ ">");                                                    \
@@ -649,6 +683,60 @@ int gemm_launch(const MtrssmGemm* p, hipStream_t stream) {
   if (e != hipSuccess) {
     set_error("gemm launch failed: %s", hipGetErrorString(e));
     return MTRSSM_ELAUNCH;
+  }
+  return MTRSSM_OK;
+}
+
+// `count` independent problems (no output of one is read or written by another; fp32 MFMA form only).  Problems of one operand
+// layout share launches, kGroupMax at a time; the FAST instantiation is used when every problem of a launch qualifies.
+int gemm_group_launch(const MtrssmGemm* ps, int count, hipStream_t stream) {
+  if (!ps || count <= 0) { set_error("gemm_group: no problems"); return MTRSSM_EINVAL; }
+  for (int layout = 0; layout < 4; ++layout) {
+    const int ar = layout >> 1, br = layout & 1;
+    GemmGroup grp;
+    grp.count = 0;
+    grp.first[0] = 0;
+    bool all_fast = true;
+    auto flush = [&]() -> int {
+      if (grp.count == 0) return MTRSSM_OK;
+      const dim3 grid((unsigned)grp.first[grp.count]);
+#define MTRSSM_GEMM_GROUP_LAUNCH(AR_, BR_)                                                                               \
+  {                                                                                                                      \
+    set_last_kernel("mtrssm::gemm_f32_group_kernel<" #AR_ ", " #BR_ ">");                                                 \
+    if (all_fast) hipLaunchKernelGGL((gemm_f32_group_kernel<AR_, BR_, true>), grid, dim3(256), 0, stream, grp);          \
+    else hipLaunchKernelGGL((gemm_f32_group_kernel<AR_, BR_, false>), grid, dim3(256), 0, stream, grp);                  \
+  }
+      if (ar && br) MTRSSM_GEMM_GROUP_LAUNCH(true, true)
+      else if (!ar && br) MTRSSM_GEMM_GROUP_LAUNCH(false, true)
+      else if (!ar && !br) MTRSSM_GEMM_GROUP_LAUNCH(false, false)
+      else MTRSSM_GEMM_GROUP_LAUNCH(true, false)
+#undef MTRSSM_GEMM_GROUP_LAUNCH
+      grp.count = 0;
+      all_fast = true;
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) { set_error("gemm_group launch failed: %s", hipGetErrorString(e)); return MTRSSM_ELAUNCH; }
+      return MTRSSM_OK;
+    };
+    // the problems of a launch share the chip: each one's reduction is cut to its share of ~1500 workgroups (alone it would be
+    // cut to fill 768 by itself, and ten of those queue up thirty deep per CU)
+    int members = 0;
+    for (int i = 0; i < count; ++i) members += ((ps[i].a_rmajor != 0) == (ar != 0) && (ps[i].b_rmajor != 0) == (br != 0)) ? 1 : 0;
+    const int fill = members > 0 ? (1536 / members < 64 ? 64 : 1536 / members) : 768;
+    for (int i = 0; i < count; ++i) {
+      const MtrssmGemm* p = ps + i;
+      if ((p->a_rmajor != 0) != (ar != 0) || (p->b_rmajor != 0) != (br != 0)) continue;
+      if (p->mfma_split != 0) { set_error("gemm_group: fp32 MFMA problems only (mfma_split = 0)"); return MTRSSM_EINVAL; }
+      GemmArgs g;
+      dim3 grid;
+      bool fast = false;
+      if (int rc = gemm_prepare(p, g, grid, fast, stream, fill < 768 ? fill : 768)) return rc;
+      grp.g[grp.count] = g;
+      grp.first[grp.count + 1] = grp.first[grp.count] + (int)(grid.x * grid.y * grid.z);
+      all_fast = all_fast && fast;
+      if (++grp.count == kGroupMax)
+        if (int rc = flush()) return rc;
+    }
+    if (int rc = flush()) return rc;
   }
   return MTRSSM_OK;
 }

@@ -36,23 +36,35 @@ __global__ __launch_bounds__(256) void wide_pack_kernel(const WidePackJobs jobs)
     const int n = nt * 16 + (lane & 15), k0 = ks * 32 + 8 * (lane >> 4);
     float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (n < jb.N && k0 + j < jb.K) ? jb.src[(long)n * jb.sn + (long)(k0 + j) * jb.sk] : 0.f;
+    for (int j = 0; j < 8; ++j)
+      v[j] = (n < jb.N && n >= jb.nskip && k0 + j < jb.K && k0 + j >= jb.kskip) ? jb.src[(long)(n - jb.nskip) * jb.sn + (long)(k0 + j - jb.kskip) * jb.sk] : 0.f;
     uint2 lo[P], hi[P];
     const float v0[4] = {v[0], v[1], v[2], v[3]}, v1[4] = {v[4], v[5], v[6], v[7]};
     wide_split4<P>(v0, lo);
     wide_split4<P>(v1, hi);
+    const size_t frag = (size_t)(jb.nt0 + nt) * jb.KST + (jb.ks0 + ks);
 #pragma unroll
-    for (int p = 0; p < P; ++p) jb.dst[((size_t)f * P + p) * 64 + lane] = make_uint4(lo[p].x, lo[p].y, hi[p].x, hi[p].y);
+    for (int p = 0; p < P; ++p) jb.dst[(frag * P + p) * 64 + lane] = make_uint4(lo[p].x, lo[p].y, hi[p].x, hi[p].y);
   }
 }
 
-static WidePackJob make_job(const float* src, long sn, long sk, int N, int K, uint4* dst) {
+WidePackJob wide_make_job(const float* src, long sn, long sk, int N, int K, uint4* dst) {
   WidePackJob j;
-  j.src = src; j.sn = sn; j.sk = sk; j.N = N; j.K = K; j.NT = (N + 15) / 16; j.KS = (K + 31) / 32; j.dst = dst;
+  j.src = src; j.sn = sn; j.sk = sk; j.N = N; j.K = K; j.nskip = 0; j.kskip = 0; j.NT = (N + 15) / 16; j.KS = (K + 31) / 32;
+  j.nt0 = 0; j.ks0 = 0; j.KST = j.KS; j.dst = dst;
   return j;
 }
+// a block of a larger packed matrix (KST k-blocks per tile) at tile nt0 / k-block ks0
+WidePackJob wide_make_block(const float* src, long sn, long sk, int N, int K, int nskip, int kskip, int nt0, int ks0, int KST, uint4* dst) {
+  WidePackJob j = wide_make_job(src, sn, sk, N, K, dst);
+  j.nskip = nskip; j.kskip = kskip; j.nt0 = nt0; j.ks0 = ks0; j.KST = KST;
+  return j;
+}
+static WidePackJob make_job(const float* src, long sn, long sk, int N, int K, uint4* dst) { return wide_make_job(src, sn, sk, N, K, dst); }
 
-static int launch_pack(const WidePackJobs& jobs, int pieces, hipStream_t stream) {
+int wide_launch_pack(const WidePackJobs& jobs, int pieces, hipStream_t stream);
+static int launch_pack(const WidePackJobs& jobs, int pieces, hipStream_t stream) { return wide_launch_pack(jobs, pieces, stream); }
+int wide_launch_pack(const WidePackJobs& jobs, int pieces, hipStream_t stream) {
   dim3 grid(256, jobs.count);
   if (pieces == 3) hipLaunchKernelGGL(wide_pack_kernel<3>, grid, dim3(256), 0, stream, jobs);
   else hipLaunchKernelGGL(wide_pack_kernel<2>, grid, dim3(256), 0, stream, jobs);

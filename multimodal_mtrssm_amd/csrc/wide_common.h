@@ -28,11 +28,13 @@ using wf32x4 = __attribute__((ext_vector_type(4))) float;
 struct WidePackJob {
   const float* src;
   long sn, sk;       // element strides of n and k in src
-  int N, K;
-  int NT, KS;        // ceil(N / 16), ceil(K / 32)
+  int N, K;          // extent of the block this job fills; element (n, k) of it = src[(n - nskip) sn + (k - kskip) sk] where
+  int nskip, kskip;  //   n >= nskip and k >= kskip, zero elsewhere (a source that starts inside a tile / a k-block)
+  int NT, KS;        // ceil(N / 16), ceil(K / 32): tiles / k-blocks of the block
+  int nt0, ks0, KST; // position of the block in the destination matrix (tile, k-block) and that matrix's k-blocks per tile
   uint4* dst;
 };
-constexpr int kWideMaxJobs = 8;
+constexpr int kWideMaxJobs = 16;
 struct WidePackJobs {
   WidePackJob j[kWideMaxJobs];
   int count;
@@ -43,7 +45,7 @@ __host__ __device__ inline size_t wide_pack_uint4(int N, int K, int P) {
 }
 // ---- exchange vectors: x[row < 32][k < K] as bf16 pieces in the MFMA B-operand order: [piece][k / 32][row][32 k] -- lane l
 // of row tile rt reads the 16 bytes at uint4 index ((p KS + ks) 32 + 16 rt + (l & 15)) 4 + (l >> 4): 1 KiB contiguous per wave.
-__host__ __device__ inline size_t wide_x_uint4(int K, int P) { return (size_t)P * ((K + 31) / 32) * kWRows * 4; }
+__host__ __device__ inline size_t wide_x_uint4(int K, int P, int rows = kWRows) { return (size_t)P * ((K + 31) / 32) * rows * 4; }
 
 template <int P>
 __device__ __forceinline__ void wide_split4(const float (&v)[4], uint2 (&o)[P]) {
@@ -71,14 +73,14 @@ __device__ __forceinline__ void wide_store_f2(float* p, float a, float b) {
 }
 
 // four consecutive k (k % 4 == 0) of one row into an exchange vector
-template <int P>
+template <int P, int ROWS = kWRows>
 __device__ __forceinline__ void wide_x_store4(uint4* xb, int KS, int row, int k, const float (&v)[4]) {
   uint2 o[P];
   wide_split4<P>(v, o);
   char* base = reinterpret_cast<char*>(xb);
 #pragma unroll
   for (int p = 0; p < P; ++p)
-    wide_store_u2(base + ((size_t)((p * KS + (k >> 5)) * kWRows + row) * 64 + (size_t)(k & 31) * 2), o[p]);
+    wide_store_u2(base + ((size_t)((p * KS + (k >> 5)) * ROWS + row) * 64 + (size_t)(k & 31) * 2), o[p]);
 }
 
 // acc[nt][rt] += W_tile[nt] (16 outputs x K) . x (K x 16 rows of row tile rt) over this wave's k-blocks [ks0, ks1).
@@ -95,24 +97,24 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t wide_rsrc(const void* base) {
 }
 __device__ __forceinline__ float wide_load_f(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-template <int NT, int P, int NS>
-__device__ __forceinline__ void wide_mfma_stream(wf32x4 (&acc)[NT][2], const uint4* const (&wt)[NT], const uint4* __restrict__ xbase, int KS,
+template <int NT, int P, int NS, int RT = 2>
+__device__ __forceinline__ void wide_mfma_stream(wf32x4 (&acc)[NT][RT], const uint4* const (&wt)[NT], const uint4* __restrict__ xbase, int KS,
                                                  int ks0, int ks1, int lane) {
   if (ks0 >= ks1) return;
   const int xlane = (lane & 15) * 4 + (lane >> 4);
   const __amdgpu_buffer_rsrc_t xb = wide_rsrc(xbase);
   uint4 a[NS][NT][P];
-  wu32x4 b[NS][2][P];
+  wu32x4 b[NS][RT][P];
   auto load = [&](int st, int ks) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int p = 0; p < P; ++p) a[st][nt][p] = wt[nt][((size_t)ks * P + p) * 64 + lane];
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int p = 0; p < P; ++p)
-        b[st][rt][p] = __builtin_amdgcn_raw_buffer_load_b128(xb, (((p * KS + ks) * kWRows + 16 * rt) * 4 + xlane) * 16, 0, 16);   // aux 16 = sc1
+        b[st][rt][p] = __builtin_amdgcn_raw_buffer_load_b128(xb, (((p * KS + ks) * (16 * RT) + 16 * rt) * 4 + xlane) * 16, 0, 16);   // aux 16 = sc1
   };
   auto compute = [&](int st) {
 #pragma unroll
@@ -122,7 +124,7 @@ __device__ __forceinline__ void wide_mfma_stream(wf32x4 (&acc)[NT][2], const uin
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-          for (int rt = 0; rt < 2; ++rt)
+          for (int rt = 0; rt < RT; ++rt)
             acc[nt][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wbf16x8, a[st][nt][pa]),
                                                                   __builtin_bit_cast(wbf16x8, b[st][rt][ord - pa]), acc[nt][rt], 0, 0, 0);
   };
@@ -140,17 +142,17 @@ __device__ __forceinline__ void wide_mfma_stream(wf32x4 (&acc)[NT][2], const uin
   }
 }
 
-// Cross-wave reduction through LDS: red[(wave NTOT + tile) 2 + rt][lane] (float4 each).
-template <int NTOT>
-__device__ __forceinline__ void wide_red_store(wf32x4* red, int wave, int tile, int lane, const wf32x4 (&acc)[2]) {
-  red[((wave * NTOT + tile) * 2 + 0) * kWave + lane] = acc[0];
-  red[((wave * NTOT + tile) * 2 + 1) * kWave + lane] = acc[1];
-}
-template <int NTOT>
-__device__ __forceinline__ wf32x4 wide_red_sum(const wf32x4* red, int tile, int rt, int slot) {
-  wf32x4 s = red[((0 * NTOT + tile) * 2 + rt) * kWave + slot];
+// Cross-wave reduction through LDS: red[(wave NTOT + tile) RT + rt][lane] (float4 each).
+template <int NTOT, int RT = 2>
+__device__ __forceinline__ void wide_red_store(wf32x4* red, int wave, int tile, int lane, const wf32x4 (&acc)[RT]) {
 #pragma unroll
-  for (int w = 1; w < kWW; ++w) s += red[((w * NTOT + tile) * 2 + rt) * kWave + slot];
+  for (int rt = 0; rt < RT; ++rt) red[((wave * NTOT + tile) * RT + rt) * kWave + lane] = acc[rt];
+}
+template <int NTOT, int RT = 2>
+__device__ __forceinline__ wf32x4 wide_red_sum(const wf32x4* red, int tile, int rt, int slot) {
+  wf32x4 s = red[((0 * NTOT + tile) * RT + rt) * kWave + slot];
+#pragma unroll
+  for (int w = 1; w < kWW; ++w) s += red[((w * NTOT + tile) * RT + rt) * kWave + slot];
   return s;
 }
 

@@ -92,11 +92,10 @@ SPLIT_PIECES = 0
 SPLIT_MIN_FLOPS = 5.0e8
 
 
-def gemm(a: Tensor, b: Tensor, c: Tensor, *, a_rmajor: bool, b_rmajor: bool, bias: Tensor | None = None, zgrad: Tensor | None = None,  # noqa: PLR0913
-         colsum: Tensor | None = None, act_a: int = 0, act_b: int = 0, act_z: int = 0, accumulate: bool = False, split_r: int = 0,
-         mfma_split: int | None = None) -> None:
-    """``c[i][j] (+)= (bias[j] + sum_r actA(a'(i,r)) actB(b'(j,r))) * act_z'(zgrad[i][j])`` (``include/mtrssm.h: MtrssmGemm``).
-    ``a`` is ``[M, R]`` (or ``[R, M]`` when ``a_rmajor``), ``b`` is ``[N, R]`` (or ``[R, N]`` when ``b_rmajor``), ``c`` is ``[M, N]``."""
+def _problem(a: Tensor, b: Tensor, c: Tensor, *, a_rmajor: bool, b_rmajor: bool, bias: Tensor | None = None, zgrad: Tensor | None = None,  # noqa: PLR0913
+             colsum: Tensor | None = None, act_a: int = 0, act_b: int = 0, act_z: int = 0, accumulate: bool = False, split_r: int = 0,
+             mfma_split: int | None = None) -> tuple[C.Structure, float, float]:
+    """The ``MtrssmGemm`` of one problem (+ its FLOPs and algorithmic bytes); shapes and layouts are checked here."""
     m, r = (a.shape[1], a.shape[0]) if a_rmajor else (a.shape[0], a.shape[1])
     n, r2 = (b.shape[1], b.shape[0]) if b_rmajor else (b.shape[0], b.shape[1])
     if r != r2 or tuple(c.shape) != (m, n):
@@ -126,9 +125,117 @@ def gemm(a: Tensor, b: Tensor, c: Tensor, *, a_rmajor: bool, b_rmajor: bool, bia
         if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
             msg = "gemm: bias / colsum must be contiguous fp32 vectors"
             raise _lib.MtrssmLibraryError(msg)
+    return g, 2.0 * m * n * r, 4.0 * (m * r + n * r + m * n)
+
+
+def gemm(a: Tensor, b: Tensor, c: Tensor, **kw) -> None:  # noqa: ANN003
+    """``c[i][j] (+)= (bias[j] + sum_r actA(a'(i,r)) actB(b'(j,r))) * act_z'(zgrad[i][j])`` (``include/mtrssm.h: MtrssmGemm``).
+    ``a`` is ``[M, R]`` (or ``[R, M]`` when ``a_rmajor``), ``b`` is ``[N, R]`` (or ``[R, N]`` when ``b_rmajor``), ``c`` is ``[M, N]``.
+    Keywords: ``a_rmajor, b_rmajor, bias, zgrad, colsum, act_a, act_b, act_z, accumulate, split_r, mfma_split``."""
+    g, flops, nbytes = _problem(a, b, c, **kw)
     lib = _lib.load()
-    _lib.check(_lib.TIMERS.call("mtrssm_gemm", lib.mtrssm_gemm, C.byref(g), _lib.stream_ptr(a.device), flops=2.0 * m * n * r,
-                                nbytes=4.0 * (m * r + n * r + m * n)), "mtrssm_gemm")
+    _lib.check(_lib.TIMERS.call("mtrssm_gemm", lib.mtrssm_gemm, C.byref(g), _lib.stream_ptr(a.device), flops=flops, nbytes=nbytes), "mtrssm_gemm")
+
+
+GROUP_GEMMS = True  # False: every problem of a group as its own launch (A/B runs, tests)
+
+
+def _span(t: Tensor) -> tuple[int, int]:
+    """Byte range a (possibly strided) tensor's elements lie in."""
+    lo = t.data_ptr()
+    return lo, lo + 4 * (sum((n - 1) * st for n, st in zip(t.shape, t.stride(), strict=True)) + 1 if t.numel() else 0)
+
+
+def _rounds(problems: list) -> list[list]:
+    """Problems whose outputs (C, column sums) may touch the same memory must not share a launch (a problem whose reduction is
+    not split accumulates by plain read-modify-write): e.g. the prior head's weights collect a gradient from the initial state
+    AND one from the scan.  Greedy rounds by byte range; interleaved column views of one matrix land in different rounds too."""
+    rounds: list[tuple[list, list]] = []
+    for problem in problems:
+        (_a, _b, c), kw = problem
+        spans = [_span(c)] + ([_span(kw["colsum"])] if kw.get("colsum") is not None else [])
+        for members, taken in rounds:
+            if all(hi <= lo2 or hi2 <= lo for lo, hi in spans for lo2, hi2 in taken):
+                members.append(problem)
+                taken.extend(spans)
+                break
+        else:
+            rounds.append(([problem], list(spans)))
+    return [members for members, _ in rounds]
+
+
+def gemm_group(problems: list[tuple[tuple[Tensor, Tensor, Tensor], dict]]) -> None:
+    """Problems ``[((a, b, c), keywords of gemm), ...]`` whose outputs are not operands of each other, in as few launches as
+    their operand layouts and output overlaps allow (``mtrssm_gemm_group``; problems accumulating into the SAME memory go to
+    successive launches): what the weight gradients of one backward pass are."""
+    if not problems:
+        return
+    if not GROUP_GEMMS or len(problems) == 1:
+        for (a, b, c), kw in problems:
+            gemm(a, b, c, **kw)
+        return
+    rounds = _rounds(problems)
+    if len(rounds) > 1:
+        for members in rounds:
+            gemm_group(members)
+        return
+    built = [_problem(a, b, c, mfma_split=0, **kw) for (a, b, c), kw in problems]
+    arr = (_lib.Gemm * len(built))(*[g for g, _, _ in built])
+    dev = problems[0][0][0].device
+    lib = _lib.load()
+    _lib.check(_lib.TIMERS.call("mtrssm_gemm_group", lib.mtrssm_gemm_group, arr, len(built), _lib.stream_ptr(dev),
+                                flops=sum(f for _, f, _ in built), nbytes=sum(n for _, _, n in built)), "mtrssm_gemm_group")
+
+
+class _DeferredWeightGrads:
+    """Weight gradients that accumulate straight into a flat gradient buffer feed nothing else in the backward pass, so they
+    need not run where autograd reaches their layer: they are collected and launched SIDE BY SIDE at the end of the pass (one
+    ``mtrssm_gemm_group`` call from autograd's ``queue_callback``) -- two dozen latency-bound launches of 20-40 us each become
+    one or two.  The operands (saved activations, gradient tensors) stay referenced until then.  As for ``conv._ConvGradSink``:
+    a backward that raises never runs the callback, so ``discard()`` re-arms at the next step and ``flush()`` is also called
+    by the consumers of the flat buffer (``FlatAdamW.step``, ``FlatDataParallel.reduce``)."""
+
+    def __init__(self) -> None:
+        self.pending: list = []
+        self.armed = False
+
+    def add(self, problem: tuple) -> bool:
+        if not self.armed:
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(self.flush)  # noqa: SLF001
+            except RuntimeError:  # not inside a backward pass: nothing would ever flush
+                return False
+            self.armed = True
+        self.pending.append(problem)
+        return True
+
+    def flush(self) -> None:
+        self.armed = False
+        problems, self.pending = self.pending, []
+        # big problems fill the chip on their own (grouped they only share its caches); the small ones go side by side
+        small = [p for p in problems if 2.0 * p[0][0].numel() * p[0][1].shape[1] < GROUP_MAX_FLOPS]
+        big = [p for p in problems if 2.0 * p[0][0].numel() * p[0][1].shape[1] >= GROUP_MAX_FLOPS]
+        gemm_group(small)
+        for (a, b, c), kw in big:
+            gemm(a, b, c, **kw)
+
+    def discard(self) -> None:
+        self.armed = False
+        self.pending = []
+
+
+DEFER_WEIGHT_GRADS = True
+GROUP_MAX_FLOPS = 4.0e9  # per problem (2 M N R): above it a GEMM is a chip-filling launch of its own
+_DEFERRED = _DeferredWeightGrads()
+
+
+def flush_deferred() -> None:
+    if _DEFERRED.pending:
+        _DEFERRED.flush()
+
+
+def discard_deferred() -> None:
+    _DEFERRED.discard()
 
 
 def weight_grad(gy: Tensor, x: Tensor, weight: Tensor, bias: Tensor | None, *, act_x: int = 0, want_weight: bool = True,
@@ -147,7 +254,10 @@ def weight_grad(gy: Tensor, x: Tensor, weight: Tensor, bias: Tensor | None, *, a
         if gb is None:
             gb = gb_ret = torch.zeros(bias.shape, device=gy.device, dtype=torch.float32)
     if want_weight:
-        gemm(gy, x, gw, a_rmajor=True, b_rmajor=True, act_b=act_x, colsum=gb, accumulate=True)
+        problem = ((gy, x, gw), dict(a_rmajor=True, b_rmajor=True, act_b=act_x, colsum=gb, accumulate=True))
+        sunk = gw_ret is None and gb_ret is None  # nothing is handed back to autograd: the launch can wait for the end of the pass
+        if not (DEFER_WEIGHT_GRADS and sunk and _DEFERRED.add(problem)):
+            gemm(gy, x, gw, **problem[1])
     elif gb is not None:
         gb.add_(gy.sum(0))
     return gw_ret, gb_ret

@@ -106,6 +106,7 @@ class FlatParameters:
         inside a captured train step a 16 MB memset node came back with foreign bytes at the buffer's head on replay."""
         g = self.grad_full
         conv.discard_pending_grads()  # packed conv weight gradients of a backward that raised belong to the sums being cleared
+        linear.discard_deferred()
         if g.is_cuda:
             _lib.check(_lib.load().mtrssm_clear(_lib.ptr(g), g.numel() * 4, _lib.stream_ptr(g.device)), "mtrssm_clear")
         else:
@@ -172,6 +173,7 @@ class FlatAdamW:
         if check:
             scan.STATUS.poll()  # raises if a scan launch of an EARLIER step failed (its update was skipped on the device)
             conv.flush_pending_grads()  # a backward that raised half-way left conv weight gradients in their packed buffers
+            linear.flush_deferred()  # ... and weight-gradient GEMMs waiting for the end of the pass
             f.check_views()
             self.sync_lr()
         lib = _lib.load()

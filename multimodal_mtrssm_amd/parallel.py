@@ -16,7 +16,7 @@ import torch
 import torch.distributed as dist
 from torch import Tensor
 
-from multimodal_mtrssm_amd import conv
+from multimodal_mtrssm_amd import conv, linear
 from multimodal_mtrssm_amd.optim import FlatParameters
 
 
@@ -96,6 +96,7 @@ class FlatDataParallel:
     def reduce(self) -> None:
         """THE exchange of the step: one all-reduce (SUM, left un-normalised) over gradients + tail."""
         conv.flush_pending_grads()  # (only after a backward that raised: the sink's callback never ran)
+        linear.flush_deferred()
         if self.active:  # also with one rank: same code path, the collective is then a no-op copy
             dist.all_reduce(self.flat.grad_full, op=dist.ReduceOp.SUM, group=self.group)
 

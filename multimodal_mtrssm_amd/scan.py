@@ -25,7 +25,8 @@ from torch import Tensor
 
 from multimodal_mtrssm_amd import _lib
 from multimodal_mtrssm_amd.distributions import KL_BALANCE_ALPHA
-from multimodal_mtrssm_amd.linear import gemm, grad_target, linear
+from multimodal_mtrssm_amd import linear as _linear
+from multimodal_mtrssm_amd.linear import gemm, gemm_group, grad_target, linear
 
 
 @dataclass(frozen=True)
@@ -43,6 +44,7 @@ class ScanConfig:
 
 
 KERNEL_TIMERS = _lib.TIMERS
+DEFER_SCAN_GRADS = True  # the scan's weight gradients join the end-of-backward group of linear._DeferredWeightGrads
 
 # Two families of COOPERATIVE scan kernels (their workgroups wait for each other inside one launch, so every workgroup must be
 # resident: a GPU shared with another process must switch them off):
@@ -170,13 +172,15 @@ def _opt(t: Tensor | None) -> Tensor | None:
 
 
 class _WeightGrads:
-    """Collects ``dW[:, cols] += gy^T x`` / ``db += colsum(gy)`` launches of one backward; ``result(w)`` is what autograd gets
-    for ``w``: None when the gradient went straight into a flat gradient buffer, else the tensor it was accumulated in."""
+    """Collects the ``dW[:, cols] += gy^T x`` / ``db += colsum(gy)`` problems of one backward scan; ``result(w)`` is what autograd
+    gets for ``w``: None when the gradient goes straight into a flat gradient buffer, else the tensor it was accumulated in.
+    The problems are independent of each other: ``flush()`` launches them side by side."""
 
     def __init__(self) -> None:
         self.own: dict[int, Tensor] = {}
+        self.pending: list = []  # (problem, lands in a flat gradient buffer)
 
-    def _target(self, w: Tensor, rows: slice | None, cols: slice | None) -> Tensor:
+    def _target(self, w: Tensor, rows: slice | None, cols: slice | None) -> tuple[Tensor, bool]:
         view = w
         if rows is not None:
             view = view[rows]
@@ -184,7 +188,7 @@ class _WeightGrads:
             view = view[:, cols]
         tgt = grad_target(view)
         if tgt is not None:
-            return tgt
+            return tgt, True
         full = self.own.get(id(w))
         if full is None:
             full = self.own[id(w)] = torch.zeros_like(w)
@@ -193,14 +197,27 @@ class _WeightGrads:
             out = out[rows]
         if cols is not None:
             out = out[:, cols]
-        return out
+        return out, False
 
     def add(self, gy: Tensor, x: Tensor, w: Tensor, *, cols: slice | None = None, bias: Tensor | None = None) -> None:
         """``w.grad[:, cols] += gy^T x`` with ``gy [B*T, out]``, ``x [B*T, in]`` (strided column views welcome)."""
-        gemm(gy, x, self._target(w, None, cols), a_rmajor=True, b_rmajor=True, colsum=None if bias is None else self._target(bias, None, None),
-             accumulate=True)
+        target, sunk = self._target(w, None, cols)
+        colsum = None
+        if bias is not None:
+            colsum, bias_sunk = self._target(bias, None, None)
+            sunk = sunk and bias_sunk
+        self.pending.append((((gy, x, target), dict(a_rmajor=True, b_rmajor=True, colsum=colsum, accumulate=True)), sunk))
+
+    def flush(self) -> None:
+        """Problems that land in a flat gradient buffer join the end-of-backward group of ``linear._DeferredWeightGrads``; the
+        others (their results are handed back to autograd) go here, as one grouped launch (``mtrssm_gemm_group``)."""
+        now = [problem for problem, sunk in self.pending if not (DEFER_SCAN_GRADS and sunk and _linear._DEFERRED.add(problem))]  # noqa: SLF001
+        gemm_group(now)
+        self.pending = []
 
     def result(self, w: Tensor) -> Tensor | None:
+        if self.pending:
+            self.flush()
         return self.own.get(id(w))
 
 
@@ -548,8 +565,20 @@ class _MmtrssmScan(torch.autograd.Function):
             u_prior_l=u_prior_l, u_prior_h=u_prior_h, **o, **sv,
         )
         dims = cfg.dims(B, T, LD, HD, H, 1)
-        _lib.check(_lib.TIMERS.call("mtrssm_mmtrssm_rollout_fwd", lib.mtrssm_mmtrssm_rollout_fwd, C.byref(dims), C.byref(fw), C.byref(io),
-                                     _lib.stream_ptr(xl.device)), "mtrssm_mmtrssm_rollout_fwd")
+        macs = (LS + HS) * LD + LD * LD + HS * HD + HD * HD + 4 * H * LD + 2 * H * HD + 3 * LS * H + 2 * HS * H
+        per_bt = LD + 2 * H + 2 * (LD + HD) + 2 * (LS + HS) + 2 * (LS + HS) + 2 + (5 * H + 2 * LS if need_grad else 0)
+        wide = (WIDE_SCAN and cfg.rows_per_block == 0 and cfg.threads == 0
+                and bool(lib.mtrssm_mmtrssm_wide_supported(C.byref(dims), WIDE_PIECES)))
+        ctx.scan_kind = "wide" if wide else None
+        if wide:
+            ws = _workspace(xl.device, int(lib.mtrssm_mmtrssm_wide_workspace_bytes(C.byref(dims), WIDE_PIECES)))
+            _lib.check(_lib.TIMERS.call("mtrssm_mmtrssm_rollout_fwd_wide", lib.mtrssm_mmtrssm_rollout_fwd_wide, C.byref(dims), C.byref(fw),
+                                         C.byref(io), WIDE_PIECES, _lib.raw_ptr(ws), ws.numel() * 8, _lib.stream_ptr(xl.device),
+                                         flops=2.0 * B * T * macs, nbytes=4.0 * B * T * per_bt), "mtrssm_mmtrssm_rollout_fwd_wide")
+        else:
+            _lib.check(_lib.TIMERS.call("mtrssm_mmtrssm_rollout_fwd", lib.mtrssm_mmtrssm_rollout_fwd, C.byref(dims), C.byref(fw), C.byref(io),
+                                         _lib.stream_ptr(xl.device), flops=2.0 * B * T * macs, nbytes=4.0 * B * T * per_bt),
+                       "mtrssm_mmtrssm_rollout_fwd")
         del tensors
         if need_grad:
             ctx.cfg, ctx.A = cfg, A
@@ -597,8 +626,17 @@ class _MmtrssmScan(torch.autograd.Function):
             g_kl_l=_opt(g_kll), g_kl_h=_opt(g_klh), **g0, **d,
         )
         dims = cfg.dims(B, T, LD, HD, H, 1)
-        _lib.check(_lib.TIMERS.call("mtrssm_mmtrssm_rollout_bwd", lib.mtrssm_mmtrssm_rollout_bwd, C.byref(dims), C.byref(bw), C.byref(io),
-                                     _lib.stream_ptr(deter_l.device)), "mtrssm_mmtrssm_rollout_bwd")
+        macs = (LS + HS) * LD + LD * LD + HS * HD + HD * HD + 4 * H * LD + 2 * H * HD + 3 * LS * H + 2 * HS * H
+        per_bt = 5 * H + 2 * LS + 4 * (LD + HD) + 4 * (LS + HS) + 2 * (LD + HD) + 5 * H + 3 * LS + 2 * HS
+        if getattr(ctx, "scan_kind", None) == "wide" and WIDE_SCAN and WIDE_BWD:
+            ws = _workspace(deter_l.device, int(lib.mtrssm_mmtrssm_wide_bwd_workspace_bytes(C.byref(dims), WIDE_PIECES)))
+            _lib.check(_lib.TIMERS.call("mtrssm_mmtrssm_rollout_bwd_wide", lib.mtrssm_mmtrssm_rollout_bwd_wide, C.byref(dims), C.byref(bw),
+                                         C.byref(io), WIDE_PIECES, _lib.raw_ptr(ws), ws.numel() * 8, _lib.stream_ptr(deter_l.device),
+                                         flops=2.0 * B * T * macs, nbytes=4.0 * B * T * per_bt), "mtrssm_mmtrssm_rollout_bwd_wide")
+        else:
+            _lib.check(_lib.TIMERS.call("mtrssm_mmtrssm_rollout_bwd", lib.mtrssm_mmtrssm_rollout_bwd, C.byref(dims), C.byref(bw), C.byref(io),
+                                         _lib.stream_ptr(deter_l.device), flops=2.0 * B * T * macs, nbytes=4.0 * B * T * per_bt),
+                       "mtrssm_mmtrssm_rollout_bwd")
 
         prev_sl = torch.cat([stoch_l0.unsqueeze(1), post_stoch_l[:, :-1]], dim=1)
         prev_sh = torch.cat([stoch_h0.unsqueeze(1), post_stoch_h[:, :-1]], dim=1)

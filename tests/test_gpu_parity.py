@@ -288,6 +288,53 @@ def test_wide_scan_matches_single_cu_scan(pieces: int, batch: int, steps: int, l
         np.testing.assert_allclose(_np(g1[k]), _np(g), rtol=1e-3, atol=2e-5 * loose * (float(g.abs().max()) + 1e-9), err_msg=k)
 
 
+@pytest.mark.parametrize(("pieces", "batch", "steps"), [(3, 5, 6), (3, 70, 3), (2, 9, 4)])
+def test_wide_mmtrssm_scan_matches_single_cu_scan(pieces: int, batch: int, steps: int, lib_loaded: None) -> None:
+    """csrc/mmtrssm_wide.hip (default for ld or hd >= 128: BASELINE configs[2] dims, ld = hd = H = 200, 6 x 5 categoricals on both
+    levels) vs csrc/mmtrssm_scan.hip on the same inputs, forward and BPTT: same samples on both levels, deter / hidden /
+    probabilities to 5e-6, losses to 5e-6, gradients to 2e-5 of the tensor's max (two pieces: x 20).  70 rows = two passes of 64
+    rows, the second one ragged; 200 is not a multiple of 16: the last column tile of every product is half empty."""
+    from multimodal_mtrssm_amd import scan
+
+    case = with_sizes(CASES["mmtrssm_cfg3dims"], batch, steps)
+    oracle = build_model(case)
+    batch_t = tuple(b.to(DEV) for b in build_batch(case))
+    noise = _to(build_noise(case), DEV)
+    runs = {}
+    saved = (scan.WIDE_SCAN, scan.WIDE_PIECES)
+    for wide in (False, True):
+        scan.WIDE_SCAN, scan.WIDE_PIECES = wide, pieces
+        try:
+            model = product_from_case(case, oracle, DEV)
+            with torch.no_grad():
+                state0 = model.initial_state((batch_t[1][:, 0], batch_t[2][:, 0]), noise)
+                post, prior = model.rollout_representation(actions=batch_t[0], observations=(batch_t[1], batch_t[2]), prev_state=state0,
+                                                           noise=noise)
+            out = model.shared_step(batch_t, noise)
+            out["loss"].backward()
+            scan.check_cluster_status()
+            runs[wide] = (post, prior, {k: float(v) for k, v in out.items()},
+                          {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+        finally:
+            scan.WIDE_SCAN, scan.WIDE_PIECES = saved
+    (p0, q0, l0, g0), (p1, q1, l1, g1) = runs[False], runs[True]
+    loose = 1.0 if pieces == 3 else 20.0
+    for k in ("stoch_l", "stoch_h"):
+        assert torch.equal(getattr(p0, k), getattr(p1, k)) and torch.equal(getattr(q0, k), getattr(q1, k)), k
+    for k in ("deter_l", "deter_h", "hidden_l", "hidden_h"):
+        np.testing.assert_allclose(_np(getattr(p1, k)), _np(getattr(p0, k)), atol=5e-6 * loose, err_msg=k)
+    for a, b in ((p1.distribution_l, p0.distribution_l), (p1.distribution_h, p0.distribution_h), (q1.distribution_l, q0.distribution_l),
+                 (q1.distribution_h, q0.distribution_h)):
+        np.testing.assert_allclose(_np(a.probs), _np(b.probs), atol=5e-6 * loose)
+    np.testing.assert_allclose(_np(p1.kl_per_step), _np(p0.kl_per_step), rtol=1e-4 * loose, atol=2e-6 * loose)
+    np.testing.assert_allclose(_np(p1.kl_h_per_step), _np(p0.kl_h_per_step), rtol=1e-4 * loose, atol=2e-6 * loose)
+    for k in l0:
+        np.testing.assert_allclose(l1[k], l0[k], rtol=5e-6 * loose, err_msg=k)
+    assert set(g0) == set(g1)
+    for k, g in g0.items():
+        np.testing.assert_allclose(_np(g1[k]), _np(g), rtol=1e-3, atol=2e-5 * loose * (float(g.abs().max()) + 1e-9), err_msg=k)
+
+
 # ---------------------------------------------------------------------------------------------
 # row-tile variants and ragged batches: every tiling gives the same answer
 # ---------------------------------------------------------------------------------------------
@@ -925,6 +972,53 @@ def test_gemm_kernel(m: int, n: int, r: int, a_rm: bool, b_rm: bool, extras: str
     if colsum is not None:
         want_cs = colsum0.double() + (a.t() if a_rm else a).double().sum(1)
         np.testing.assert_allclose(_np(colsum), want_cs.float().numpy(), rtol=rtol, atol=tol * float(want_cs.abs().max()))
+
+
+def test_grouped_gemm_equals_the_single_launches(lib_loaded: None) -> None:
+    """mtrssm_gemm_group (independent problems of one layout in one grid; the scan's weight gradients go through it): the same
+    arithmetic per problem as mtrssm_gemm -- bitwise when the reduction is not split, to the arrival order of the fp32 atomics
+    when it is -- over ragged and full tiles, both weight-gradient style (r-major operands, accumulate, column sums) and plain
+    forward problems in ONE call (two layouts = two launches), and more problems than one launch holds (24)."""
+    from multimodal_mtrssm_amd import linear
+
+    g = torch.Generator().manual_seed(3)
+    problems, singles = [], []
+    shapes = [(200, 200, 3200), (30, 200, 3200), (600, 200, 640), (64, 128, 256), (7, 5, 33)] * 6  # 30 weight-gradient problems
+    for i, (m, n, r) in enumerate(shapes):
+        a = torch.randn(r, m, generator=g).to(DEV)
+        b = torch.randn(r, n, generator=g).to(DEV)
+        c0 = torch.randn(m, n, generator=g).to(DEV)
+        cs0 = torch.randn(m, generator=g).to(DEV)
+        c1, c2, cs1, cs2 = c0.clone(), c0.clone(), cs0.clone(), cs0.clone()
+        kw = dict(a_rmajor=True, b_rmajor=True, accumulate=True)
+        problems.append(((a, b, c1), dict(kw, colsum=cs1 if i % 2 == 0 else None)))
+        singles.append(((a, b, c2), dict(kw, colsum=cs2 if i % 2 == 0 else None), cs1, cs2))
+    for m, n, r in ((3200, 200, 256), (100, 64, 96)):  # forward-layout problems in the same call
+        a = torch.randn(m, r, generator=g).to(DEV)
+        b = torch.randn(n, r, generator=g).to(DEV)
+        bias = torch.randn(n, generator=g).to(DEV)
+        c1, c2 = torch.empty(m, n, device=DEV), torch.empty(m, n, device=DEV)
+        problems.append(((a, b, c1), dict(a_rmajor=False, b_rmajor=False, bias=bias)))
+        singles.append(((a, b, c2), dict(a_rmajor=False, b_rmajor=False, bias=bias), None, None))
+    # two problems that accumulate into the SAME matrix (the prior head's weights get a gradient from the initial state and one from
+    # the scan): they must not share a launch (an unsplit reduction accumulates by plain read-modify-write) -- successive rounds
+    a = torch.randn(40, 64, generator=g).to(DEV)
+    b = torch.randn(40, 32, generator=g).to(DEV)
+    shared1, shared2 = torch.zeros(64, 32, device=DEV), torch.zeros(64, 32, device=DEV)
+    for _ in range(2):
+        problems.append(((a, b, shared1), dict(a_rmajor=True, b_rmajor=True, accumulate=True)))
+        singles.append(((a, b, shared2), dict(a_rmajor=True, b_rmajor=True, accumulate=True), None, None))
+    assert len(linear._rounds(problems)) == 2  # noqa: SLF001
+    linear.gemm_group(problems)
+    for (abc, kw, _cs1, _cs2) in singles:
+        linear.gemm(*abc, **kw)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(_np(shared1), 2.0 * _np(a.t() @ b), rtol=1e-5, atol=1e-4)
+    for ((_, _, c1), _), ((a, _, c2), kw, cs1, cs2) in zip(problems, singles, strict=True):
+        scale = float(c2.abs().max()) + 1e-9
+        np.testing.assert_allclose(_np(c1), _np(c2), rtol=0, atol=2e-6 * scale)
+        if kw.get("colsum") is not None:
+            np.testing.assert_allclose(_np(cs1), _np(cs2), rtol=0, atol=2e-5 * (float(cs2.abs().max()) + 1e-9))
 
 
 def test_linear_function_and_gradient_sink(lib_loaded: None) -> None:
