@@ -46,6 +46,7 @@ int gemm_group_launch(const MtrssmGemm*, int, hipStream_t);
 int debug_set_cluster_profile(void*);
 int debug_set_resident_profile(void*);
 int debug_set_wide_profile(void*);
+int debug_set_mmt_profile(void*);
 int mrssm_cluster_supported(const MtrssmMrssmDims*);
 size_t mrssm_cluster_workspace_bytes(const MtrssmMrssmDims*);
 size_t mrssm_cluster_bwd_workspace_bytes(const MtrssmMrssmDims*);
@@ -131,6 +132,7 @@ MTRSSM_API int mtrssm_mrssm_rollout_fwd_cluster(const MtrssmMrssmDims* d, const 
 extern "C" __attribute__((visibility("default"))) int mtrssm_debug_set_cluster_profile(void* buf) { return debug_set_cluster_profile(buf); }
 extern "C" __attribute__((visibility("default"))) int mtrssm_debug_set_resident_profile(void* buf) { return debug_set_resident_profile(buf); }
 extern "C" __attribute__((visibility("default"))) int mtrssm_debug_set_wide_profile(void* buf) { return debug_set_wide_profile(buf); }
+extern "C" __attribute__((visibility("default"))) int mtrssm_debug_set_mmt_profile(void* buf) { return debug_set_mmt_profile(buf); }
 MTRSSM_API int64_t mtrssm_mrssm_cluster_bwd_workspace_bytes(const MtrssmMrssmDims* d) { return (int64_t)mrssm_cluster_bwd_workspace_bytes(d); }
 MTRSSM_API int mtrssm_mrssm_rollout_bwd_cluster(const MtrssmMrssmDims* d, const MtrssmMrssmClusterWeights* w, const MtrssmMrssmBwdIO* io,
                                                 void* workspace, int64_t workspace_bytes, void* stream) {

@@ -29,6 +29,13 @@ WidePackJob wide_make_job(const float* src, long sn, long sk, int N, int K, uint
 WidePackJob wide_make_block(const float* src, long sn, long sk, int N, int K, int nskip, int kskip, int nt0, int ks0, int KST, uint4* dst);
 int wide_launch_pack(const WidePackJobs& jobs, int pieces, hipStream_t stream);
 
+// Development aid (tools/wide_probe.py mmt-fwd | mmt-bwd): as g_wide_prof of mrssm_wide.hip.
+__device__ unsigned long long* g_mmt_prof = nullptr;
+#define MTRSSM_MMT_STAMP(i)                                                                                               \
+  do {                                                                                                                    \
+    if (prof && tstamp >= 8 && tstamp < 12) prof[((size_t)blockIdx.x * 4 + (tstamp - 8)) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+
 constexpr int kMRT = 4;             // row tiles per pass
 constexpr int kMRows = 16 * kMRT;   // 64 batch rows
 constexpr int kMNS = 3;             // register stages of the operand ring
@@ -118,8 +125,11 @@ __global__ __launch_bounds__(kWT) void mmtrssm_wide_fwd_kernel(const MmtWideFwdA
       }
     }
     int cur = 0;
+    unsigned long long* const prof = (tid == 0 && rb == 0) ? g_mmt_prof : nullptr;
 
     for (int t = 0; t <= T; ++t) {
+      const int tstamp = t;
+      MTRSSM_MMT_STAMP(0);
       // ============ F0: one workgroup per batch row ============
       for (int r = nblk - 1 - blk; r < nrows; r += nblk) {
         const size_t b = (size_t)(rb + r);
@@ -142,31 +152,32 @@ __global__ __launch_bounds__(kWT) void mmtrssm_wide_fwd_kernel(const MmtWideFwdA
             }
           }
           lds_barrier();
-          if (wave == 0) {
+          MTRSSM_MMT_STAMP(10);
+          if (wave == 0) {   // lower level: MoPoE mix, categorical block
             wave_mopoe_mix<true>(Lla, Llv, Lmx, LS, lane);
             for (int s2 = lane; s2 < LS; s2 += kWave) {
               io.prior_logits_l[q * LS + s2] = Llpl[s2];
               io.post_logits_l[q * LS + s2] = Lmx[s2];
               if (io.sv_la) { io.sv_la[q * LS + s2] = Lla[s2]; io.sv_lv[q * LS + s2] = Llv[s2]; }
             }
-            for (int s2 = lane; s2 < HS; s2 += kWave) {
-              io.prior_logits_h[q * HS + s2] = Llph[s2];
-              io.post_logits_h[q * HS + s2] = Llqh[s2];
-            }
             float kll = CL <= 8 ? cat_block_fwd_fast8(Lmx, Llpl, KL, CL, lane, Lu, io.u_prior_l ? Lu + 64 : nullptr, Ls, io.post_stoch_l + q * LS,
                                                      io.prior_stoch_l ? io.prior_stoch_l + q * LS : nullptr, true)
                                 : cat_block_fwd<true, true>(Lmx, Llpl, KL, CL, lane, Lu, io.u_prior_l ? Lu + 64 : nullptr, Ls, io.post_stoch_l + q * LS,
                                                             io.prior_stoch_l ? io.prior_stoch_l + q * LS : nullptr, true);
+            kll = wave_sum(kll);
+            if (lane == 0 && io.kl_l) io.kl_l[q] = kll;
+            MTRSSM_MMT_STAMP(11);
+          } else if (wave == 1) {   // higher level, beside it on another SIMD
+            for (int s2 = lane; s2 < HS; s2 += kWave) {
+              io.prior_logits_h[q * HS + s2] = Llph[s2];
+              io.post_logits_h[q * HS + s2] = Llqh[s2];
+            }
             float klh = CH <= 8 ? cat_block_fwd_fast8(Llqh, Llph, KH, CH, lane, Lu + 128, io.u_prior_h ? Lu + 192 : nullptr, Ls + LS,
                                                      io.post_stoch_h + q * HS, io.prior_stoch_h ? io.prior_stoch_h + q * HS : nullptr, true)
                                 : cat_block_fwd<true, true>(Llqh, Llph, KH, CH, lane, Lu + 128, io.u_prior_h ? Lu + 192 : nullptr, Ls + LS,
                                                             io.post_stoch_h + q * HS, io.prior_stoch_h ? io.prior_stoch_h + q * HS : nullptr, true);
-            kll = wave_sum(kll);
             klh = wave_sum(klh);
-            if (lane == 0) {
-              if (io.kl_l) io.kl_l[q] = kll;
-              if (io.kl_h) io.kl_h[q] = klh;
-            }
+            if (lane == 0 && io.kl_h) io.kl_h[q] = klh;
           }
           lds_barrier();
         } else {
@@ -185,7 +196,9 @@ __global__ __launch_bounds__(kWT) void mmtrssm_wide_fwd_kernel(const MmtWideFwdA
         lds_barrier();
       }
       if (t == T) break;
+      MTRSSM_MMT_STAMP(1);
       if (!bar.sync(1 + 4 * t)) return;
+      MTRSSM_MMT_STAMP(2);
 
       // ============ F1: both MTRNN cells, one workgroup per 16 deter units ============
       for (int u = blk; u < G.NTL + G.NTHd; u += nblk) {
@@ -223,7 +236,9 @@ __global__ __launch_bounds__(kWT) void mmtrssm_wide_fwd_kernel(const MmtWideFwdA
         lds_barrier();
       }
       cur ^= 1;
+      MTRSSM_MMT_STAMP(3);
       if (!bar.sync(2 + 4 * t)) return;
+      MTRSSM_MMT_STAMP(4);
 
       // ============ F2: layer 0 of the five heads on [d_l | d_h] ============
       for (int u = blk; u < 5 * G.NTHP; u += nblk) {
@@ -260,7 +275,9 @@ __global__ __launch_bounds__(kWT) void mmtrssm_wide_fwd_kernel(const MmtWideFwdA
         }
         lds_barrier();
       }
+      MTRSSM_MMT_STAMP(5);
       if (!bar.sync(3 + 4 * t)) return;
+      MTRSSM_MMT_STAMP(6);
 
       // ============ F3: layer 1 of the five heads: lpl | la | lv | lqh | lph ============
       {
@@ -286,7 +303,9 @@ __global__ __launch_bounds__(kWT) void mmtrssm_wide_fwd_kernel(const MmtWideFwdA
           lds_barrier();
         }
       }
+      MTRSSM_MMT_STAMP(7);
       if (!bar.sync(4 + 4 * t)) return;
+      MTRSSM_MMT_STAMP(8);
     }
     if (!bar.sync(0x40000000)) return;   // the next tile's set-up overwrites the exchange vectors
   }
@@ -342,8 +361,11 @@ __global__ __launch_bounds__(kWT) void mmtrssm_wide_bwd_kernel(const MmtWideBwdA
     const bool e_valid = e_row < nrows;
     const size_t e_b = (size_t)(rb + (e_valid ? e_row : 0));
     float c_d[4] = {0.f, 0.f, 0.f, 0.f}, c_hid[4] = {0.f, 0.f, 0.f, 0.f};   // carries of the deter units this workgroup owns (R2, R3)
+    unsigned long long* const prof = (tid == 0 && rb == 0) ? g_mmt_prof : nullptr;
 
     for (int t = T - 1; t >= 0; --t) {
+      const int tstamp = T - 1 - t;
+      MTRSSM_MMT_STAMP(0);
       // ============ R0: categorical blocks + MoPoE mix backward, one workgroup per batch row ============
       for (int r = nblk - 1 - blk; r < nrows; r += nblk) {
         const size_t q = (size_t)(rb + r) * T + t;
@@ -361,19 +383,23 @@ __global__ __launch_bounds__(kWT) void mmtrssm_wide_bwd_kernel(const MmtWideBwdA
         }
         for (int s2 = tid; s2 < LS + HS; s2 += kWT) Lcs[s2] = t == T - 1 ? 0.f : wide_load_f(a.cs + (size_t)r * LSHp + s2);
         lds_barrier();
-        if (wave == 0) {
-          const float gkl = io.g_kl_l ? io.g_kl_l[q] : 0.f, gkh = io.g_kl_h ? io.g_kl_h[q] : 0.f;
+        MTRSSM_MMT_STAMP(10);
+        if (wave == 0) {   // lower level: categorical block, then the MoPoE mix backward
+          const float gkl = io.g_kl_l ? io.g_kl_l[q] : 0.f;
           const float* gpsl = io.g_prior_stoch_l ? io.g_prior_stoch_l + q * LS : nullptr;
           const float* gpll = io.g_post_logits_l ? io.g_post_logits_l + q * LS : nullptr;
           const float* gprl = io.g_prior_logits_l ? io.g_prior_logits_l + q * LS : nullptr;
+          if (CL <= 8) cat_block_bwd_fast8(Lmx, Llpl, KL, CL, lane, Lgps, Lcs, gpsl, gpll, gprl, gkl, a.dm.kl_w_post, a.dm.kl_w_prior, Ldmx, Ldlpl);
+          else cat_block_bwd<true>(Lmx, Llpl, KL, CL, lane, Lgps, Lcs, gpsl, gpll, gprl, gkl, a.dm.kl_w_post, a.dm.kl_w_prior, Ldmx, Ldlpl);
+          wave_mopoe_mix_bwd<true>(Lla, Llv, Lmx, Ldmx, Ldla, Ldlv, LS, lane);
+          MTRSSM_MMT_STAMP(11);
+        } else if (wave == 1) {   // higher level, beside it on another SIMD
+          const float gkh = io.g_kl_h ? io.g_kl_h[q] : 0.f;
           const float* gpsh = io.g_prior_stoch_h ? io.g_prior_stoch_h + q * HS : nullptr;
           const float* gplh = io.g_post_logits_h ? io.g_post_logits_h + q * HS : nullptr;
           const float* gprh = io.g_prior_logits_h ? io.g_prior_logits_h + q * HS : nullptr;
-          if (CL <= 8) cat_block_bwd_fast8(Lmx, Llpl, KL, CL, lane, Lgps, Lcs, gpsl, gpll, gprl, gkl, a.dm.kl_w_post, a.dm.kl_w_prior, Ldmx, Ldlpl);
-          else cat_block_bwd<true>(Lmx, Llpl, KL, CL, lane, Lgps, Lcs, gpsl, gpll, gprl, gkl, a.dm.kl_w_post, a.dm.kl_w_prior, Ldmx, Ldlpl);
           if (CH <= 8) cat_block_bwd_fast8(Llqh, Llph, KH, CH, lane, Lgps + LS, Lcs + LS, gpsh, gplh, gprh, gkh, a.dm.kl_w_post, a.dm.kl_w_prior, Ldlqh, Ldlph);
           else cat_block_bwd<true>(Llqh, Llph, KH, CH, lane, Lgps + LS, Lcs + LS, gpsh, gplh, gprh, gkh, a.dm.kl_w_post, a.dm.kl_w_prior, Ldlqh, Ldlph);
-          wave_mopoe_mix_bwd<true>(Lla, Llv, Lmx, Ldmx, Ldla, Ldlv, LS, lane);
         }
         lds_barrier();
         // outputs and exchange vectors: lpl, la, lv (K = LS), lqh, lph (K = HS)
@@ -394,7 +420,9 @@ __global__ __launch_bounds__(kWT) void mmtrssm_wide_bwd_kernel(const MmtWideBwdA
         }
         lds_barrier();
       }
+      MTRSSM_MMT_STAMP(1);
       if (!bar.sync(1 + 4 * t)) return;
+      MTRSSM_MMT_STAMP(2);
 
       // ============ R1: pre-activation gradients of layer 0: dz = act'(h) * (W2nd^T dl), five heads ============
       for (int u = blk; u < 5 * G.NTHP; u += nblk) {
@@ -426,7 +454,9 @@ __global__ __launch_bounds__(kWT) void mmtrssm_wide_bwd_kernel(const MmtWideBwdA
         }
         lds_barrier();
       }
+      MTRSSM_MMT_STAMP(3);
       if (!bar.sync(2 + 4 * t)) return;
+      MTRSSM_MMT_STAMP(4);
 
       // ============ R2: gradients at d_l / d_h, through tanh into the leaky integrators ============
       for (int u = blk; u < G.NTL + G.NTHd; u += nblk) {
@@ -471,7 +501,9 @@ __global__ __launch_bounds__(kWT) void mmtrssm_wide_bwd_kernel(const MmtWideBwdA
         }
         lds_barrier();
       }
+      MTRSSM_MMT_STAMP(5);
       if (!bar.sync(3 + 4 * t)) return;
+      MTRSSM_MMT_STAMP(6);
 
       // ============ R3: carries into step t-1: W_d^T du (kept by the workgroups of R2) | W_x^T du -> [s_l ; s_h] ============
       for (int u = blk; u < G.NTL + G.NTHd + NTS; u += nblk) {
@@ -515,7 +547,9 @@ __global__ __launch_bounds__(kWT) void mmtrssm_wide_bwd_kernel(const MmtWideBwdA
         }
         lds_barrier();
       }
+      MTRSSM_MMT_STAMP(7);
       if (!bar.sync(4 + 4 * t)) return;
+      MTRSSM_MMT_STAMP(8);
     }
   }
 }
@@ -523,6 +557,11 @@ __global__ __launch_bounds__(kWT) void mmtrssm_wide_bwd_kernel(const MmtWideBwdA
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+int debug_set_mmt_profile(void* buf) {
+  unsigned long long* p = static_cast<unsigned long long*>(buf);
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_mmt_prof), &p, sizeof(p)) == hipSuccess ? MTRSSM_OK : MTRSSM_ELAUNCH;
+}
+
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static bool mmt_wide_dims_ok(const MtrssmMmtrssmDims* d) {
