@@ -32,6 +32,7 @@ from torch import Tensor, nn
 from multimodal_mtrssm_amd import _lib
 from multimodal_mtrssm_amd.linear import linear
 from multimodal_mtrssm_amd.conv import (
+    gemm_pieces,
     conv2d,
     conv2d_pair,
     conv_transpose2d,
@@ -215,7 +216,7 @@ class Encoder(nn.Module):
         # "act -> flatten -> Linear [-> act -> Linear ...]": every activation rides in the following GEMM's operand staging
         x = x.flatten(start_dim=1)
         for lin in self.linears:
-            x = linear(x, lin.weight, lin.bias, pre_act=self.act_id)
+            x = linear(x, lin.weight, lin.bias, pre_act=self.act_id, pieces=gemm_pieces())
         return self.out_act(x).reshape(*lead, -1)
 
 
@@ -269,7 +270,7 @@ class Decoder(nn.Module):
             self.to(f.device)
         x = f.reshape(-1, f.shape[-1])
         for i, lin in enumerate(self.linears):
-            x = linear(x, lin.weight, lin.bias, pre_act=self.act_id if i > 0 else 0)
+            x = linear(x, lin.weight, lin.bias, pre_act=self.act_id if i > 0 else 0, pieces=gemm_pieces())
         return x.reshape(-1, *self.conv_in_shape)
 
     def tail(self, x: Tensor, lead: torch.Size, *, raw: bool = False) -> Tensor:

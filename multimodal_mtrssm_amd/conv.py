@@ -181,6 +181,12 @@ def mfma_mode() -> str:
     return next(k for k, v in MFMA_MODES.items() if v == _MFMA_SPLIT)
 
 
+def gemm_pieces() -> int:
+    """bf16 pieces per operand for the large Linear layers INSIDE the conv stacks (cnn.Encoder head, cnn.Decoder stem): the
+    arithmetic of the convolutions around them (``bf16x2`` -> 2, ``bf16x3`` -> 3, ``f32`` -> 0 = fp32 MFMA, ``bf16`` -> 2)."""
+    return {0: 0, 3: 3, 2: 2, 1: 2}[_MFMA_SPLIT]
+
+
 def _geom(**kw: int) -> C.Structure:
     g = _lib.ConvGeom()
     for k, v in kw.items():

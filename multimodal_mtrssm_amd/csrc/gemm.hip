@@ -15,12 +15,15 @@
 //     weight   dW = dY^T X      : A = dY read as A'(n, m),      B = X read as B'(k, m)           (both r-major)
 // Workgroup tile 64 x 64, four waves of one 32 x 32 accumulator each, reduction in steps of 32 through double-buffered LDS
 // (operand rows padded to 33 floats, r-major images to 96: conflict-free ds_read_b32 for the two k halves of a wave).
+#include <cstdlib>
+
 #include "scan_common.h"
 
 namespace mtrssm {
 
 void set_error(const char* fmt, ...);
 void set_last_kernel(const char* name);
+int device_cu_count();
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
@@ -578,6 +581,20 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs g) {
   if (colsum_now) atomicAdd(g.colsum + i0 + tid, csum);
 }
 
+}  // namespace mtrssm
+#include "gemm_tile.h"
+namespace mtrssm {
+
+// 0 = the tile kernel (gemm_tile.h) does not take this problem; else its column tile (128 or 64)
+static int tile_kernel_columns(const MtrssmGemm* p) {
+  if (p->mfma_split != 2 && p->mfma_split != 3) return 0;
+  if (p->M % kGM || p->R % kGK || p->R < kGK) return 0;
+  if ((!p->a_rmajor && ((p->lda & 3) || ((uintptr_t)p->A & 15))) || (!p->b_rmajor && ((p->ldb & 3) || ((uintptr_t)p->B & 15)))) return 0;
+  if (p->N % 128 == 0) return 128;
+  if (p->N % 64 == 0) return 64;
+  return 0;
+}
+
 // Validation, split choice and the clears a problem needs before its kernel; fills `g`, the grid and whether the FAST
 // (full-tile) instantiation applies.
 static int gemm_prepare(const MtrssmGemm* p, GemmArgs& g, dim3& grid, bool& fast, hipStream_t stream, int fill_target = 768) {
@@ -600,12 +617,13 @@ static int gemm_prepare(const MtrssmGemm* p, GemmArgs& g, dim3& grid, bool& fast
   g.M = p->M; g.N = p->N; g.R = p->R; g.lda = p->lda; g.ldb = p->ldb; g.ldc = p->ldc; g.ldz = p->ldz;
   g.a_rmajor = p->a_rmajor; g.b_rmajor = p->b_rmajor; g.act_a = p->act_a; g.act_b = p->act_b; g.act_out = p->act_out;
   g.act_z = p->act_z; g.accumulate = p->accumulate;
-  if (p->mfma_split != 0 && p->mfma_split != 2) {
-    set_error("gemm: mfma_split must be 0 (fp32 MFMA) or 2 (two bf16 pieces), got %d", p->mfma_split);
+  if (p->mfma_split != 0 && p->mfma_split != 2 && p->mfma_split != 3) {
+    set_error("gemm: mfma_split must be 0 (fp32 MFMA), 2 or 3 (bf16 pieces per operand), got %d", p->mfma_split);
     return MTRSSM_EINVAL;
   }
-  const bool split_mfma = p->mfma_split == 2;
-  const int tile_m = split_mfma ? kSM : kTile, tile_n = split_mfma ? kSN : kTile;
+  const int tile_cols = tile_kernel_columns(p);
+  const bool split_mfma = p->mfma_split == 2 && !tile_cols;   // the older 128 x 64 split kernel: ragged shapes at two pieces
+  const int tile_m = tile_cols ? kGM : (split_mfma ? kSM : kTile), tile_n = tile_cols ? tile_cols : (split_mfma ? kSN : kTile);
   const int ti = (p->M + tile_m - 1) / tile_m, tj = (p->N + tile_n - 1) / tile_n;
   int splits = p->split_r;
   const int steps = (p->R + kStep - 1) / kStep;
@@ -619,8 +637,9 @@ static int gemm_prepare(const MtrssmGemm* p, GemmArgs& g, dim3& grid, bool& fast
     // gradient) then needs the ticket words for its last-arriver pass.
     splits = 1;
     if ((plain_epilogue && (p->accumulate || dense_c)) || (!plain_epilogue && can_finalize))
-      while (ti * tj * splits < fill_target && steps / (splits * 2) >= 4) splits *= 2;
+      while (ti * tj * splits < (tile_cols ? 200 : fill_target) && steps / (splits * 2) >= 4) splits *= 2;
   }
+  while (splits > 1 && (splits - 1) * ((steps + splits - 1) / splits) >= steps) --splits;   // no empty slice: each one takes a ticket
   bool finalize = false;
   if (splits > 1 && !plain_epilogue) {
     if (!can_finalize) {
@@ -642,7 +661,7 @@ static int gemm_prepare(const MtrssmGemm* p, GemmArgs& g, dim3& grid, bool& fast
   g.splits = splits;
   grid = dim3(tj, ti, splits);
   const int per_slice = (steps + splits - 1) / splits;
-  fast = !split_mfma && p->M % kTile == 0 && p->N % kTile == 0 && p->R % kStep == 0 && steps % splits == 0 && per_slice >= 1 &&
+  fast = !split_mfma && !tile_cols && p->M % kTile == 0 && p->N % kTile == 0 && p->R % kStep == 0 && steps % splits == 0 && per_slice >= 1 &&
          (p->lda & 3) == 0 && (p->ldb & 3) == 0 && ((uintptr_t)p->A & 15) == 0 && ((uintptr_t)p->B & 15) == 0;
   return MTRSSM_OK;
 }
@@ -652,7 +671,27 @@ int gemm_launch(const MtrssmGemm* p, hipStream_t stream) {
   dim3 grid;
   bool fast = false;
   if (int rc = gemm_prepare(p, g, grid, fast, stream)) return rc;
-  if (p->mfma_split == 2) {
+  if (const int tn = tile_kernel_columns(p)) {
+    const size_t lds_bytes = 2 * (size_t)p->mfma_split * (kGM + tn) * kGPitch;   // two buffers of P pieces of both operand images
+#define MTRSSM_GEMM_TILE(AR_, BR_, P_, TN_)                                                                            \
+  {                                                                                                                   \
+    auto kern = gemm_tile_kernel<AR_, BR_, P_, TN_>;                                                                   \
+    if (lds_bytes > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+    set_last_kernel("mtrssm::gemm_tile_kernel<" #AR_ ", " #BR_ ", " #P_ ", " #TN_ ">");                                \
+    hipLaunchKernelGGL(kern, dim3(grid.x * grid.y * grid.z), dim3(512), lds_bytes, stream, g);                        \
+  }
+#define MTRSSM_GEMM_TILE_PT(AR_, BR_)                                                                                 \
+  {                                                                                                                   \
+    if (p->mfma_split == 3) { if (tn == 128) MTRSSM_GEMM_TILE(AR_, BR_, 3, 128) else MTRSSM_GEMM_TILE(AR_, BR_, 3, 64) } \
+    else { if (tn == 128) MTRSSM_GEMM_TILE(AR_, BR_, 2, 128) else MTRSSM_GEMM_TILE(AR_, BR_, 2, 64) }                 \
+  }
+    if (p->a_rmajor && p->b_rmajor) MTRSSM_GEMM_TILE_PT(true, true)
+    else if (!p->a_rmajor && p->b_rmajor) MTRSSM_GEMM_TILE_PT(false, true)
+    else if (!p->a_rmajor && !p->b_rmajor) MTRSSM_GEMM_TILE_PT(false, false)
+    else MTRSSM_GEMM_TILE_PT(true, false)
+#undef MTRSSM_GEMM_TILE_PT
+#undef MTRSSM_GEMM_TILE
+  } else if (p->mfma_split == 2) {
     if (p->a_rmajor && p->b_rmajor) {
       set_last_kernel("mtrssm::gemm_split_kernel<true, true>");
       hipLaunchKernelGGL((gemm_split_kernel<true, true>), grid, dim3(256), 0, stream, g);
@@ -725,7 +764,10 @@ int gemm_group_launch(const MtrssmGemm* ps, int count, hipStream_t stream) {
     for (int i = 0; i < count; ++i) {
       const MtrssmGemm* p = ps + i;
       if ((p->a_rmajor != 0) != (ar != 0) || (p->b_rmajor != 0) != (br != 0)) continue;
-      if (p->mfma_split != 0) { set_error("gemm_group: fp32 MFMA problems only (mfma_split = 0)"); return MTRSSM_EINVAL; }
+      if (p->mfma_split != 0 && !(p->mfma_split == 3 && !tile_kernel_columns(p))) {
+        set_error("gemm_group: problems of the fp32 MFMA kernel only (mfma_split = 0, or 3 on a shape the tile kernel does not take)");
+        return MTRSSM_EINVAL;
+      }
       GemmArgs g;
       dim3 grid;
       bool fast = false;

@@ -83,12 +83,14 @@ def _ld(t: Tensor) -> int:
     return int(t.stride(0)) if t.shape[0] > 1 else max(int(t.stride(0)), int(t.shape[1]))
 
 
-# MFMA operand format of the LARGE GEMMs (>= SPLIT_MIN_FLOPS: the Linear layers inside the conv stacks, cnn.Encoder.head /
-# cnn.Decoder.stem and their gradients): 0 = fp32 MFMA (default); 2 = two bf16 pieces per fp32 operand, the conv kernels'
-# default arithmetic (gemm_split_kernel).  The split kernel is tested and NOT faster (both kernels are
-# bound by the load round trip per k-step, not by the MFMA pipe), so it stays off.  Everything smaller -- the scan's
-# projections, init_proj, the prior head, the scan's weight gradients -- always runs the fp32 MFMA kernel.
-SPLIT_PIECES = 0
+# MFMA operand format of the LARGE GEMMs (>= SPLIT_MIN_FLOPS) when the caller does not say: 3 = every fp32 operand as three bf16
+# pieces, six bf16 MFMA products, fp32 accumulation (exact to 2^-24: fp32-grade) on the 128 x {128, 64}-tile kernel of
+# csrc/gemm_tile.h where the shape is made of full tiles, else the fp32 MFMA kernel; 2 = two pieces, three products (16
+# significant bits: what the Linear layers INSIDE the conv stacks use, like the convolutions around them -- cnn.py passes
+# ``pieces=conv.gemm_pieces()``); 0 = fp32 MFMA always.  Everything smaller -- the scan's projections at the base dims, init_proj,
+# the prior head, the small weight gradients -- runs the fp32 MFMA kernel (latency-bound launches: the operand format is not
+# what they wait for).
+SPLIT_PIECES = 3
 SPLIT_MIN_FLOPS = 5.0e8
 
 
@@ -179,7 +181,7 @@ def gemm_group(problems: list[tuple[tuple[Tensor, Tensor, Tensor], dict]]) -> No
         for members in rounds:
             gemm_group(members)
         return
-    built = [_problem(a, b, c, mfma_split=0, **kw) for (a, b, c), kw in problems]
+    built = [_problem(a, b, c, **{**kw, "mfma_split": 0}) for (a, b, c), kw in problems]
     arr = (_lib.Gemm * len(built))(*[g for g, _, _ in built])
     dev = problems[0][0][0].device
     lib = _lib.load()
@@ -225,7 +227,7 @@ class _DeferredWeightGrads:
 
 
 DEFER_WEIGHT_GRADS = True
-GROUP_MAX_FLOPS = 4.0e9  # per problem (2 M N R): above it a GEMM is a chip-filling launch of its own
+GROUP_MAX_FLOPS = 1.0e9  # per problem (2 M N R): above it a GEMM is a chip-filling launch of its own (on the tile kernel)
 _DEFERRED = _DeferredWeightGrads()
 
 
@@ -238,8 +240,13 @@ def discard_deferred() -> None:
     _DEFERRED.discard()
 
 
+def _pick(pieces: int | None, m: int, n: int, r: int) -> int | None:
+    """A layer's operand format applies to its LARGE GEMMs only (None = the module default, decided in ``_problem``)."""
+    return None if pieces is None else (int(pieces) if 2.0 * m * n * r >= SPLIT_MIN_FLOPS else 0)
+
+
 def weight_grad(gy: Tensor, x: Tensor, weight: Tensor, bias: Tensor | None, *, act_x: int = 0, want_weight: bool = True,
-                want_bias: bool = True) -> tuple[Tensor | None, Tensor | None]:
+                want_bias: bool = True, pieces: int | None = None) -> tuple[Tensor | None, Tensor | None]:
     """``dW = gy^T act(x)`` (``[N, K]``), ``db = column sums of gy`` for ``y = act(x) W^T + b`` with ``gy [M, N]``, ``x [M, K]``.
     Accumulated into the flat gradient buffer when ``weight`` / ``bias`` live in one (then None is returned for that
     tensor), else returned.  One launch for both."""
@@ -254,7 +261,8 @@ def weight_grad(gy: Tensor, x: Tensor, weight: Tensor, bias: Tensor | None, *, a
         if gb is None:
             gb = gb_ret = torch.zeros(bias.shape, device=gy.device, dtype=torch.float32)
     if want_weight:
-        problem = ((gy, x, gw), dict(a_rmajor=True, b_rmajor=True, act_b=act_x, colsum=gb, accumulate=True))
+        problem = ((gy, x, gw), dict(a_rmajor=True, b_rmajor=True, act_b=act_x, colsum=gb, accumulate=True,
+                                     mfma_split=_pick(pieces, gy.shape[1], x.shape[1], gy.shape[0])))
         sunk = gw_ret is None and gb_ret is None  # nothing is handed back to autograd: the launch can wait for the end of the pass
         if not (DEFER_WEIGHT_GRADS and sunk and _DEFERRED.add(problem)):
             gemm(gy, x, gw, **problem[1])
@@ -265,16 +273,17 @@ def weight_grad(gy: Tensor, x: Tensor, weight: Tensor, bias: Tensor | None, *, a
 
 class _Linear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x: Tensor, weight: Tensor, bias: Tensor | None, pre_act: int) -> Tensor:  # noqa: ANN001
+    def forward(ctx, x: Tensor, weight: Tensor, bias: Tensor | None, pre_act: int, pieces: int | None) -> Tensor:  # noqa: ANN001
         lead = x.shape[:-1]
         x2 = x.reshape(-1, x.shape[-1])
         if x2.stride(1) != 1:
             x2 = x2.contiguous()
         w = weight if weight.stride(1) == 1 else weight.contiguous()
         y = torch.empty(x2.shape[0], w.shape[0], device=x.device, dtype=torch.float32)
-        gemm(x2, w, y, a_rmajor=False, b_rmajor=False, bias=None if bias is None else bias.contiguous(), act_a=pre_act)
+        gemm(x2, w, y, a_rmajor=False, b_rmajor=False, bias=None if bias is None else bias.contiguous(), act_a=pre_act,
+             mfma_split=_pick(pieces, x2.shape[0], w.shape[0], x2.shape[1]))
         ctx.save_for_backward(x2, weight, bias if bias is not None else x2.new_zeros(0))
-        ctx.pre_act, ctx.has_bias, ctx.lead = pre_act, bias is not None, lead
+        ctx.pre_act, ctx.has_bias, ctx.lead, ctx.pieces = pre_act, bias is not None, lead, pieces
         return y.reshape(*lead, w.shape[0])
 
     @staticmethod
@@ -288,13 +297,15 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             w = weight if weight.stride(1) == 1 else weight.contiguous()
             gx = torch.empty_like(x2)
-            gemm(gy2, w, gx, a_rmajor=False, b_rmajor=True, zgrad=x2 if ctx.pre_act else None, act_z=ctx.pre_act)
+            gemm(gy2, w, gx, a_rmajor=False, b_rmajor=True, zgrad=x2 if ctx.pre_act else None, act_z=ctx.pre_act,
+                 mfma_split=_pick(ctx.pieces, gy2.shape[0], x2.shape[1], gy2.shape[1]))
             gx = gx.reshape(*ctx.lead, x2.shape[1])
         gw, gb = weight_grad(gy2, x2, weight, bias, act_x=ctx.pre_act, want_weight=ctx.needs_input_grad[1],
-                             want_bias=ctx.has_bias and ctx.needs_input_grad[2])
-        return gx, gw, gb, None
+                             want_bias=ctx.has_bias and ctx.needs_input_grad[2], pieces=ctx.pieces)
+        return gx, gw, gb, None, None
 
 
-def linear(x: Tensor, weight: Tensor, bias: Tensor | None = None, *, pre_act: int = 0) -> Tensor:
-    """``F.linear(act(x), weight, bias)`` over any leading dims, on the fp32-MFMA GEMM; GPU tensors only (no fallback)."""
-    return _Linear.apply(x, weight, bias, int(pre_act))
+def linear(x: Tensor, weight: Tensor, bias: Tensor | None = None, *, pre_act: int = 0, pieces: int | None = None) -> Tensor:
+    """``F.linear(act(x), weight, bias)`` over any leading dims, on the hand-written GEMMs; GPU tensors only (no fallback).
+    ``pieces``: MFMA operand format of this layer's three GEMMs when they are large (None = ``SPLIT_PIECES``)."""
+    return _Linear.apply(x, weight, bias, int(pre_act), pieces)

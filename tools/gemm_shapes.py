@@ -28,7 +28,7 @@ for name, m, n, r, a_rm, b_rm, acc in (base if which == "base" else large):
     b = torch.randn((r, n) if b_rm else (n, r), device=dev)
     c = torch.zeros(m, n, device=dev)
     row = []
-    for pieces in (0, 2):
+    for pieces in (0, 2, 3):
         for _ in range(3):
             gemm(a, b, c, a_rmajor=bool(a_rm), b_rmajor=bool(b_rm), mfma_split=pieces, accumulate=bool(acc))
         torch.cuda.synchronize()
