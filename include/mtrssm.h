@@ -471,7 +471,9 @@ int mtrssm_pack_conv_weight(const float* w, int32_t O, int32_t I, int32_t KH, in
                             int64_t sw, int32_t OPad, int32_t IPad, int32_t pieces, float* wp, uint16_t* wq, void* stream);
 /* The same for `count` weights in one launch (the train step packs every conv weight once, in both the forward and the
  * backward-data layout, right after the optimizer changed them).  `table` is DEVICE memory: MTRSSM_PACK_DESC_WORDS int64 words
- * per weight = { w, wp, wq (addresses), O, I, KH, KW, so, si, sh, sw, OPad, IPad, pieces, 0, 0 } with the meanings above;
+ * per weight = { w, wp, wq (addresses), O, I, KH, KW, so, si, sh, sw, OPad, IPad, pieces, VH, VW } with the meanings above;
+ * VH, VW > 0: the view holds only the leading VH x VW taps of the KH x KW tap grid, the rest are packed as zeros (the
+ * parity-class sub-kernels of a 3 x 3 kernel run as a zero-padded 4 x 4 transposed convolution); 0, 0: every tap.
  * blocks_per_weight workgroups of 256 threads stride over each weight. */
 #define MTRSSM_PACK_DESC_WORDS 16
 int mtrssm_pack_conv_weights(const int64_t* table, int32_t count, int32_t blocks_per_weight, void* stream);

@@ -41,15 +41,31 @@ PAIR_LAUNCH = os.environ.get("MTRSSM_PAIR_LAUNCH", "1") != "0"
 _DEFER: list[tuple] | None = None
 
 
-def _pack_buffers(w: Tensor) -> tuple[Tensor, Tensor | None]:
+def _pack_buffers(w: Tensor, grid: tuple[int, int] | None = None) -> tuple[Tensor, Tensor | None]:
     o, i, kh, kw = w.shape
+    if grid is not None:
+        kh, kw = grid
     opad, ipad = _pads(o, i)
     wp = torch.zeros(opad, kh * kw, ipad, device=w.device, dtype=torch.float32)
     wq = torch.zeros(_MFMA_SPLIT, opad, kh * kw, ipad, device=w.device, dtype=torch.int16) if _MFMA_SPLIT else None
     return wp, wq
 
 
-def _pack_now(w: Tensor, wp: Tensor, wq: Tensor | None) -> None:
+def _pack_row(w: Tensor, wp: Tensor, wq: Tensor | None, grid: tuple[int, int] | None) -> list[int]:
+    """One descriptor of ``mtrssm_pack_conv_weights`` (include/mtrssm.h: MTRSSM_PACK_DESC_WORDS)."""
+    o, i, kh, kw = w.shape
+    gh, gw = grid if grid is not None else (kh, kw)
+    return [w.data_ptr(), wp.data_ptr(), 0 if wq is None else wq.data_ptr(), o, i, gh, gw, *w.stride(), wp.shape[0], wp.shape[2],
+            0 if wq is None else wq.shape[0], kh if grid is not None else 0, kw if grid is not None else 0]
+
+
+def _pack_now(w: Tensor, wp: Tensor, wq: Tensor | None, grid: tuple[int, int] | None = None) -> None:
+    if grid is not None and tuple(grid) != tuple(w.shape[2:]):
+        # a view that fills only the leading taps of its tap grid: the table entry describes it (rare: outside a step's plan)
+        table = torch.tensor([_pack_row(w, wp, wq, grid)], dtype=torch.int64).to(w.device)
+        _lib.check(_lib.TIMERS.call("mtrssm_pack_conv_weights", _lib.load().mtrssm_pack_conv_weights, _lib.raw_ptr(table), 1, 8,
+                                    _lib.stream_ptr(w.device)), "mtrssm_pack_conv_weights")
+        return
     o, i, kh, kw = w.shape
     so, si, sh, sw = w.stride()
     _lib.check(_lib.TIMERS.call("mtrssm_pack_conv_weight", _lib.load().mtrssm_pack_conv_weight, _lib.raw_ptr(w), o, i, kh, kw, so, si,
@@ -67,7 +83,7 @@ class _PackPlan:
     epoch (``.data`` has its own version counter) -- call ``invalidate_packs()`` after such an edit."""
 
     def __init__(self) -> None:
-        # key -> [w (strong ref: keeps the address valid), wp, wq, version, epoch packed, epoch used, serial]
+        # key -> [w (strong ref: keeps the address valid), wp, wq, version, epoch packed, epoch used, serial, tap grid]
         self.entries: dict[tuple, list] = {}
         self.epoch = 0
         self.step_epoch = -1  # the epoch begin_step opened; after invalidate() nothing is trusted until the next begin_step
@@ -81,8 +97,8 @@ class _PackPlan:
         self.epoch += 1
 
     @staticmethod
-    def key(w: Tensor) -> tuple:
-        return (w.data_ptr(), tuple(w.shape), w.stride(), _MFMA_SPLIT, w.device)
+    def key(w: Tensor, grid: tuple[int, int] | None = None) -> tuple:
+        return (w.data_ptr(), tuple(w.shape), w.stride(), _MFMA_SPLIT, w.device, grid)
 
     def begin_step(self, device: torch.device) -> None:
         self.epoch += 1
@@ -96,11 +112,7 @@ class _PackPlan:
             return
         serials = tuple(e[6] for _, e in live)
         if serials != self.table_serials or self.table is None or self.table.device != device:
-            rows = []
-            for _, (w, wp, wq, *_rest) in live:
-                o, i, kh, kw = w.shape
-                rows.append([w.data_ptr(), wp.data_ptr(), 0 if wq is None else wq.data_ptr(), o, i, kh, kw, *w.stride(), wp.shape[0],
-                             wp.shape[2], 0 if wq is None else wq.shape[0], 0, 0])
+            rows = [_pack_row(e[0], e[1], e[2], e[7]) for _, e in live]
             self.table = torch.tensor(rows, dtype=torch.int64).to(device)
             self.table_serials = serials
         _lib.check(_lib.TIMERS.call("mtrssm_pack_conv_weights", _lib.load().mtrssm_pack_conv_weights, _lib.raw_ptr(self.table), len(live),
@@ -108,14 +120,14 @@ class _PackPlan:
         for _, e in live:
             e[3], e[4] = e[0]._version, self.epoch
 
-    def get(self, w: Tensor) -> tuple[Tensor, Tensor | None]:
-        k = self.key(w)
+    def get(self, w: Tensor, grid: tuple[int, int] | None = None) -> tuple[Tensor, Tensor | None]:
+        k = self.key(w, grid)
         e = self.entries.get(k)
         if e is None:
             self.serial += 1
-            e = self.entries[k] = [w, *_pack_buffers(w), -1, -1, self.epoch, self.serial]
+            e = self.entries[k] = [w, *_pack_buffers(w, grid), -1, -1, self.epoch, self.serial, grid]
         if e[4] != self.epoch or e[3] != w._version or self.epoch != self.step_epoch:
-            _pack_now(w, e[1], e[2])
+            _pack_now(w, e[1], e[2], grid)
             e[3], e[4] = w._version, self.epoch
         e[5] = self.epoch
         return e[1], e[2]
@@ -137,24 +149,27 @@ def invalidate_packs() -> None:
     _PLAN.invalidate()
 
 
-def pack_weight(w: Tensor, sub: int = 0) -> tuple[Tensor, Tensor | None]:
+def pack_weight(w: Tensor, sub: int = 0, grid: tuple[int, int] | None = None) -> tuple[Tensor, Tensor | None]:
     """``w[O][I][kh][kw]`` (any strided view) -> zero-padded fp32 ``wp[OPad][kh*kw][IPad]`` (channel fastest) and, in a
-    bf16 MFMA mode, its bf16 pieces ``wq[pieces][OPad][kh*kw][IPad]`` (``mtrssm_pack_conv_weight``).
+    bf16 MFMA mode, its bf16 pieces ``wq[pieces][OPad][kh*kw][IPad]`` (``mtrssm_pack_conv_weight``).  ``grid = (KH, KW)``:
+    the view holds the leading ``kh x kw`` taps of a ``KH x KW`` tap grid whose other taps are zeros.
 
     Inside a step announced by ``begin_step`` the copies come from the step's one pack launch (``_PackPlan``).  Otherwise
     the buffers are cached per (shape, device, stream): every use is "pack, then enqueue the kernel that reads it" on one
     stream, so a later pack of another same-shaped layer cannot overtake the earlier kernel.
     """
     o, i, kh, kw = w.shape
+    if grid is not None and tuple(grid) == (kh, kw):
+        grid = None
     if PACK_PLAN and w.is_cuda and kh * kw > 0 and torch.cuda.current_stream(w.device).cuda_stream == _PLAN.stream:
-        return _PLAN.get(w)
+        return _PLAN.get(w, grid)
     slot = len(_DEFER) if _DEFER is not None else 0  # deferred (paired) launches: one buffer per pending job
-    key = (o, i, kh, kw, _MFMA_SPLIT, slot, sub, w.device, torch.cuda.current_stream(w.device).cuda_stream if w.is_cuda else 0)
+    key = (o, i, kh, kw, grid, _MFMA_SPLIT, slot, sub, w.device, torch.cuda.current_stream(w.device).cuda_stream if w.is_cuda else 0)
     bufs = _PACK_BUFFERS.get(key)  # (`sub`: same-shaped weights packed for ONE pending launch, e.g. the four parity sub-kernels)
     if bufs is None:
-        bufs = _PACK_BUFFERS[key] = _pack_buffers(w)
+        bufs = _PACK_BUFFERS[key] = _pack_buffers(w, grid)
     if kh * kw > 0:
-        _pack_now(w, *bufs)
+        _pack_now(w, *bufs, grid)
     return bufs
 
 
@@ -335,24 +350,23 @@ def _conv_transposed_gather(y: Tensor, w: Tensor, bias: Tensor | None, stride: i
             nbytes=4.0 * (y.numel() + out.numel())), "mtrssm_convt_k4s2_thin")
         return out
     quad_fwd = kh == 4 and kw == 4 and actgrad_in is None and (o, c, hs * ws) in ((64, 32, 64), (32, 16, 256))  # noqa: PLR2004
-    # The same kernel takes the backward-data of a Conv2d(k = 3, s = 2, p = 1) with its kernel zero-padded to 4 x 4 (the encoders'
-    # third conv: 4 x 60 -> 88 us).  OFF by default: the padded weight is a new tensor every step, which the step's pack plan
-    # cannot learn (it rebuilt its table -- a host-to-device copy -- every step, which also breaks graph capture) and the extra
-    # pad / pack launches ate the gain.  Needs a pack descriptor with "valid taps" instead of a padded copy.
+    # The same kernel takes the backward-data of a Conv2d(k = 3, s = 2, p = 1) as the transposed convolution of its kernel
+    # zero-padded to 4 x 4 (the encoders' third conv: 4 paired launches of ~54 us -> one of ~90): the parity-class sub-kernels
+    # are strided views of the PARAMETER with 2 x 2, 2 x 1, 1 x 2 and 1 x 1 taps, packed into a 2 x 2 tap grid (`grid`), so the
+    # step's pack plan learns them like every other weight view.
     quad_bwd = (CONVT_QUAD_BWD and kh == 3 and kw == 3 and actgrad_in is not None and bias is None  # noqa: PLR2004
                 and (o, c, hs * ws) == (32, 16, 64))
     if (stride == 2 and pad == 1 and (ho, wo) == (2 * hs, 2 * ws) and add_in is None and _MFMA_SPLIT == 2 and CONVT_QUAD  # noqa: PLR2004
             and (quad_fwd or quad_bwd)):
         # the decoders' ConvTranspose layers (and the backward-data of the encoders' third conv = the same transposed conv with
         # its 3 x 3 kernel zero-padded to 4 x 4): all four parity classes in one pass over the source (convt_quad_resident_kernel)
-        w4 = w if kh == 4 else torch.nn.functional.pad(w, (0, 1, 0, 1))  # noqa: PLR2004
         geoms = (_lib.ConvGeom * 4)()
         wqs = []
         for q in range(4):
             qy, qx = q >> 1, q & 1
             ky0, kx0 = (qy + pad) % stride, (qx + pad) % stride
-            wsub = w4[:, :, ky0::stride, kx0::stride].permute(1, 0, 2, 3)  # [c][o][2][2]
-            wp, wq = pack_weight(wsub, sub=q)
+            wsub = w[:, :, ky0::stride, kx0::stride].permute(1, 0, 2, 3)  # [c][o][2 or 1][2 or 1]
+            wp, wq = pack_weight(wsub, sub=q, grid=(2, 2))
             geoms[q] = _geom(N=n, C=o, Hs=hs, Ws=ws, C2=0, Cpad=wp.shape[2], KH=2, KW=2, SS=1, TS=-1,
                              OFFY=(qy + pad - ky0) // stride, OFFX=(qx + pad - kx0) // stride, Hq=hs, Wq=ws, OS=stride, QY=qy, QX=qx,
                              Ho=ho, Wo=wo, Cout=c, CoutPad=wp.shape[0], pre_act=int(pre_act), act=act)
@@ -395,7 +409,7 @@ def _conv_transposed_gather(y: Tensor, w: Tensor, bias: Tensor | None, stride: i
 # never handed out twice and is freed by the allocator when the last view of it dies.
 TGATHER_THIN = os.environ.get("MTRSSM_TGATHER_THIN", "1") != "0"  # A/B switch of conv_tgather_thin_kernel
 CONVT_QUAD = os.environ.get("MTRSSM_CONVT_QUAD", "1") != "0"  # A/B switch of convt_quad_resident_kernel
-CONVT_QUAD_BWD = os.environ.get("MTRSSM_CONVT_QUAD_BWD", "0") == "1"  # its use for a k=3 s=2 conv's backward-data (see there)
+CONVT_QUAD_BWD = os.environ.get("MTRSSM_CONVT_QUAD_BWD", "1") != "0"  # its use for a k=3 s=2 conv's backward-data (see there)
 _ZERO_CHUNK_FLOATS = 2 << 20
 _ZERO_CHUNKS: dict[tuple, list] = {}
 

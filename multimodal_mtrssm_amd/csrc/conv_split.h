@@ -59,7 +59,11 @@ __device__ __forceinline__ unsigned swz_row(int row, int half) { return (unsigne
 // wq [pieces][OPad][taps][IPad] of the same values.
 __device__ __forceinline__ void pack_conv_weight_slice(const float* __restrict__ w, int O, int I, int KH, int KW, long so, long si,
                                                        long sh, long sw, int OPad, int IPad, int pieces, float* __restrict__ wp,
-                                                       unsigned short* __restrict__ wq, long first, long step) {
+                                                       unsigned short* __restrict__ wq, long first, long step, int VH = 0, int VW = 0) {
+  // VH x VW (0: all): the view holds only the leading VH x VW taps of the KH x KW grid, the others are zeros (a 3 x 3 kernel
+  // seen as the 4 x 4 kernel of a transposed convolution: its parity-class sub-kernels have 2 x 2, 2 x 1, 1 x 2 and 1 x 1 taps)
+  if (VH <= 0) VH = KH;
+  if (VW <= 0) VW = KW;
   const int taps = KH * KW;
   const long total = (long)OPad * taps * IPad;
   for (long idx = first; idx < total; idx += step) {
@@ -67,7 +71,7 @@ __device__ __forceinline__ void pack_conv_weight_slice(const float* __restrict__
     const long ot = idx / IPad;
     const int tap = (int)(ot % taps), o = (int)(ot / taps);
     float v = 0.f;
-    if (o < O && i < I) v = w[o * so + i * si + (tap / KW) * sh + (tap % KW) * sw];
+    if (o < O && i < I && tap / KW < VH && tap % KW < VW) v = w[o * so + i * si + (tap / KW) * sh + (tap % KW) * sw];
     wp[idx] = v;
     float r = v;
     for (int s = 0; s < pieces; ++s) {
@@ -90,7 +94,7 @@ __global__ void pack_conv_weights_kernel(const long* __restrict__ table) {
   const long* d = table + (size_t)blockIdx.y * MTRSSM_PACK_DESC_WORDS;
   pack_conv_weight_slice(reinterpret_cast<const float*>(d[0]), (int)d[3], (int)d[4], (int)d[5], (int)d[6], d[7], d[8], d[9], d[10],
                          (int)d[11], (int)d[12], (int)d[13], reinterpret_cast<float*>(d[1]), reinterpret_cast<unsigned short*>(d[2]),
-                         (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+                         (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x, (int)d[14], (int)d[15]);
 }
 
 // One gather problem of a launch.  A launch carries two (the audio and the vision branch run the same layer on different planes):

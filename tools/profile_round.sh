@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (on the GPU box): tools/profile_round.sh   -> gpurun_out/final/{stats,pmc_fetch,pmc_write}/ + bench_*.json
+# usage (on the GPU box): tools/profile_round.sh [stats]  -> gpurun_out/final/{stats,pmc_fetch,pmc_write}/ + bench_*.json
 # The passes behind profiles/roundN_*: kernel trace + stats of the default bench command, the two HBM counter passes
 # (separately, as MI355X_MICROARCH.md prescribes), then one plain bench line per mode.
 set -o pipefail
@@ -9,6 +9,11 @@ OUT=gpurun_out/final
 rm -rf $OUT && mkdir -p $OUT
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench --output-format csv -- python3 bench.py --steps 25 --warmup 3 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.log || exit 1
 echo stats done
+for MODEL in mmtrssm large; do
+  rocprofv3 --kernel-trace --stats -d $OUT/stats_$MODEL -o bench --output-format csv -- python3 bench.py --model $MODEL --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_${MODEL}_under_rocprof.json 2> $OUT/stats_$MODEL.log || exit 1
+  echo stats $MODEL done
+done
+[ "$1" = "stats" ] && { find $OUT -name "*kernel_trace.csv" -delete; ls $OUT/*; exit 0; }
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o f --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1 || exit 1
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o w --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1 || exit 1
 echo pmc done
