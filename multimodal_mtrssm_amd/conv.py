@@ -355,7 +355,7 @@ def _conv_transposed_gather(y: Tensor, w: Tensor, bias: Tensor | None, stride: i
     # are strided views of the PARAMETER with 2 x 2, 2 x 1, 1 x 2 and 1 x 1 taps, packed into a 2 x 2 tap grid (`grid`), so the
     # step's pack plan learns them like every other weight view.
     quad_bwd = (CONVT_QUAD_BWD and kh == 3 and kw == 3 and actgrad_in is not None and bias is None  # noqa: PLR2004
-                and (o, c, hs * ws) == (32, 16, 64))
+                and (o, c, hs * ws) in ((32, 16, 64), (16, 8, 256)))
     if (stride == 2 and pad == 1 and (ho, wo) == (2 * hs, 2 * ws) and add_in is None and _MFMA_SPLIT == 2 and CONVT_QUAD  # noqa: PLR2004
             and (quad_fwd or quad_bwd)):
         # the decoders' ConvTranspose layers (and the backward-data of the encoders' third conv = the same transposed conv with

@@ -1990,6 +1990,7 @@ static int quad_key(const MtrssmConvGeom* g4) {
   if (g0.C == 64 && g0.Cout == 32 && plane == 64) return 1;
   if (g0.C == 32 && g0.Cout == 16 && plane == 256) return 2;
   if (g0.C == 32 && g0.Cout == 16 && plane == 64) return 3;  // backward-data of the encoders' third conv (k = 3 zero-padded to 4)
+  if (g0.C == 16 && g0.Cout == 8 && plane == 256) return 4;  // ... of their second conv (8 of the tile's 32 output rows in use: HBM-bound)
   return 0;
 }
 
@@ -2001,8 +2002,8 @@ int conv_convt_quad_launch(const MtrssmConvGeom* ga4, const float* srca, const u
   const int key = quad_key(ga4);
   const bool epi = actgrada != nullptr;
   if (!key || !srca || !wqa4 || !outa || (gb4 && (quad_key(gb4) != key || !srcb || !wqb4 || !outb || (actgradb != nullptr) != epi)) ||
-      (epi != (key == 3))) {
-    set_error("convt_quad: layer outside the kernel's shapes (k4 s2 p1: 64 -> 32 on 64-pixel planes, 32 -> 16 on 256-pixel planes; with act' operand: 32 -> 16 on 64-pixel planes; two bf16 pieces)");
+      (epi != (key >= 3))) {
+    set_error("convt_quad: layer outside the kernel's shapes (k4 s2 p1: 64 -> 32 on 64-pixel planes, 32 -> 16 on 256-pixel planes; with act' operand: 32 -> 16 on 64-pixel planes, 16 -> 8 on 256-pixel planes; two bf16 pieces)");
     return MTRSSM_EINVAL;
   }
   QuadProblem qa{}, qb{};
@@ -2040,6 +2041,7 @@ int conv_convt_quad_launch(const MtrssmConvGeom* ga4, const float* srca, const u
   }
   if (key == 1) MTRSSM_QUAD_LAUNCH(64, 32, 64, false)
   if (key == 2) MTRSSM_QUAD_LAUNCH(32, 16, 256, false)
+  if (key == 4) MTRSSM_QUAD_LAUNCH(16, 8, 256, true)
   MTRSSM_QUAD_LAUNCH(32, 16, 64, true)
 #undef MTRSSM_QUAD_LAUNCH
 }
