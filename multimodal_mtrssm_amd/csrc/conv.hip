@@ -748,7 +748,9 @@ __global__ __launch_bounds__(kConvThreads) void conv_gather_thin_kernel(
 // of its input position from the 3 x 3 neighbourhood: 9 LDS reads + 16 fmas per channel, weights through the
 // scalar cache (wave-uniform addresses).
 // ------------------------------------------------------------------------------------------------
-constexpr int kCtTH = 8, kCtTW = 32, kCtPW = kCtTW + 2, kCtPS = (kCtTH + 2) * kCtPW + 1;
+// (tile of TW x 256 / TW input positions: 32 x 8, or 16 x 16 for planes only 16 wide -- the audio decoder's 64 x 16 -- where half of
+// a 32-wide tile's threads had no pixel: 176 -> ~100 us)
+constexpr int kCtTW = 32, kCtTH = 8, kCtPS = (kCtTH + 2) * (kCtTW + 2) + 1;  // the larger of the two tiles' LDS planes
 
 // Transposed gather with <= 8 output channels (backward-data of the encoders' second conv: dX[N, 8, 32, 32] from
 // dY[N, 16, 16, 16], k = 3, s = 2, p = 1), ALL output parity classes in one pass: one thread per output pixel visits the taps
@@ -839,10 +841,11 @@ __global__ __launch_bounds__(kConvThreads) void conv_tgather_thin_kernel(
     if (j < Cc) out[base + (size_t)j * plane_o] = v;
   }
 }
-template <int COT>
+template <int COT, int TW>
 __global__ __launch_bounds__(kConvThreads) void convt_k4s2_thin_kernel(
     const int N, const int C, const int Hs, const int Ws, const int Cout, const float* __restrict__ src,
     const float* __restrict__ w, const float* __restrict__ bias, const int pre_act, const int act, float* __restrict__ out) {
+  constexpr int kCtTW = TW, kCtTH = kConvThreads / TW, kCtPW = kCtTW + 2, kCtPS = (kCtTH + 2) * kCtPW + 1;  // (shadow the defaults)
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [C][kCtPS]
   const int tid = threadIdx.x;
   const int x0 = blockIdx.x * kCtTW, y0 = blockIdx.y * kCtTH, n = blockIdx.z;
@@ -1942,11 +1945,13 @@ int convt_k4s2_thin_launch(int N, int C, int Hs, int Ws, int Cout, const float* 
   if ((uintptr_t)out & 7) { set_error("convt_k4s2_thin: out must be 8-byte aligned"); return MTRSSM_EINVAL; }
   const size_t lds = (size_t)C * kCtPS * sizeof(float);
   if (lds > 64 * 1024) { set_error("convt_k4s2_thin: %d input channels do not fit the LDS tile", C); return MTRSSM_ELDS; }
-  const dim3 grid((Ws + kCtTW - 1) / kCtTW, (Hs + kCtTH - 1) / kCtTH, N);
-  if (Cout == 1)
-    { set_last_kernel("mtrssm::convt_k4s2_thin_kernel<1>"); hipLaunchKernelGGL(convt_k4s2_thin_kernel<1>, grid, dim3(kConvThreads), lds, stream, N, C, Hs, Ws, Cout, src, w, bias, pre_act, act, out); }
-  else
-    { set_last_kernel("mtrssm::convt_k4s2_thin_kernel<2>"); hipLaunchKernelGGL(convt_k4s2_thin_kernel<2>, grid, dim3(kConvThreads), lds, stream, N, C, Hs, Ws, Cout, src, w, bias, pre_act, act, out); }
+  const int tw = Ws <= 16 ? 16 : 32, th = kConvThreads / tw;
+  const dim3 grid((Ws + tw - 1) / tw, (Hs + th - 1) / th, N);
+#define MTRSSM_CT_LAUNCH(COT_, TW_)                                                                                  \
+  { set_last_kernel("mtrssm::convt_k4s2_thin_kernel<" #COT_ ", " #TW_ ">"); hipLaunchKernelGGL((convt_k4s2_thin_kernel<COT_, TW_>), grid, dim3(kConvThreads), lds, stream, N, C, Hs, Ws, Cout, src, w, bias, pre_act, act, out); }
+  if (Cout == 1) { if (tw == 16) MTRSSM_CT_LAUNCH(1, 16) else MTRSSM_CT_LAUNCH(1, 32) }
+  else { if (tw == 16) MTRSSM_CT_LAUNCH(2, 16) else MTRSSM_CT_LAUNCH(2, 32) }
+#undef MTRSSM_CT_LAUNCH
   return launched("convt_k4s2_thin");
 }
 
