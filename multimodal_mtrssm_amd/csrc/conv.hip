@@ -656,6 +656,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_gather_gemm_patch_kernel(
 }  // namespace mtrssm
 #include "conv_split.h"
 #include "conv_resident.h"
+#include "conv_s2_band.h"
 #include "conv_wgrad_resident.h"
 namespace mtrssm {
 
@@ -1377,12 +1378,56 @@ int pack_conv_weights_launch(const int64_t* table, int count, int blocks_per_wei
   return launched("pack_conv_weights");
 }
 
+// MTRSSM_CONV_S2_BAND=0: the thin / patch-staged kernels for the encoders' first two layers (A/B runs of conv3x3s2_band_kernel)
+static bool s2_band_enabled() {
+  static const bool on = [] { const char* e = getenv("MTRSSM_CONV_S2_BAND"); return !(e && e[0] == '0'); }();
+  return on;
+}
+// conv3x3s2_band_kernel's shapes: Conv2d(k 3, s 2, p 1) forward, <= 8 input channels (coordinate channels included), <= 16 outputs
+static bool s2_band_covers(const MtrssmConvGeom* g, bool has_wq, bool has_epilogue_operand) {
+  return s2_band_enabled() && g->mfma_split == 2 && has_wq && !has_epilogue_operand && g->KH == 3 && g->KW == 3 && g->SS == 2 && g->TS == 1 &&
+         g->OFFY == -1 && g->OFFX == -1 && g->OS == 1 && g->QY == 0 && g->QX == 0 && g->Hs == 2 * g->Hq && g->Ws == 2 * g->Wq &&
+         g->Ho == g->Hq && g->Wo == g->Wq && (g->Wq == 8 || g->Wq == 16 || g->Wq == 32) && g->Hq % (kBandPx / g->Wq) == 0 &&
+         ((g->C == 1 && g->C2 == 2) || (g->C == 8 && g->C2 == 0)) && g->Cout <= 16 && g->CoutPad == 32 && g->Cpad == 16 && g->act != MTRSSM_ACT_TANH &&
+         (long)g->N * g->C * g->Hs * g->Ws < (1L << 31) && (long)g->N * g->Cout * g->Hq * g->Wq < (1L << 31);
+}
+static int launch_s2_band(const GatherProblem& pa, const GatherProblem* pb, hipStream_t stream) {
+  const long ta = (long)pa.g.N * (pa.g.Hq * pa.g.Wq / kBandPx), tb = pb ? (long)pb->g.N * (pb->g.Hq * pb->g.Wq / kBandPx) : 0;
+  const int slots = 2 * cu_count();  // two workgroups per CU
+  GatherProblem qa = pa, qb{};
+  if (pb) qb = *pb;
+  if (tb == 0) {
+    qa.nx = (int)(ta < slots ? ta : slots);
+    qb.nx = 0;
+  } else {
+    long na = (slots * ta + (ta + tb) / 2) / (ta + tb);
+    na = na < 1 ? 1 : (na > slots - 1 ? slots - 1 : na);
+    qa.nx = (int)(na < ta ? na : ta);
+    qb.nx = (int)(slots - na < tb ? slots - na : tb);
+  }
+  const int wmax = pb && pb->g.Wq < pa.g.Wq ? pb->g.Wq : pa.g.Wq;  // the narrower plane has the taller band: the larger image
+  const size_t lds = (size_t)band_lds_bytes(wmax);
+  if (pa.g.C == 1) {
+    set_last_kernel("mtrssm::conv3x3s2_band_kernel<1, 2>");
+    hipLaunchKernelGGL((conv3x3s2_band_kernel<1, 2>), dim3((unsigned)(qa.nx + qb.nx)), dim3(256), lds, stream, qa, qb);
+  } else {
+    set_last_kernel("mtrssm::conv3x3s2_band_kernel<8, 0>");
+    hipLaunchKernelGGL((conv3x3s2_band_kernel<8, 0>), dim3((unsigned)(qa.nx + qb.nx)), dim3(256), lds, stream, qa, qb);
+  }
+  return launched("conv_gather_gemm(s2 band)");
+}
+
 int conv_gather_gemm_launch(const MtrssmConvGeom* g, const float* src, const float* src2, const float* wp, const unsigned short* wq,
                             const float* bias, const float* actgrad_in, const float* add_in, float* out, hipStream_t stream) {
   if (int rc = check_geom(g, "conv_gather_gemm")) return rc;
   if (!src || !wp || !out || (g->C2 > 0 && !src2)) { set_error("conv_gather_gemm: null pointer"); return MTRSSM_EINVAL; }
   if ((uintptr_t)wp & 15) { set_error("conv_gather_gemm: packed weights must be 16-byte aligned"); return MTRSSM_EINVAL; }
   const long ptot = (long)g->N * g->Hq * g->Wq;
+  if (s2_band_covers(g, wq != nullptr, actgrad_in || add_in)) {
+    GatherProblem p{};
+    p.g = *g; p.src = src; p.src2 = src2; p.wq = wq; p.bias = bias; p.out = out;
+    return launch_s2_band(p, nullptr, stream);
+  }
   if ((g->Cout <= 8 || g->C + g->C2 <= 2) && g->Cout <= 16 && g->KH * g->KW * (g->C + g->C2) <= kThinMaxK) {  // thin layer: VALU kernel
     const dim3 grid((unsigned)((ptot + kConvThreads - 1) / kConvThreads));
     if (g->Cout <= 2)
@@ -1441,6 +1486,8 @@ int conv_gather_gemm_launch(const MtrssmConvGeom* g, const float* src, const flo
 // 1 when the two problems run the same split kernel and therefore go out as ONE grid (mtrssm_conv_gather_pair_merges)
 int conv_gather_pair_merges(const MtrssmConvGeom* ga, const MtrssmConvGeom* gb, bool has_wq) {
   if (!ga || !gb || check_geom(ga, "conv_gather_gemm_pair") || check_geom(gb, "conv_gather_gemm_pair")) return 0;
+  // (the band kernel's pair: epilogue operands are checked again at launch, where a pair with one falls back to two launches)
+  if (s2_band_covers(ga, has_wq, false) && s2_band_covers(gb, has_wq, false) && ga->C == gb->C) return 1;
   const bool thin_a = (ga->Cout <= 8 || ga->C + ga->C2 <= 2) && ga->Cout <= 16;
   const bool thin_b = (gb->Cout <= 8 || gb->C + gb->C2 <= 2) && gb->Cout <= 16;
   if (thin_a || thin_b) return 0;
@@ -1452,8 +1499,16 @@ int conv_gather_gemm_pair_launch(const MtrssmConvGeom* ga, const float* srca, co
                                  const float* biasa, const float* actgrada, const float* adda, float* outa, const MtrssmConvGeom* gb,
                                  const float* srcb, const float* src2b, const float* wpb, const unsigned short* wqb, const float* biasb,
                                  const float* actgradb, const float* addb, float* outb, hipStream_t stream) {
+  if (srca && srcb && outa && outb && ga && gb && !(ga->C2 > 0 && !src2a) && !(gb->C2 > 0 && !src2b) && !check_geom(ga, "conv_gather_gemm_pair") &&
+      !check_geom(gb, "conv_gather_gemm_pair") && s2_band_covers(ga, wqa != nullptr, actgrada || adda) && s2_band_covers(gb, wqb != nullptr, actgradb || addb) && ga->C == gb->C) {
+    GatherProblem p{}, q{};
+    p.g = *ga; p.src = srca; p.src2 = src2a; p.wq = wqa; p.bias = biasa; p.out = outa;
+    q.g = *gb; q.src = srcb; q.src2 = src2b; q.wq = wqb; q.bias = biasb; q.out = outb;
+    return launch_s2_band(p, &q, stream);
+  }
   if (srca && srcb && outa && outb && !(ga && ga->C2 > 0 && !src2a) && !(gb && gb->C2 > 0 && !src2b) &&
-      conv_gather_pair_merges(ga, gb, wqa != nullptr && wqb != nullptr)) {
+      conv_gather_pair_merges(ga, gb, wqa != nullptr && wqb != nullptr) &&
+      !(s2_band_covers(ga, true, false) && s2_band_covers(gb, true, false) && ga->C == gb->C)) {
     const SplitPlan pa = plan_split(ga, true), pb = plan_split(gb, true);
     return launch_split(pa, pa.lds > pb.lds ? pa.lds : pb.lds, make_problem(ga, pa, srca, src2a, wqa, biasa, actgrada, adda, outa),
                         make_problem(gb, pb, srcb, src2b, wqb, biasb, actgradb, addb, outb), stream);

@@ -1,0 +1,230 @@
+// Conv2d(k = 3, s = 2, p = 1) forward with few input channels (<= 8 per position: the encoders' first two layers, frame +
+// 2 coordinate channels -> 8 and 8 -> 16, default.yaml:31-60), included by conv.hip after conv_split.h.
+//
+// Both layers are HBM-bound by two orders of magnitude (1.4 / 3.8 GFLOP for 157 MB each); the VALU kernel
+// (conv_gather_thin_kernel: one thread per output pixel, every tap a stride-2 4-byte gather) and the patch-staged split
+// kernel (two barriers per 16-channel step) ran them at 1.6 TB/s.  Here the staged recipe of the weight-gradient kernels:
+//   * a tile = 256 output pixels of one frame (a band of 256 / Wq output rows) = 2 * 256 / Wq + 1 source rows, loaded once
+//     with coalesced 16-byte loads, four positions (all <= 8 channels) per thread, a whole tile ahead in registers;
+//   * activated and split into two bf16 pieces once, written as ONE 16-byte LDS row per position and piece, the columns
+//     de-interleaved by parity (even image columns | odd image columns) so that the 32 pixels of an MFMA column tile read
+//     consecutive rows for every tap of the stride-2 window;
+//   * a tap IS a k-half: k-block kb = taps 2 kb and 2 kb + 1 (lane half kl), 8 channels each; 5 k-blocks (tap 9 has zero
+//     weights) x 3 products per 32-pixel unit, the weights (32 output-channel rows, of which 8 or 16 are real) in registers
+//     for the whole launch;
+//   * two workgroups per CU, each with two register sets of requests (this tile's and the next one's); a third workgroup
+//     per CU (168 registers: spills in the loop) doubled the 3-channel layer's time.
+// Same arithmetic as the other bf16x2 kernels (fp32 accumulation of the three products).
+#pragma once
+#include <type_traits>
+
+namespace mtrssm {
+
+using band_f4 = __attribute__((ext_vector_type(4))) float;
+constexpr int kBandPx = 256;  // output pixels per tile
+
+__host__ __device__ constexpr int band_row_bytes(int Wq) { return (2 * Wq + 2) * 16; }  // Wq + 1 even slots, Wq odd slots, 1 pad
+__host__ __device__ constexpr int band_lds_bytes(int Wq) { return 2 * (2 * (kBandPx / Wq) + 1) * band_row_bytes(Wq); }
+
+template <int C, int C2>  // input channels per frame / frame-independent coordinate channels (1 + 2 or 8 + 0)
+__global__ __launch_bounds__(256, 2) void conv3x3s2_band_kernel(const GatherProblem pa, const GatherProblem pb) {
+  const bool second = blockIdx.x >= (unsigned)pa.nx;  // workgroup-uniform
+  const GatherProblem& P = second ? pb : pa;
+  const MtrssmConvGeom g = P.g;
+  const float* __restrict__ src = P.src;
+  const float* __restrict__ src2 = P.src2;
+  const float* __restrict__ bias = P.bias;
+  float* __restrict__ out = P.out;
+  const int wg = second ? (int)blockIdx.x - pa.nx : (int)blockIdx.x, nwg = P.nx;
+  const int Ws = g.Ws, Wq = g.Wq;                 // host: Ws == 2 Wq, Hs == 2 Hq, Wq in {8, 16, 32}
+  const int wsh = 31 - __builtin_clz(Ws), qsh = wsh - 1;
+  const int BR = kBandPx >> qsh;                  // output rows per band (host: Hq % BR == 0)
+  const int bands = g.Hq / BR, ntiles = g.N * bands;
+  const int SR = 2 * BR + 1;                      // source rows per band (the first one is the row above the band)
+  const int RP = band_row_bytes(Wq), IMG = SR * RP;
+  constexpr int CT = C + C2;                      // host: g.C == C, g.C2 == C2
+  static_assert(CT <= 8, "one 16-byte row per position");
+  const int plane_s = g.Hs * Ws, plane_o = g.Hq * Wq;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, il = lane & 31, kl = lane >> 5;
+  if (wg >= ntiles) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char band_lds[];  // [2 pieces][SR rows][RP]
+
+  // weights: A operands, row = output channel il, k-block kb = (tap 2 kb + kl) x channels 0..7
+  bf16x8 a[5][2];
+  {
+    const size_t piece = (size_t)g.CoutPad * 9 * g.Cpad;  // host: CoutPad == 32, Cpad == 16
+#pragma unroll
+    for (int kb = 0; kb < 5; ++kb) {
+      const int tap = 2 * kb + kl;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        u32x4 v = u32x4{0u, 0u, 0u, 0u};
+        if (tap < 9) v = *reinterpret_cast<const u32x4*>(P.wq + s * piece + ((size_t)il * 9 + tap) * g.Cpad);
+        a[kb][s] = __builtin_bit_cast(bf16x8, v);
+      }
+    }
+  }
+  for (int o = tid * 16; o < 2 * IMG; o += 256 * 16) *reinterpret_cast<u32x4*>(band_lds + o) = u32x4{0u, 0u, 0u, 0u};
+
+  // a thread owns 4 consecutive positions of one row (one 16-byte request per channel): the band's 1024 positions are one such
+  // group per thread; the row above the band (Ws / 4 groups x CT channels <= 128 requests) is ONE more request per thread,
+  // thread -> (channel hc, group hg), unconditional like the others (idle threads repeat a valid address)
+  const int hgroups = Ws >> 2;
+  const int hc = tid / hgroups, hg = tid - hc * hgroups;
+  const bool hreal = hc < CT;
+  const int hcc = hreal ? hc : 0;
+  band_f4 pv[2][CT], ph[2];  // [register set]
+  // requests as buffer loads: one 32-bit offset per group, the frame / channel part of the address in scalar registers
+  const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src2 ? src2 : src), 0, 0x7fffffff, 0x00020000);
+  auto request = [&](int tile, auto set_tag) {
+    constexpr int SET = decltype(set_tag)::value;
+    const int n = tile / bands, band = tile - n * bands;
+    const int sy0 = 2 * band * BR;  // the band's first own source row (the row above it is the halo request)
+    const __amdgpu_buffer_rsrc_t rsf =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src + (size_t)n * C * plane_s), 0, 0x7fffffff, 0x00020000);
+    const int off = (sy0 * Ws + tid * 4) * 4;
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+      pv[SET][c] = __builtin_bit_cast(band_f4, __builtin_amdgcn_raw_buffer_load_b128(c < C ? rsf : rs2, off, (c < C ? c : c - C) * plane_s * 4, 0));
+    const int hoff = (((sy0 > 0 ? sy0 - 1 : 0) * Ws + hg * 4) + (hcc < C ? hcc : hcc - C) * plane_s) * 4;  // (frame row -1: stored as zeros)
+    if (C2 > 0) {
+      const band_f4 hf = __builtin_bit_cast(band_f4, __builtin_amdgcn_raw_buffer_load_b128(rsf, hcc < C ? hoff : 0, 0, 0));
+      const band_f4 h2 = __builtin_bit_cast(band_f4, __builtin_amdgcn_raw_buffer_load_b128(rs2, hcc < C ? 0 : hoff, 0, 0));
+      ph[SET] = hcc < C ? hf : h2;
+    } else {
+      ph[SET] = __builtin_bit_cast(band_f4, __builtin_amdgcn_raw_buffer_load_b128(rsf, hoff, 0, 0));
+    }
+  };
+  const int act = g.act;
+  const int mode = g.pre_act == 0 ? 0 : (act == MTRSSM_ACT_ELU ? 1 : 2);  // (one uniform branch per tile, not per element)
+  auto stage_as = [&](int tile, auto mode_tag, auto set_tag) {
+    constexpr int MODE = decltype(mode_tag)::value, SET = decltype(set_tag)::value;
+    const int band = tile % bands;
+    auto activate = [&](float v) {
+      if (MODE == 1) v = elu_fast(v);
+      if (MODE == 2) v = act_fwd(v, act);
+      return v;
+    };
+    {
+      const int p = tid * 4, r = 1 + (p >> wsh), x = p & (Ws - 1);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        u16x8 q0, q1;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          float v = 0.f;
+          if (c < CT) v = activate(pv[SET][c < CT ? c : 0][e]);
+          unsigned short h[2];
+          split_bf16<2>(v, h);
+          q0[c] = h[0];
+          q1[c] = h[1];
+        }
+        const int ic = x + e + 1;  // image column (0 = the zero column left of the frame)
+        const int slot = (ic & 1) ? Wq + 1 + (ic >> 1) : (ic >> 1);
+        unsigned char* d = band_lds + r * RP + slot * 16;
+        *reinterpret_cast<u16x8*>(d) = q0;
+        *reinterpret_cast<u16x8*>(d + IMG) = q1;
+      }
+    }
+    if (hreal) {  // image row 0: the source row above the band, one channel of 4 positions per thread
+      const bool real = band > 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        unsigned short h[2];
+        split_bf16<2>(real ? activate(ph[SET][e]) : 0.f, h);
+        const int ic = hg * 4 + e + 1;
+        const int slot = (ic & 1) ? Wq + 1 + (ic >> 1) : (ic >> 1);
+        unsigned short* d = reinterpret_cast<unsigned short*>(band_lds + slot * 16) + hc;
+        d[0] = h[0];
+        d[IMG / 2] = h[1];
+      }
+    }
+  };
+  auto stage = [&](int tile, auto set_tag) {
+    if (mode == 0) stage_as(tile, std::integral_constant<int, 0>{}, set_tag);
+    else if (mode == 1) stage_as(tile, std::integral_constant<int, 1>{}, set_tag);
+    else stage_as(tile, std::integral_constant<int, 2>{}, set_tag);
+  };
+
+  // this wave's two units: pixel j = 32 u + il of the band -> (oy, ox); tap (ty, tx) reads image row 2 oy + ty, column 2 ox + tx
+  unsigned baddr[2][5];
+  int opix[2];
+#pragma unroll
+  for (int uu = 0; uu < 2; ++uu) {
+    const int j = (2 * wave + uu) * 32 + il, oy = j >> qsh, ox = j & (Wq - 1);
+    opix[uu] = oy * Wq + ox;
+#pragma unroll
+    for (int kb = 0; kb < 5; ++kb) {
+      const int tap = 2 * kb + kl < 9 ? 2 * kb + kl : 8, ty = tap / 3, tx = tap - 3 * ty;
+      const int slot = (tx & 1) ? Wq + 1 + ox : ox + (tx >> 1);
+      baddr[uu][kb] = (unsigned)((2 * oy + ty) * RP + slot * 16);
+    }
+  }
+  float bv[16];
+  {
+    const float* bsafe = bias ? bias : src;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = 4 * kl + (r & 3) + 8 * (r >> 2);
+      const float b = bsafe[co < g.Cout ? co : 0];
+      bv[r] = (bias && co < g.Cout) ? b : 0.f;
+    }
+  }
+
+  // Two register sets of requests: the tile after this one is requested BEFORE this one is converted, so a workgroup has
+  // requests in flight all the time (one set, requested after the conversion: 2.5 TB/s -- nothing was in flight while a
+  // workgroup converted).  The requests stay unconditional (past the last tile they repeat it) so that the wait before a
+  // conversion counts only the older set.
+  auto compute = [&](int tile) {
+    const int n = tile / bands, band = tile - n * bands;
+    float* obase = out + (size_t)n * g.Cout * plane_o + (size_t)band * kBandPx;
+    f32x16 acc[2];  // the two units' chains interleaved: a dependent MFMA waits out its predecessor's passes
+#pragma unroll
+    for (int uu = 0; uu < 2; ++uu)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[uu][r] = bv[r];
+#pragma unroll
+    for (int kb = 0; kb < 5; ++kb) {
+      bf16x8 b0[2], b1[2];
+#pragma unroll
+      for (int uu = 0; uu < 2; ++uu) {
+        b0[uu] = *reinterpret_cast<const bf16x8*>(band_lds + baddr[uu][kb]);
+        b1[uu] = *reinterpret_cast<const bf16x8*>(band_lds + baddr[uu][kb] + IMG);
+      }
+#pragma unroll
+      for (int uu = 0; uu < 2; ++uu) acc[uu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kb][0], b1[uu], acc[uu], 0, 0, 0);
+#pragma unroll
+      for (int uu = 0; uu < 2; ++uu) acc[uu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kb][1], b0[uu], acc[uu], 0, 0, 0);
+#pragma unroll
+      for (int uu = 0; uu < 2; ++uu) acc[uu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kb][0], b0[uu], acc[uu], 0, 0, 0);
+    }
+#pragma unroll
+    for (int uu = 0; uu < 2; ++uu)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = 4 * kl + (r & 3) + 8 * (r >> 2);
+        if (co < g.Cout) obase[(size_t)co * plane_o + opix[uu]] = acc[uu][r];
+      }
+  };
+  const int last = wg + ((ntiles - 1 - wg) / nwg) * nwg;  // this workgroup's last tile
+  const std::integral_constant<int, 0> s0{};
+  const std::integral_constant<int, 1> s1{};
+  request(wg, s0);
+  __syncthreads();  // the zero fill
+  for (int tile = wg; tile < ntiles; tile += 2 * nwg) {
+    const int t1 = tile + nwg, t2 = tile + 2 * nwg;
+    request(t1 < last ? t1 : last, s1);
+    stage(tile, s0);
+    lds_barrier();
+    compute(tile);
+    lds_barrier();  // every wave is done with the image before the next tile overwrites it
+    if (t1 >= ntiles) break;  // workgroup-uniform
+    request(t2 < last ? t2 : last, s0);
+    stage(t1, s1);
+    lds_barrier();
+    compute(t1);
+    lds_barrier();
+  }
+}
+
+}  // namespace mtrssm

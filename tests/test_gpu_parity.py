@@ -754,14 +754,15 @@ def test_one_pass_parity_class_kernels_match_the_per_class_launches(lib_loaded: 
 
     res = {}
     for one_pass in (False, True):
-        conv.CONVT_QUAD = conv.TGATHER_THIN = conv.CONVT_QUAD_BWD = one_pass  # (the backward-data use is off by default)
+        conv.CONVT_QUAD = conv.TGATHER_THIN = conv.CONVT_QUAD_BWD = one_pass
         try:
             res[one_pass] = run()
         finally:
             conv.CONVT_QUAD = conv.TGATHER_THIN = True
-            conv.CONVT_QUAD_BWD = False
+            conv.CONVT_QUAD_BWD = True
     for i, (a, b) in enumerate(zip(res[True], res[False], strict=True)):
-        np.testing.assert_allclose(_np(a), _np(b), rtol=2e-5, atol=2e-6 * float(b.abs().max()), err_msg=str(i))
+        # (x4.grad: the per-class path is the fp32 VALU kernel, the one-pass path two bf16 pieces per operand: 16 significant bits)
+        np.testing.assert_allclose(_np(a), _np(b), rtol=2e-5, atol=(5e-6 if i == 7 else 2e-6) * float(b.abs().max()), err_msg=str(i))
 
 
 def test_paired_launches_change_nothing(lib_loaded: None) -> None:
