@@ -479,6 +479,15 @@ int mtrssm_pack_conv_weight(const float* w, int32_t O, int32_t I, int32_t KH, in
 int mtrssm_pack_conv_weights(const int64_t* table, int32_t count, int32_t blocks_per_weight, void* stream);
 int mtrssm_conv_weight_grad(const MtrssmConvGeom* g, const float* a, const float* src, const float* src2,
                             int32_t pre_act_a, float* dwp, float* dbias, void* workspace, int64_t workspace_bytes, void* stream);
+/* mtrssm_conv_weight_grad with the sum of its partial tile sets DEFERRED: the main kernel is launched, the small launch that
+ * adds the sets into dwp / dbias is recorded for `stream` instead (38 such launches of 6-15 us per train step otherwise).
+ * mtrssm_conv_weight_grad_reduce(stream) then runs every recorded sum in one launch.  Contract: the workspace of a deferred
+ * call stays untouched -- no other call may be given the same bytes -- and dwp / dbias are not read until the reduce; a
+ * second deferred call on the same dwp or workspace first flushes the recorded ones (order is kept).  Kernels without
+ * partial sets (general geometry, atomics mode) behave exactly like mtrssm_conv_weight_grad. */
+int mtrssm_conv_weight_grad_deferred(const MtrssmConvGeom* g, const float* a, const float* src, const float* src2,
+                                     int32_t pre_act_a, float* dwp, float* dbias, void* workspace, int64_t workspace_bytes, void* stream);
+int mtrssm_conv_weight_grad_reduce(void* stream);
 /* Bytes of workspace the kernel chosen for this geometry wants for its partial tile sets (0: none; -1: invalid geometry; up to
  * ~38 MB for the reference's layer shapes at B*T = 3200 frames).  A host-side query, nothing is launched. */
 int64_t mtrssm_conv_weight_grad_workspace_bytes(const MtrssmConvGeom* g, int32_t pre_act_a);

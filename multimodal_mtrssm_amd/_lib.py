@@ -114,6 +114,8 @@ SYMBOLS: dict[str, tuple[type | None, list[type]]] = {
     "mtrssm_pack_conv_weights": (C.c_int, [_p, _i, _i, _p]),
     "mtrssm_unpack_conv_grads": (C.c_int, [_p, _i, _i, _p]),
     "mtrssm_conv_weight_grad": (C.c_int, [C.POINTER(ConvGeom), _p, _p, _p, _i, _p, _p, _p, C.c_int64, _p]),
+    "mtrssm_conv_weight_grad_deferred": (C.c_int, [C.POINTER(ConvGeom), _p, _p, _p, _i, _p, _p, _p, C.c_int64, _p]),
+    "mtrssm_conv_weight_grad_reduce": (C.c_int, [_p]),
     "mtrssm_conv_weight_grad_workspace_bytes": (C.c_int64, [C.POINTER(ConvGeom), _i]),
     "mtrssm_channel_sum": (C.c_int, [_p, _i, _i, _i, _p, _p]),
     "mtrssm_convt_k4s2_thin": (C.c_int, [_i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _p, _p]),

@@ -470,11 +470,13 @@ class _ConvGradSink:
         buffers and re-arm."""
         if self.pending:
             self.pending = False
+            _reduce_deferred()  # (drops the recorded sums of the abandoned backward; their targets are cleared below)
             for packed, _dst, _owner in self.entries.values():
                 packed.zero_()
 
     def flush(self) -> None:
         self.pending = False
+        _reduce_deferred()  # the partial-set sums of the step's weight-gradient kernels, one launch, before they are unpacked
         if any(v[2]() is None for v in self.entries.values()):
             self.entries = {k: v for k, v in self.entries.items() if v[2]() is not None}
             self.table = None
@@ -527,7 +529,23 @@ _WGRAD_WS_RETIRED: list[Tensor] = []
 _WGRAD_NEED: dict[tuple, int] = {}
 
 
-def _wgrad_workspace(geom: C.Structure, pre_act_a: int, device: torch.device) -> Tensor | None:
+# With the partial-set sums deferred to the end of the backward pass (``DEFER_WGRAD_REDUCE``; include/mtrssm.h:
+# mtrssm_conv_weight_grad_deferred) every weight-gradient launch of the step needs bytes of its own until then: slot k of the
+# (device, stream) serves the k-th deferred launch since the last reduce.
+DEFER_WGRAD_REDUCE = os.environ.get("MTRSSM_DEFER_WGRAD_REDUCE", "1") != "0"
+_WGRAD_SLOTS: dict[tuple, list[Tensor]] = {}
+_WGRAD_SLOT_NEXT: dict[tuple, int] = {}
+
+
+def _reduce_deferred() -> None:
+    for (device, stream), used in list(_WGRAD_SLOT_NEXT.items()):
+        if used:
+            _WGRAD_SLOT_NEXT[(device, stream)] = 0
+            _lib.check(_lib.TIMERS.call("mtrssm_conv_weight_grad_reduce", _lib.load().mtrssm_conv_weight_grad_reduce, C.c_void_p(stream)),
+                       "mtrssm_conv_weight_grad_reduce")
+
+
+def _wgrad_workspace(geom: C.Structure, pre_act_a: int, device: torch.device, *, own: bool = False) -> Tensor | None:
     gkey = (tuple(getattr(geom, n) for n, _ in geom._fields_), pre_act_a)
     need = _WGRAD_NEED.get(gkey)
     if need is None:
@@ -535,6 +553,16 @@ def _wgrad_workspace(geom: C.Structure, pre_act_a: int, device: torch.device) ->
     if need == 0:
         return None
     key = (device, torch.cuda.current_stream(device).cuda_stream)
+    if own:
+        slots = _WGRAD_SLOTS.setdefault(key, [])
+        k = _WGRAD_SLOT_NEXT.get(key, 0)
+        _WGRAD_SLOT_NEXT[key] = k + 1
+        if k == len(slots):
+            slots.append(torch.empty((need + 3) // 4 + 64, device=device, dtype=torch.float32))
+        elif slots[k].numel() * 4 < need:
+            _WGRAD_WS_RETIRED.append(slots[k])
+            slots[k] = torch.empty((need + 3) // 4 + 64, device=device, dtype=torch.float32)
+        return slots[k]
     ws = _WGRAD_WS.get(key)
     if ws is None or ws.numel() * 4 < need:
         if ws is not None:
@@ -566,9 +594,13 @@ def _weight_grad(a: Tensor, src: Tensor, coords: Tensor | None, kh: int, kw: int
                  OS=1, QY=0, QX=0, Ho=hq, Wo=wq, Cout=o, CoutPad=opad, pre_act=int(pre_act_src), act=act)
     flops = 2.0 * n * hq * wq * o * kh * kw * (c + c2)
     nbytes = 4.0 * (a.numel() + src.numel())
-    ws = _wgrad_workspace(geom, int(pre_act_a), a.device)
+    # the sums of the partial sets wait for the end of the backward pass when both results go to the flat buffer (the sink's
+    # flush runs them in one launch before it unpacks); a gradient handed back to autograd as a tensor is summed on the spot
+    defer = DEFER_WGRAD_REDUCE and sunk is not None and (not want_bias or bias_sunk is not None)
+    ws = _wgrad_workspace(geom, int(pre_act_a), a.device, own=defer)
+    entry = lib.mtrssm_conv_weight_grad_deferred if defer and ws is not None else lib.mtrssm_conv_weight_grad
     _lib.check(_lib.TIMERS.call(
-        "mtrssm_conv_weight_grad", lib.mtrssm_conv_weight_grad, C.byref(geom), _lib.ptr(a), _lib.ptr(src), _lib.ptr(coords),
+        "mtrssm_conv_weight_grad", entry, C.byref(geom), _lib.ptr(a), _lib.ptr(src), _lib.ptr(coords),
         int(pre_act_a), _lib.ptr(dwp), _lib.ptr(dbias), _lib.raw_ptr(ws), 0 if ws is None else ws.numel() * 4, _lib.stream_ptr(a.device),
         flops=flops, nbytes=nbytes), "mtrssm_conv_weight_grad")
     g_w = None if sunk is not None else dwp[:o, :, : c + c2].reshape(o, kh, kw, c + c2).permute(0, 3, 1, 2)

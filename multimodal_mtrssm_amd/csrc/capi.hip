@@ -30,6 +30,8 @@ int pack_conv_weight_launch(const float*, int, int, int, int, long, long, long, 
 int pack_conv_weights_launch(const int64_t*, int, int, hipStream_t);
 int conv_gather_pair_merges(const MtrssmConvGeom*, const MtrssmConvGeom*, bool);
 int conv_weight_grad_launch(const MtrssmConvGeom*, const float*, const float*, const float*, int, float*, float*, void*, size_t, size_t*, hipStream_t);
+int conv_weight_grad_deferred_launch(const MtrssmConvGeom*, const float*, const float*, const float*, int, float*, float*, void*, size_t, hipStream_t);
+int conv_weight_grad_reduce_flush(hipStream_t);
 int channel_sum_launch(const float*, int, int, int, float*, hipStream_t);
 int convt_k4s2_thin_launch(int, int, int, int, int, const float*, const float*, const float*, int, int, float*, hipStream_t);
 int conv_convt_quad_supported(const MtrssmConvGeom*);
@@ -211,6 +213,12 @@ MTRSSM_API int mtrssm_conv_weight_grad(const MtrssmConvGeom* g, const float* a, 
   return conv_weight_grad_launch(g, a, src, src2, pre_act_a, dwp, dbias, workspace, workspace_bytes < 0 ? 0 : (size_t)workspace_bytes, nullptr,
                                  static_cast<hipStream_t>(stream));
 }
+MTRSSM_API int mtrssm_conv_weight_grad_deferred(const MtrssmConvGeom* g, const float* a, const float* src, const float* src2, int32_t pre_act_a,
+                                               float* dwp, float* dbias, void* workspace, int64_t workspace_bytes, void* stream) {
+  return conv_weight_grad_deferred_launch(g, a, src, src2, pre_act_a, dwp, dbias, workspace, workspace_bytes < 0 ? 0 : (size_t)workspace_bytes,
+                                          static_cast<hipStream_t>(stream));
+}
+MTRSSM_API int mtrssm_conv_weight_grad_reduce(void* stream) { return conv_weight_grad_reduce_flush(static_cast<hipStream_t>(stream)); }
 MTRSSM_API int64_t mtrssm_conv_weight_grad_workspace_bytes(const MtrssmConvGeom* g, int32_t pre_act_a) {
   size_t need = 0;
   if (conv_weight_grad_launch(g, nullptr, nullptr, nullptr, pre_act_a, nullptr, nullptr, nullptr, 0, &need, nullptr) != MTRSSM_OK) return -1;

@@ -658,6 +658,107 @@ __global__ __launch_bounds__(kConvThreads) void conv_gather_gemm_patch_kernel(
 #include "conv_resident.h"
 #include "conv_s2_band.h"
 #include "conv_wgrad_resident.h"
+
+namespace mtrssm {
+
+// ---- partial-set reduction of the staged weight-gradient kernels, immediate or batched -----------------------------
+// Every staged weight-gradient kernel leaves S partial tile sets in the caller's workspace and a small kernel sums them into
+// dwp (38 such launches of 6-15 us per train step, launch-bound).  With deferral on (mtrssm_conv_weight_grad_deferred) the
+// sums are recorded instead and mtrssm_conv_weight_grad_reduce() runs them all in ONE launch: the jobs travel by value in the
+// kernel arguments (a captured graph replays them), each workgroup finds its job by its block range.
+static int launched(const char* who);
+enum ReduceVariant { kRedRes64, kRedRes32, kRed1x1_64, kRed1x1_128, kRedThin, kRedThinT, kRedS2, kRedT4, kRedT4b, kRedS2c };
+struct ReduceJob {
+  const float4* part;
+  float* dwp;
+  float* dbias;
+  int S, cpad, variant, gx, gy;   // gx x gy blocks (block lb of the job = (lb % gx, lb / gx))
+  __host__ int variant_gy() const { return gy; }
+};
+constexpr int kReduceBatchMax = 48;
+struct ReduceBatch {
+  int count;
+  int first[kReduceBatchMax + 1];   // first block of job j; first[count] = the grid
+  ReduceJob job[kReduceBatchMax];
+};
+__device__ __forceinline__ void wgrad_reduce_dispatch(const ReduceJob& j, int bx, int by) {
+  switch (j.variant) {  // block-uniform
+    case kRedRes64: wgrad_reduce_partials_body<64>(j.part, j.S, j.cpad, j.dwp, j.dbias, bx, by); break;
+    case kRedRes32: wgrad_reduce_partials_body<32>(j.part, j.S, j.cpad, j.dwp, j.dbias, bx, by); break;
+    case kRed1x1_64: wgrad_reduce_partials1x1_body<64>(j.part, j.S, j.cpad, j.dwp, j.dbias, bx, by); break;
+    case kRed1x1_128: wgrad_reduce_partials1x1_body<128>(j.part, j.S, j.cpad, j.dwp, j.dbias, bx, by); break;
+    case kRedThin: wgrad_reduce_partials_thin_body(j.part, j.S, j.cpad, j.dwp, j.dbias, bx, by); break;
+    case kRedThinT: wgrad_reduce_partials_thint_body(j.part, j.S, j.cpad, j.dwp, bx, by); break;
+    case kRedS2: wgrad_reduce_partials_s2_body(j.part, j.S, j.cpad, j.dwp, j.dbias, bx, by); break;
+    case kRedT4: wgrad_reduce_partials_t4_body(j.part, j.S, j.cpad, j.dwp, bx, by); break;
+    case kRedT4b: wgrad_reduce_partials_t4b_body(j.part, j.S, j.cpad, j.dwp, bx, by); break;
+    default: wgrad_reduce_partials_s2c_body(j.part, j.S, j.cpad, j.dwp, j.dbias, bx, by); break;
+  }
+}
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const ReduceBatch b) {
+  int j = 0;
+  while (j + 1 < b.count && (int)blockIdx.x >= b.first[j + 1]) ++j;  // scalar: <= 48 steps
+  const int lb = (int)blockIdx.x - b.first[j], gx = b.job[j].gx;
+  wgrad_reduce_dispatch(b.job[j], lb % gx, lb / gx);
+}
+
+// jobs recorded per stream.  Two jobs of one batch never add into the same dwp / dbias words unless the SAME layer ran twice
+// between two flushes; reduce_record flushes first in that case (the sums are plain read-modify-writes).
+static thread_local bool tl_defer_reduce = false;
+static std::mutex g_reduce_mutex;
+static std::unordered_map<hipStream_t, std::vector<ReduceJob>> g_reduce_jobs;
+
+static int reduce_flush_locked(std::vector<ReduceJob>& jobs, hipStream_t stream) {
+  size_t at = 0;
+  while (at < jobs.size()) {
+    ReduceBatch b{};
+    int blocks = 0;
+    while (at < jobs.size() && b.count < kReduceBatchMax) {
+      b.first[b.count] = blocks;
+      b.job[b.count] = jobs[at];
+      blocks += jobs[at].gx * jobs[at].variant_gy();
+      ++b.count;
+      ++at;
+    }
+    b.first[b.count] = blocks;
+    set_last_kernel("mtrssm::wgrad_reduce_batch_kernel");
+    hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, b);
+  }
+  jobs.clear();
+  return launched("conv_weight_grad_reduce");
+}
+
+int conv_weight_grad_reduce_flush(hipStream_t stream) {
+  std::lock_guard<std::mutex> lock(g_reduce_mutex);
+  auto it = g_reduce_jobs.find(stream);
+  if (it == g_reduce_jobs.end() || it->second.empty()) return MTRSSM_OK;
+  return reduce_flush_locked(it->second, stream);
+}
+
+// the reduce launch of a weight-gradient kernel: now, or recorded for the batch
+static int reduce_now_or_later(int variant, dim3 rgrid, const float* part, int S, int cpad, float* dwp, float* dbias, hipStream_t stream) {
+  ReduceJob j{reinterpret_cast<const float4*>(part), dwp, dbias, S, cpad, variant, (int)rgrid.x, (int)rgrid.y};
+  if (tl_defer_reduce) {
+    std::lock_guard<std::mutex> lock(g_reduce_mutex);
+    auto& jobs = g_reduce_jobs[stream];
+    for (const ReduceJob& o : jobs)
+      if (o.dwp == dwp || o.part == j.part) {  // the same target (or workspace) again: keep the order
+        if (int rc = reduce_flush_locked(jobs, stream)) return rc;
+        break;
+      }
+    jobs.push_back(j);
+    return MTRSSM_OK;
+  }
+  ReduceBatch b{};
+  b.count = 1;
+  b.first[0] = 0;
+  b.first[1] = (int)(rgrid.x * rgrid.y);
+  b.job[0] = j;
+  hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(rgrid.x * rgrid.y), dim3(256), 0, stream, b);
+  return MTRSSM_OK;
+}
+
+}  // namespace mtrssm
 namespace mtrssm {
 
 // ------------------------------------------------------------------------------------------------
@@ -1565,6 +1666,18 @@ static bool no_direct_wgrad() {
 // too small / NULL = the atomics form of the same kernels.  query != NULL: store the bytes this geometry's kernel wants (0 for
 // the kernels without partial sets) and return WITHOUT launching anything.
 int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float* src, const float* src2, int pre_act_a,
+                            float* dwp, float* dbias, void* workspace, size_t workspace_bytes, size_t* query, hipStream_t stream);
+// the same launch with its partial-set reduction recorded for conv_weight_grad_reduce_flush (the workspace must stay untouched
+// until then)
+int conv_weight_grad_deferred_launch(const MtrssmConvGeom* g, const float* a, const float* src, const float* src2, int pre_act_a,
+                                     float* dwp, float* dbias, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  tl_defer_reduce = true;
+  const int rc = conv_weight_grad_launch(g, a, src, src2, pre_act_a, dwp, dbias, workspace, workspace_bytes, nullptr, stream);
+  tl_defer_reduce = false;
+  return rc;
+}
+
+int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float* src, const float* src2, int pre_act_a,
                             float* dwp, float* dbias, void* workspace, size_t workspace_bytes, size_t* query, hipStream_t stream) {
   if (int rc = check_geom(g, "conv_weight_grad")) return rc;
   if (!query && (!a || !src || !dwp || (g->C2 > 0 && !src2))) { set_error("conv_weight_grad: null pointer"); return MTRSSM_EINVAL; }
@@ -1605,8 +1718,7 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
 #undef MTRSSM_WG1_LAUNCH
     if (part) {
       const dim3 rgrid((unsigned)(2 * (g->C / 32) * 256 / 8 + (dbias ? 2 : 0)), cogroups);  // + the two bias blocks
-      if (g->C == 64) hipLaunchKernelGGL(wgrad_reduce_partials1x1_kernel<64>, rgrid, dim3(256), 0, stream, reinterpret_cast<const float4*>(part), (int)grid.x, g->Cpad, dwp, dbias);
-      else hipLaunchKernelGGL(wgrad_reduce_partials1x1_kernel<128>, rgrid, dim3(256), 0, stream, reinterpret_cast<const float4*>(part), (int)grid.x, g->Cpad, dwp, dbias);
+      if (int rc = reduce_now_or_later(g->C == 64 ? kRed1x1_64 : kRed1x1_128, rgrid, part, (int)grid.x, g->Cpad, dwp, dbias, stream)) return rc;
     }
     return launched("conv_weight_grad(1x1 staged)");
   }
@@ -1667,8 +1779,7 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
 #undef MTRSSM_WGRES_LAUNCH
     if (part) {
       const dim3 rgrid((unsigned)(wgres_tile_floats(g->C) / 4 / 8 + (dbias ? 2 : 0)), cogroups);  // + the two bias blocks
-      if (g->C == 64) hipLaunchKernelGGL(wgrad_reduce_partials_kernel<64>, rgrid, dim3(256), 0, stream, reinterpret_cast<const float4*>(part), (int)grid.x, g->Cpad, dwp, dbias);
-      else hipLaunchKernelGGL(wgrad_reduce_partials_kernel<32>, rgrid, dim3(256), 0, stream, reinterpret_cast<const float4*>(part), (int)grid.x, g->Cpad, dwp, dbias);
+      if (int rc = reduce_now_or_later(g->C == 64 ? kRedRes64 : kRedRes32, rgrid, part, (int)grid.x, g->Cpad, dwp, dbias, stream)) return rc;
     }
     return launched("conv_weight_grad(3x3 resident)");
   }
@@ -1726,7 +1837,7 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
     else { if (sp == 2) MTRSSM_WGTHIN_LAUNCH(2, 16) else MTRSSM_WGTHIN_LAUNCH(1, 16) }
 #undef MTRSSM_WGTHIN_LAUNCH
     if (part)
-      hipLaunchKernelGGL(wgrad_reduce_partials_thin_kernel, dim3(dbias ? 9 : 8), dim3(256), 0, stream, reinterpret_cast<const float4*>(part), (int)grid.x, g->Cpad, dwp, dbias);
+      if (int rc = reduce_now_or_later(kRedThin, dim3(dbias ? 9 : 8), part, (int)grid.x, g->Cpad, dwp, dbias, stream)) return rc;
     return launched("conv_weight_grad(3x3 s2 thin staged)");
   }
   if ((g->mfma_split == 1 || g->mfma_split == 2) && g->KH == 4 && g->KW == 4 && g->SS == 2 && g->TS == 1 && g->OFFY == -1 && g->OFFX == -1 &&
@@ -1757,7 +1868,7 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
     else { if (sp == 2) MTRSSM_WGTHINT_LAUNCH(2, 16) else MTRSSM_WGTHINT_LAUNCH(1, 16) }
 #undef MTRSSM_WGTHINT_LAUNCH
     if (part)
-      hipLaunchKernelGGL(wgrad_reduce_partials_thint_kernel, dim3(16), dim3(256), 0, stream, reinterpret_cast<const float4*>(part), (int)grid.x, g->Cpad, dwp);
+      if (int rc = reduce_now_or_later(kRedThinT, dim3(16), part, (int)grid.x, g->Cpad, dwp, nullptr, stream)) return rc;
     return launched("conv_weight_grad(k4 s2 thin staged)");
   }
   if (g->mfma_split >= 1 && g->Cout <= 32 && taps * ctot <= 32 && g->Wq >= 8 && (g->Wq & (g->Wq - 1)) == 0 && (g->Hq * g->Wq) % 16 == 0 &&
@@ -1807,7 +1918,7 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
     else { if (sp == 2) MTRSSM_WGS2_LAUNCH(2, 8) else MTRSSM_WGS2_LAUNCH(1, 8) }
 #undef MTRSSM_WGS2_LAUNCH
     if (part)
-      hipLaunchKernelGGL(wgrad_reduce_partials_s2_kernel, dim3(dbias ? 49 : 48), dim3(256), 0, stream, reinterpret_cast<const float4*>(part), (int)grid.x, g->Cpad, dwp, dbias);
+      if (int rc = reduce_now_or_later(kRedS2, dim3(dbias ? 49 : 48), part, (int)grid.x, g->Cpad, dwp, dbias, stream)) return rc;
     return launched("conv_weight_grad(3x3 s2 staged)");
   }
   if ((g->mfma_split == 1 || g->mfma_split == 2) && g->KH == 4 && g->KW == 4 && g->SS == 2 && g->TS == 1 && g->OFFY == -1 && g->OFFX == -1 &&
@@ -1838,7 +1949,7 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
     else { if (sp == 2) MTRSSM_WGT4_LAUNCH(2, 8) else MTRSSM_WGT4_LAUNCH(1, 8) }
 #undef MTRSSM_WGT4_LAUNCH
     if (part)
-      hipLaunchKernelGGL(wgrad_reduce_partials_t4_kernel, dim3(kWgT4SetFloats / 4 / 8), dim3(256), 0, stream, reinterpret_cast<const float4*>(part), (int)grid.x, g->Cpad, dwp);
+      if (int rc = reduce_now_or_later(kRedT4, dim3(kWgT4SetFloats / 4 / 8), part, (int)grid.x, g->Cpad, dwp, nullptr, stream)) return rc;
     return launched("conv_weight_grad(k4 s2 staged)");
   }
   if ((g->mfma_split == 1 || g->mfma_split == 2) && g->KH == 4 && g->KW == 4 && g->SS == 2 && g->TS == 1 && g->OFFY == -1 && g->OFFX == -1 &&
@@ -1869,7 +1980,7 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
     else { if (sp == 2) MTRSSM_WGT4B_LAUNCH(2, 4) else MTRSSM_WGT4B_LAUNCH(1, 4) }
 #undef MTRSSM_WGT4B_LAUNCH
     if (part)
-      hipLaunchKernelGGL(wgrad_reduce_partials_t4b_kernel, dim3(kWgT4bSetFloats / 4 / 8), dim3(256), 0, stream, reinterpret_cast<const float4*>(part), (int)grid.x, g->Cpad, dwp);
+      if (int rc = reduce_now_or_later(kRedT4b, dim3(kWgT4bSetFloats / 4 / 8), part, (int)grid.x, g->Cpad, dwp, nullptr, stream)) return rc;
     return launched("conv_weight_grad(k4 s2 staged, 64 rows)");
   }
   if ((g->mfma_split == 1 || g->mfma_split == 2) && g->KH == 3 && g->KW == 3 && g->SS == 2 && g->TS == 1 && g->OFFY == -1 && g->OFFX == -1 &&
@@ -1893,7 +2004,7 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
     else { if (sp == 2) MTRSSM_WGS2C_LAUNCH(2, 4) else MTRSSM_WGS2C_LAUNCH(1, 4) }
 #undef MTRSSM_WGS2C_LAUNCH
     if (part)
-      hipLaunchKernelGGL(wgrad_reduce_partials_s2c_kernel, dim3(dbias ? 161 : 160), dim3(256), 0, stream, reinterpret_cast<const float4*>(part), (int)grid.x, g->Cpad, dwp, dbias);
+      if (int rc = reduce_now_or_later(kRedS2c, dim3(dbias ? 161 : 160), part, (int)grid.x, g->Cpad, dwp, dbias, stream)) return rc;
     return launched("conv_weight_grad(3x3 s2 staged, 16 -> 32)");
   }
   MTRSSM_WGRAD_NO_PART

@@ -335,14 +335,14 @@ __global__ __launch_bounds__(64 * 2 * (C / 32), 1) void conv3x3_wgrad_resident_k
 // slices met in LDS; 8 lanes read one 128-byte line.  dwp is read-modified-written without atomics: launches that
 // accumulate into one dwp chunk are ordered by their stream.
 template <int C>
-__global__ __launch_bounds__(256) void wgrad_reduce_partials_kernel(const float4* __restrict__ part, const int S, const int cpad,
-                                                                    float* __restrict__ dwp, float* __restrict__ dbias) {
+__device__ __forceinline__ void wgrad_reduce_partials_body(const float4* __restrict__ part, const int S, const int cpad,
+                                                                    float* __restrict__ dwp, float* __restrict__ dbias, const int bx, const int by) {
   constexpr int SET4 = wgres_set_floats(C) / 4, TILE4 = wgres_tile_floats(C) / 4;
   constexpr int NL = 8, NG = 32;  // 8 float4 columns (one 128-byte line per set) x 32 slices of S per workgroup
   __shared__ float4 red[NG][NL];
   const int li = threadIdx.x & (NL - 1), sg = threadIdx.x / NL;
-  const int f = blockIdx.x * NL + li;  // host: grid.x * 8 == TILE4 (+ 16: the two bias blocks, launched when dbias != NULL)
-  const float4* const p = part + (size_t)blockIdx.y * S * SET4 + f;
+  const int f = bx * NL + li;  // host: grid.x * 8 == TILE4 (+ 16: the two bias blocks, launched when dbias != NULL)
+  const float4* const p = part + (size_t)by * S * SET4 + f;
   float4 acc4[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) acc4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_partials_kernel(const float4
 #pragma unroll
     for (int k = 1; k < NG; ++k) { t.x += red[k][li].x; t.y += red[k][li].y; t.z += red[k][li].z; t.w += red[k][li].w; }
     if (f >= TILE4) {  // block-uniform: the bias sums of channels 4 (f - TILE4) .. + 3 of this co group
-      float* const o = dbias + blockIdx.y * 64 + 4 * (f - TILE4);
+      float* const o = dbias + by * 64 + 4 * (f - TILE4);
       o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w;
       return;
     }
@@ -374,11 +374,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_partials_kernel(const float4
     const int lane = f & 63, gq = (f >> 6) & 3, wj = f >> 8, j = wj % 9, wave = wj / 9;
     const int il = lane & 31, kl = lane >> 5, tci = wave >> 1, half = wave & 1;
     const int k = j < 5 ? j : j - 5, tap = k < 3 ? (half ? 6 : 0) + k : (k == 3 ? (half ? 5 : 3) : 4);
-    const int row = blockIdx.y * 64 + (j < 5 ? half : half ^ 1) * 32 + 8 * gq + 4 * kl;
+    const int row = by * 64 + (j < 5 ? half : half ^ 1) * 32 + 8 * gq + 4 * kl;
     float* const o = dwp + ((size_t)row * 9 + tap) * cpad + tci * 32 + il;
     const size_t rs = (size_t)9 * cpad;
     o[0] += t.x; o[rs] += t.y; o[2 * rs] += t.z; o[3 * rs] += t.w;
   }
+}
+template <int C>
+__global__ __launch_bounds__(256) void wgrad_reduce_partials_kernel(const float4* __restrict__ part, const int S, const int cpad,
+                                                                    float* __restrict__ dwp, float* __restrict__ dbias) {
+  wgrad_reduce_partials_body<C>(part, S, cpad, dwp, dbias, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -553,16 +558,16 @@ __global__ __launch_bounds__(512, 1) void conv1x1_wgrad_staged_kernel(
 // Partial tiles of conv1x1_wgrad_staged_kernel (part [cogroups][S][8 waves][256] float4, accumulator order) into dwp; a
 // workgroup's waves w and w + NTILE hold the same tile (k-halves), so the kernel sums 8 / NTILE x S slices per tile.
 template <int C>
-__global__ __launch_bounds__(256) void wgrad_reduce_partials1x1_kernel(const float4* __restrict__ part, const int S, const int cpad,
-                                                                       float* __restrict__ dwp, float* __restrict__ dbias) {
+__device__ __forceinline__ void wgrad_reduce_partials1x1_body(const float4* __restrict__ part, const int S, const int cpad,
+                                                                       float* __restrict__ dwp, float* __restrict__ dbias, const int bx, const int by) {
   constexpr int NTILE = 2 * (C / 32), KS = 8 / NTILE, TILE4 = 256, SET4 = kWg1x1SetFloats / 4;
   constexpr int NL = 8, NG = 32;  // 8 float4 columns (one 128-byte line per slice) x 32 slice groups per workgroup
   __shared__ float4 red[NG][NL];
   const int li = threadIdx.x & (NL - 1), sg = threadIdx.x / NL;
-  const int f = blockIdx.x * NL + li;  // float4 of the NTILE tiles; host: grid.x * 8 == NTILE * 256 (+ 16: two bias blocks)
+  const int f = bx * NL + li;  // float4 of the NTILE tiles; host: grid.x * 8 == NTILE * 256 (+ 16: two bias blocks)
   const bool bias = f >= NTILE * TILE4;  // block-uniform
   const int tile = f / TILE4, ft = f - tile * TILE4;
-  const float4* const p = part + (size_t)blockIdx.y * S * SET4 + (bias ? (size_t)(8 * TILE4 + (f - NTILE * TILE4)) : (size_t)tile * TILE4 + ft);
+  const float4* const p = part + (size_t)by * S * SET4 + (bias ? (size_t)(8 * TILE4 + (f - NTILE * TILE4)) : (size_t)tile * TILE4 + ft);
   float4 acc4[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) acc4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -589,15 +594,20 @@ __global__ __launch_bounds__(256) void wgrad_reduce_partials1x1_kernel(const flo
 #pragma unroll
     for (int k = 1; k < NG; ++k) { v.x += red[k][li].x; v.y += red[k][li].y; v.z += red[k][li].z; v.w += red[k][li].w; }
     if (bias) {
-      float* const o = dbias + blockIdx.y * 64 + 4 * (f - NTILE * TILE4);
+      float* const o = dbias + by * 64 + 4 * (f - NTILE * TILE4);
       o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w;
       return;
     }
     const int lane = ft & 63, gq = ft >> 6, il = lane & 31, kl = lane >> 5;
     const int tco = tile & 1, tci = tile >> 1;
-    float* const o = dwp + (size_t)(blockIdx.y * 64 + tco * 32 + 8 * gq + 4 * kl) * cpad + tci * 32 + il;
+    float* const o = dwp + (size_t)(by * 64 + tco * 32 + 8 * gq + 4 * kl) * cpad + tci * 32 + il;
     o[0] += v.x; o[cpad] += v.y; o[2 * (size_t)cpad] += v.z; o[3 * (size_t)cpad] += v.w;
   }
+}
+template <int C>
+__global__ __launch_bounds__(256) void wgrad_reduce_partials1x1_kernel(const float4* __restrict__ part, const int S, const int cpad,
+                                                                       float* __restrict__ dwp, float* __restrict__ dbias) {
+  wgrad_reduce_partials1x1_body<C>(part, S, cpad, dwp, dbias, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -792,12 +802,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_wgrad_staged_kernel(
 }
 
 // Partial sets of conv3x3s2_wgrad_staged_kernel into dwp / dbias: 72 columns x 16 rows, two k-halves per workgroup.
-__global__ __launch_bounds__(256) void wgrad_reduce_partials_s2_kernel(const float4* __restrict__ part, const int S, const int cpad,
-                                                                       float* __restrict__ dwp, float* __restrict__ dbias) {
+__device__ __forceinline__ void wgrad_reduce_partials_s2_body(const float4* __restrict__ part, const int S, const int cpad,
+                                                                       float* __restrict__ dwp, float* __restrict__ dbias, const int bx, const int by) {
   constexpr int SET4 = kWgS2SetFloats / 4, NL = 8, NG = 32;
   __shared__ float4 red[NG][NL];
   const int li = threadIdx.x & (NL - 1), sg = threadIdx.x / NL;
-  const int f = blockIdx.x * NL + li;  // float4 (ct * 2 + half) * 64 + lane of the three column tiles: 384 of them, then 4 bias float4
+  const int f = bx * NL + li;  // float4 (ct * 2 + half) * 64 + lane of the three column tiles: 384 of them, then 4 bias float4
   const bool bias = f >= 384;          // block-uniform (48 tile blocks, then one bias block of which 4 columns are used)
   if (bias && f >= 388) {              // padding columns of the bias block: nothing to read
     red[sg][li] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -842,6 +852,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_partials_s2_kernel(const flo
       o[0] += v.x; o[rs] += v.y; o[2 * rs] += v.z; o[3 * rs] += v.w;
     }
   }
+}
+__global__ __launch_bounds__(256) void wgrad_reduce_partials_s2_kernel(const float4* __restrict__ part, const int S, const int cpad,
+                                                                       float* __restrict__ dwp, float* __restrict__ dbias) {
+  wgrad_reduce_partials_s2_body(part, S, cpad, dwp, dbias, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1004,12 +1018,12 @@ __global__ __launch_bounds__(512, 1) void convt4s2_wgrad_staged_kernel(
 }
 
 // Partial sets of convt4s2_wgrad_staged_kernel into dwp.
-__global__ __launch_bounds__(256) void wgrad_reduce_partials_t4_kernel(const float4* __restrict__ part, const int S, const int cpad,
-                                                                       float* __restrict__ dwp) {
+__device__ __forceinline__ void wgrad_reduce_partials_t4_body(const float4* __restrict__ part, const int S, const int cpad,
+                                                                       float* __restrict__ dwp, const int bx, const int by) {
   constexpr int SET4 = kWgT4SetFloats / 4, NL = 8, NG = 32;
   __shared__ float4 red[NG][NL];
   const int li = threadIdx.x & (NL - 1), sg = threadIdx.x / NL;
-  const int f = blockIdx.x * NL + li;  // host: grid.x * 8 == SET4
+  const int f = bx * NL + li;  // host: grid.x * 8 == SET4
   const float4* const p = part + f;
   float4 acc4[4];
 #pragma unroll
@@ -1039,6 +1053,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_partials_t4_kernel(const flo
     const size_t rs = (size_t)16 * cpad;
     o[0] += v.x; o[rs] += v.y; o[2 * rs] += v.z; o[3 * rs] += v.w;
   }
+}
+__global__ __launch_bounds__(256) void wgrad_reduce_partials_t4_kernel(const float4* __restrict__ part, const int S, const int cpad,
+                                                                       float* __restrict__ dwp) {
+  wgrad_reduce_partials_t4_body(part, S, cpad, dwp, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1211,12 +1229,12 @@ __global__ __launch_bounds__(512, 1) void convt4s2b_wgrad_staged_kernel(
 }
 
 // Partial sets of convt4s2b_wgrad_staged_kernel into dwp.
-__global__ __launch_bounds__(256) void wgrad_reduce_partials_t4b_kernel(const float4* __restrict__ part, const int S, const int cpad,
-                                                                        float* __restrict__ dwp) {
+__device__ __forceinline__ void wgrad_reduce_partials_t4b_body(const float4* __restrict__ part, const int S, const int cpad,
+                                                                        float* __restrict__ dwp, const int bx, const int by) {
   constexpr int SET4 = kWgT4bSetFloats / 4, NL = 8, NG = 32;
   __shared__ float4 red[NG][NL];
   const int li = threadIdx.x & (NL - 1), sg = threadIdx.x / NL;
-  const int f = blockIdx.x * NL + li;  // host: grid.x * 8 == SET4
+  const int f = bx * NL + li;  // host: grid.x * 8 == SET4
   const float4* const p = part + f;
   float4 acc4[4];
 #pragma unroll
@@ -1246,6 +1264,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_partials_t4b_kernel(const fl
     const size_t rs = (size_t)16 * cpad;
     o[0] += v.x; o[rs] += v.y; o[2 * rs] += v.z; o[3 * rs] += v.w;
   }
+}
+__global__ __launch_bounds__(256) void wgrad_reduce_partials_t4b_kernel(const float4* __restrict__ part, const int S, const int cpad,
+                                                                        float* __restrict__ dwp) {
+  wgrad_reduce_partials_t4b_body(part, S, cpad, dwp, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1432,12 +1454,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2_thin_wgrad_staged_kernel(
 }
 
 // Partial sets of conv3x3s2_thin_wgrad_staged_kernel into dwp / dbias: one tile, eight k-parts per workgroup.
-__global__ __launch_bounds__(256) void wgrad_reduce_partials_thin_kernel(const float4* __restrict__ part, const int S, const int cpad,
-                                                                         float* __restrict__ dwp, float* __restrict__ dbias) {
+__device__ __forceinline__ void wgrad_reduce_partials_thin_body(const float4* __restrict__ part, const int S, const int cpad,
+                                                                         float* __restrict__ dwp, float* __restrict__ dbias, const int bx, const int by) {
   constexpr int SET4 = kWgThinSetFloats / 4, NL = 8, NG = 32;
   __shared__ float4 red[NG][NL];
   const int li = threadIdx.x & (NL - 1), sg = threadIdx.x / NL;
-  const int f = blockIdx.x * NL + li;  // lane's float4 (64 of them: 8 blocks), then the bias block (2 float4 used)
+  const int f = bx * NL + li;  // lane's float4 (64 of them: 8 blocks), then the bias block (2 float4 used)
   const bool bias = f >= 64;           // block-uniform
   float4 acc4[2];
   acc4[0] = acc4[1] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1477,6 +1499,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_partials_thin_kernel(const f
       o[0] += v.x; o[rs] += v.y; o[2 * rs] += v.z; o[3 * rs] += v.w;
     }
   }
+}
+__global__ __launch_bounds__(256) void wgrad_reduce_partials_thin_kernel(const float4* __restrict__ part, const int S, const int cpad,
+                                                                         float* __restrict__ dwp, float* __restrict__ dbias) {
+  wgrad_reduce_partials_thin_body(part, S, cpad, dwp, dbias, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1626,12 +1652,12 @@ __global__ __launch_bounds__(512, 1) void convt4s2_thin_wgrad_staged_kernel(
 }
 
 // Partial sets of convt4s2_thin_wgrad_staged_kernel into dwp: one tile, eight k-parts per workgroup.
-__global__ __launch_bounds__(256) void wgrad_reduce_partials_thint_kernel(const float4* __restrict__ part, const int S, const int cpad,
-                                                                          float* __restrict__ dwp) {
+__device__ __forceinline__ void wgrad_reduce_partials_thint_body(const float4* __restrict__ part, const int S, const int cpad,
+                                                                          float* __restrict__ dwp, const int bx, const int by) {
   constexpr int SET4 = kWgThinTSetFloats / 4, NL = 8, NG = 32;
   __shared__ float4 red[NG][NL];
   const int li = threadIdx.x & (NL - 1), sg = threadIdx.x / NL;
-  const int f = blockIdx.x * NL + li;  // half * 64 + lane: 128 of them (host: 16 blocks)
+  const int f = bx * NL + li;  // half * 64 + lane: 128 of them (host: 16 blocks)
   const float4* const p = part + f;
   float4 acc4[2];
   acc4[0] = acc4[1] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1662,6 +1688,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_partials_thint_kernel(const 
       o[0] += v.x; o[rs] += v.y; o[2 * rs] += v.z; o[3 * rs] += v.w;
     }
   }
+}
+__global__ __launch_bounds__(256) void wgrad_reduce_partials_thint_kernel(const float4* __restrict__ part, const int S, const int cpad,
+                                                                          float* __restrict__ dwp) {
+  wgrad_reduce_partials_thint_body(part, S, cpad, dwp, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1828,12 +1858,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3s2c_wgrad_staged_kernel(
 }
 
 // Partial sets of conv3x3s2c_wgrad_staged_kernel into dwp / dbias.
-__global__ __launch_bounds__(256) void wgrad_reduce_partials_s2c_kernel(const float4* __restrict__ part, const int S, const int cpad,
-                                                                        float* __restrict__ dwp, float* __restrict__ dbias) {
+__device__ __forceinline__ void wgrad_reduce_partials_s2c_body(const float4* __restrict__ part, const int S, const int cpad,
+                                                                        float* __restrict__ dwp, float* __restrict__ dbias, const int bx, const int by) {
   constexpr int SET4 = kWgS2cSetFloats / 4, NL = 8, NG = 32;
   __shared__ float4 red[NG][NL];
   const int li = threadIdx.x & (NL - 1), sg = threadIdx.x / NL;
-  const int f = blockIdx.x * NL + li;  // float4 of the five column tiles: 1280 (160 blocks), then 8 bias float4 (one block)
+  const int f = bx * NL + li;  // float4 of the five column tiles: 1280 (160 blocks), then 8 bias float4 (one block)
   const bool bias = f >= 1280;         // block-uniform
   const float4* const p = part + (bias ? (size_t)(8 * 256 + (f - 1280)) : (size_t)f);
   float4 acc4[4];
@@ -1872,6 +1902,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_partials_s2c_kernel(const fl
       o[0] += v.x; o[rs] += v.y; o[2 * rs] += v.z; o[3 * rs] += v.w;
     }
   }
+}
+__global__ __launch_bounds__(256) void wgrad_reduce_partials_s2c_kernel(const float4* __restrict__ part, const int S, const int cpad,
+                                                                        float* __restrict__ dwp, float* __restrict__ dbias) {
+  wgrad_reduce_partials_s2c_body(part, S, cpad, dwp, dbias, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 }  // namespace mtrssm

@@ -89,6 +89,8 @@ def test_invalid_arguments_are_rejected_without_a_launch() -> None:
     # round-3 entries
     assert lib.mtrssm_conv_weight_grad_workspace_bytes(C.byref(_lib.ConvGeom()), 0) == -1  # all-zero geometry
     assert lib.mtrssm_conv_weight_grad(C.byref(_lib.ConvGeom()), None, None, None, 0, None, None, None, 0, None) == -1
+    assert lib.mtrssm_conv_weight_grad_deferred(C.byref(_lib.ConvGeom()), None, None, None, 0, None, None, None, 0, None) == -1
+    assert lib.mtrssm_conv_weight_grad_reduce(None) == 0  # nothing recorded: no launch
     large = _lib.MrssmDims(32, 100, 1024, 1024, 16, 8, 2, 1, 0.2, 0.8, 0, 0)
     assert lib.mtrssm_mrssm_wide_supported(C.byref(large), 3) == 0  # no device here: the grid cannot be sized
     assert lib.mtrssm_mrssm_wide_workspace_bytes(C.byref(large), 3) > 60e6  # six bytes per weight of the ~10 M scan weights
