@@ -445,13 +445,55 @@ def mrssm_posterior_rollout(  # noqa: PLR0913
             "prior_stoch": prior_stoch if u_prior is not None else None, "kl": kl}
 
 
+def _st_sample(logits: Tensor, cats: int, classes: int, u: Tensor) -> tuple[Tensor, Tensor]:
+    """Straight-through one-hot sample of K C-way categoricals from flat logits and given uniforms (inverse CDF on the detached
+    probabilities, ``onehot + probs - probs.detach()``: distributions.MultiOneHot.rsample)."""
+    from multimodal_mtrssm_amd.distributions import onehot_from_uniforms  # noqa: PLC0415
+
+    probs = torch.softmax(logits.reshape(*logits.shape[:-1], cats, classes), dim=-1)
+    onehot = onehot_from_uniforms(probs.detach(), u)
+    return (onehot + (probs - probs.detach())).flatten(start_dim=-2), probs
+
+
+def _mrssm_prior_rollout_differentiable(transition, actions: Tensor, deter0: Tensor, stoch0: Tensor,  # noqa: ANN001
+                                        u_prior: Tensor | None) -> dict[str, Tensor]:
+    """``rollout_transition`` with autograd on (``core.py:170-185`` = T times ``Transition.forward``, ``networks.py:150-173``):
+    MLP([action, stoch]) -> GRUCell -> MLP -> straight-through sample, step by step.  Every Linear runs on the library's own
+    GEMM with its fused epilogues (``linear.py``; the MLPs through ``networks.MLP.forward``), the GRU gate arithmetic and the
+    sample are elementwise torch ops, and autograd chains them -- a composed path for the rare differentiable use (the
+    reference itself only calls this method from callbacks, without gradients); the fused scan kernel serves inference."""
+    factory = transition.distribution_factory
+    cats, classes = factory.category_size, factory.class_size
+    B, T, _ = actions.shape
+    cell = transition.rnn_cell
+    if u_prior is None:
+        u_prior = torch.rand(B, T, cats, device=actions.device)
+    actions, deter, stoch, u_prior = actions.float(), deter0.float(), stoch0.float(), u_prior.float()
+    deters, logits_all, stochs = [], [], []
+    for t in range(T):
+        x = transition.action_state_projector(_c(torch.cat([actions[:, t], stoch], dim=-1)))
+        gi = linear(x, cell.weight_ih, cell.bias_ih)
+        gh = linear(_c(deter), cell.weight_hh, cell.bias_hh)
+        i_r, i_z, i_n = gi.chunk(3, dim=-1)
+        h_r, h_z, h_n = gh.chunk(3, dim=-1)
+        r, z = torch.sigmoid(i_r + h_r), torch.sigmoid(i_z + h_z)
+        deter = (1.0 - z) * torch.tanh(i_n + r * h_n) + z * deter   # torch.nn.GRUCell's update
+        logits = transition.rnn_to_prior_projector(_c(deter))
+        stoch, _ = _st_sample(logits, cats, classes, u_prior[:, t])
+        deters.append(deter)
+        logits_all.append(logits)
+        stochs.append(stoch)
+    return {"deter": torch.stack(deters, 1), "prior_logits": torch.stack(logits_all, 1), "prior_stoch": torch.stack(stochs, 1)}
+
+
 def mrssm_prior_rollout(transition, actions: Tensor, deter0: Tensor, stoch0: Tensor, u_prior: Tensor | None,  # noqa: ANN001
                         *, rows_per_block: int = 0, threads: int = 0) -> dict[str, Tensor]:
-    """``BaseRSSM.rollout_transition`` (``core.py:170-185``): prior-only scan, inference (no autograd)."""
+    """``BaseRSSM.rollout_transition`` (``core.py:170-185``): the prior-only scan.  Under ``torch.no_grad()`` (how the reference's
+    callbacks call it, mrssm/callback.py:184) ONE fused scan kernel; with autograd on, the step-by-step differentiable form."""
     lib = _lib.load()
-    if torch.is_grad_enabled() and any(p.requires_grad for p in transition.parameters()) and (actions.requires_grad or deter0.requires_grad):
-        msg = "the prior-only HIP rollout is an inference path (callbacks / evaluation): call it under torch.no_grad()"
-        raise NotImplementedError(msg)
+    if torch.is_grad_enabled() and (actions.requires_grad or deter0.requires_grad or stoch0.requires_grad
+                                    or any(p.requires_grad for p in transition.parameters())):
+        return _mrssm_prior_rollout_differentiable(transition, actions, deter0, stoch0, u_prior)
     with torch.no_grad():
         factory = transition.distribution_factory
         K, Cc = factory.category_size, factory.class_size
@@ -719,10 +761,49 @@ def mmtrssm_posterior_rollout(model, actions: Tensor, audio_embed: Tensor, visio
     return res
 
 
+def _mtrnn_step(rnn, x: Tensor, deter: Tensor, hidden: Tensor) -> tuple[Tensor, Tensor]:  # noqa: ANN001
+    """``MTRNN.forward`` (``mmtrssm/mopoe_mmtrssm/core.py:59-60``): hidden = (1 - 1/tau) hidden + (W_d d + W_x x) / tau, d = tanh(hidden)."""
+    pre = linear(_c(deter), rnn._d2h.weight, rnn._d2h.bias) + linear(_c(x), rnn._input2h.weight, rnn._input2h.bias)  # noqa: SLF001
+    hidden = (1.0 - 1.0 / rnn.tau) * hidden + pre / rnn.tau
+    return torch.tanh(hidden), hidden
+
+
+def _mmtrssm_prior_rollout_differentiable(model, actions: Tensor, state0: dict[str, Tensor],  # noqa: ANN001
+                                          noise: dict[str, Tensor | None]) -> dict[str, Tensor]:
+    """``MoPoE_MMTRSSM.rollout_transition`` with autograd on (``mmtrssm core.py:496-544``), step by step on the library's GEMMs --
+    the composed counterpart of ``_mrssm_prior_rollout_differentiable``."""
+    kl, cl = model.l_dist.category_size, model.l_dist.class_size
+    kh, ch = model.h_dist.category_size, model.h_dist.class_size
+    B, T, _ = actions.shape
+    u_l, u_h = noise.get("u_prior_l"), noise.get("u_prior_h")
+    u_l = torch.rand(B, T, kl, device=actions.device) if u_l is None else u_l.float()
+    u_h = torch.rand(B, T, kh, device=actions.device) if u_h is None else u_h.float()
+    st = {k: state0[k].float() for k in ("deter_l", "deter_h", "hidden_l", "hidden_h", "stoch_l", "stoch_h")}
+    deter_l, deter_h, hidden_l, hidden_h, stoch_l, stoch_h = (st[k] for k in ("deter_l", "deter_h", "hidden_l", "hidden_h", "stoch_l", "stoch_h"))
+    names = ("deter_l", "deter_h", "hidden_l", "hidden_h", "prior_logits_l", "prior_logits_h", "prior_stoch_l", "prior_stoch_h")
+    keep: dict[str, list[Tensor]] = {k: [] for k in names}
+    actions = actions.float()
+    for t in range(T):
+        deter_l, hidden_l = _mtrnn_step(model.l_rnn, torch.cat([actions[:, t], stoch_l, stoch_h], dim=-1), deter_l, hidden_l)
+        logits_l = model.l_prior(_c(deter_l))
+        deter_h, hidden_h = _mtrnn_step(model.h_rnn, stoch_h, deter_h, hidden_h)
+        logits_h = model.h_prior(_c(deter_h))
+        stoch_h, _ = _st_sample(logits_h, kh, ch, u_h[:, t])
+        stoch_l, _ = _st_sample(logits_l, kl, cl, u_l[:, t])
+        for k, v in zip(names, (deter_l, deter_h, hidden_l, hidden_h, logits_l, logits_h, stoch_l, stoch_h), strict=True):
+            keep[k].append(v)
+    return {k: torch.stack(v, dim=1) for k, v in keep.items()}
+
+
 def mmtrssm_prior_rollout(model, actions: Tensor, state0: dict[str, Tensor], noise: dict[str, Tensor | None],  # noqa: ANN001
                           *, rows_per_block: int = 0, threads: int = 0) -> dict[str, Tensor]:
-    """``MoPoE_MMTRSSM.rollout_transition`` (``core.py:496-544``): prior-only scan, inference."""
+    """``MoPoE_MMTRSSM.rollout_transition`` (``core.py:496-544``): prior-only scan; one fused kernel under ``torch.no_grad()``,
+    the step-by-step differentiable form with autograd on."""
     lib = _lib.load()
+    if torch.is_grad_enabled() and (actions.requires_grad or any(v is not None and v.requires_grad for v in state0.values())
+                                    or any(p.requires_grad for m in (model.l_rnn, model.h_rnn, model.l_prior, model.h_prior)
+                                           for p in m.parameters())):
+        return _mmtrssm_prior_rollout_differentiable(model, actions, state0, noise)
     with torch.no_grad():
         LD, HD = model.ld_dim, model.hd_dim
         B, T, A = actions.shape

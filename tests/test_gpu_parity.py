@@ -176,6 +176,78 @@ def test_mmtrssm_rollout_matches_golden(name: str, lib_loaded: None) -> None:
         assert joined.feature.shape == post.feature.shape
 
 
+@pytest.mark.parametrize("name", list(GOLDEN_CASES))
+def test_prior_rollout_is_differentiable_and_matches_the_oracle(name: str, lib_loaded: None) -> None:
+    """``rollout_transition`` with autograd on (reference ``core.py:170-185`` / mmtrssm ``core.py:496-544`` are plain differentiable
+    loops): values equal the fused inference kernel's, and the gradients of a fixed random functional of every output -- with
+    respect to the parameters, the actions and the start state -- equal the oracle's autograd on the host."""
+    from multimodal_mtrssm_amd import scan
+
+    case = CASES[name]
+    d = case.dims
+    fx = load_golden(name)
+    oracle = build_model(case)
+    model = product_from_case(case, oracle, DEV)
+    batch, noise = golden_batch(fx), golden_noise(fx)
+    q = case.query
+    n = case.steps - q
+    gen = torch.Generator().manual_seed(5)
+    actions = batch[0][:, q:].clone()
+    mr = case.kind == "mrssm"
+    with torch.no_grad():
+        if mr:
+            s0 = oracle.initial_state(batch[1][:, 0], batch[2][:, 0], noise["u_init"])
+            state0 = {"deter": s0["deter"], "stoch": s0["stoch"]}
+            u = {"u_prior": noise["u_trans"][:, :n]}
+        else:
+            s0 = oracle.initial_state(batch[1][:, 0], batch[2][:, 0], noise["u_init_h"], noise["u_init_l"])
+            state0 = {k: s0[k] for k in ("deter_l", "deter_h", "hidden_l", "hidden_h", "stoch_l", "stoch_h")}
+            u = {"u_prior_h": noise["u_trans_h"][:, :n], "u_prior_l": noise["u_trans_l"][:, :n]}
+
+    def run(on_gpu: bool):  # noqa: ANN202
+        dev = DEV if on_gpu else "cpu"
+        a = actions.detach().clone().to(dev).requires_grad_(True)
+        st = {k: v.detach().clone().to(dev).requires_grad_(not k.startswith("stoch")) for k, v in state0.items()}
+        un = {k: v.to(dev) for k, v in u.items()}
+        if on_gpu:
+            out = (scan.mrssm_prior_rollout(model.transition, a, st["deter"], st["stoch"], un["u_prior"]) if mr
+                   else scan.mmtrssm_prior_rollout(model, a, st, un))
+            with torch.no_grad():  # the fused inference kernel on the same inputs
+                fused = (scan.mrssm_prior_rollout(model.transition, a.detach(), st["deter"].detach(), st["stoch"], un["u_prior"]) if mr
+                         else scan.mmtrssm_prior_rollout(model, a.detach(), {k: v.detach() for k, v in st.items()}, un))
+            for k, v in fused.items():
+                np.testing.assert_allclose(_np(out[k]), _np(v), atol=1e-5, err_msg=f"composed vs fused {k}")
+        else:
+            out = oracle.rollout_transition(a, st, un["u_prior"]) if mr else oracle.rollout_transition(a, st, un)
+        gen.manual_seed(5)
+        loss = sum((v * torch.randn(v.shape, generator=gen).to(dev)).sum() for _, v in sorted(out.items()))
+        for p_ in (model.parameters() if on_gpu else oracle.parameters()):
+            p_.grad = None
+        loss.backward()
+        return out, a.grad, {k: v.grad for k, v in st.items() if v.requires_grad}
+
+    ref_out, ref_ga, ref_gs = run(False)
+    out, ga, gs = run(True)
+    torch.cuda.synchronize()
+    for k in ref_out:
+        np.testing.assert_allclose(_np(out[k]), ref_out[k].detach().numpy(), atol=1e-5, err_msg=k)
+    scale = float(ref_ga.abs().max()) + 1e-12
+    np.testing.assert_allclose(_np(ga), ref_ga.numpy(), rtol=2e-4, atol=2e-4 * scale, err_msg="d actions")
+    for k, g in ref_gs.items():
+        scale = float(g.abs().max()) + 1e-12
+        np.testing.assert_allclose(_np(gs[k]), g.numpy(), rtol=2e-4, atol=2e-4 * scale, err_msg=f"d {k}")
+    got = dict(model.named_parameters())
+    seen = 0
+    for k, p_ in oracle.named_parameters():
+        if p_.grad is None:
+            continue
+        assert got[k].grad is not None, k
+        scale = float(p_.grad.abs().max()) + 1e-12
+        np.testing.assert_allclose(_np(got[k].grad), p_.grad.numpy(), rtol=2e-4, atol=2e-4 * scale, err_msg=f"grad {k}")
+        seen += 1
+    assert seen >= 6  # the prior path's Linear layers (and nothing of the posterior / encoders)
+
+
 # ---------------------------------------------------------------------------------------------
 # BASELINE "Large" core dims: the > 64 KiB dynamic-LDS path of the scan kernels (GPU vs oracle, no fixture)
 # ---------------------------------------------------------------------------------------------
