@@ -1251,6 +1251,14 @@ static bool patch_limit_768() {
   return on;
 }
 
+// hipFuncSetAttribute is per device: the "done" flags of the launch macros are kept per device (a process that drives several
+// GPUs -- not this package's one-process-per-GPU model, but nothing forbids it -- sets the attribute on each)
+static int device_slot() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return dev & 63;
+}
+
 static int cu_count() {
   static const int n = [] {
     int dev = 0, v = 0;
@@ -1349,7 +1357,7 @@ static int launch_split(const SplitPlan& pl, size_t lds, const GatherProblem& pa
     const dim3 rgrid((unsigned)(qa.nx + qb.nx));
 #define MTRSSM_RES_LAUNCH_E(CIN_, NCT_, KS_, EPI_)                                                                   \
   {                                                                                                                   \
-    static bool attr_done = false;                                                                                    \
+    static bool attr_done_dev[64] = {}; bool& attr_done = attr_done_dev[device_slot()];                                                                                    \
     const size_t rl = res_lds_bytes<CIN_, NCT_, KS_>();                                                               \
     if (!attr_done) {                                                                                                 \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_resident_kernel<CIN_, NCT_, KS_, EPI_>),        \
@@ -1408,7 +1416,7 @@ static int launch_split(const SplitPlan& pl, size_t lds, const GatherProblem& pa
   const int sp = pl.sp;
 #define MTRSSM_ATTR_ONCE(K_)                                                                                         \
   {                                                                                                                   \
-    static bool attr_done = false;                                                                                    \
+    static bool attr_done_dev[64] = {}; bool& attr_done = attr_done_dev[device_slot()];                                                                                    \
     if (!attr_done) {                                                                                                 \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(K_), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
       attr_done = true;                                                                                               \
@@ -1701,7 +1709,7 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
     MTRSSM_WGRAD_PART((size_t)grid.x * cogroups * kWg1x1SetFloats * sizeof(float))
 #define MTRSSM_WG1_LAUNCH(SP_, C_)                                                                                              \
   {                                                                                                                             \
-    static bool attr_done = false; /* once per instantiation: never while another stream may be running the kernel */       \
+    static bool attr_done_dev[64] = {}; bool& attr_done = attr_done_dev[device_slot()]; /* once per instantiation: never while another stream may be running the kernel */       \
     constexpr int lds_b = wg1x1_lds_bytes<SP_, C_>();                                                                           \
     if (!attr_done) {                                                                                                           \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_wgrad_staged_kernel<SP_, C_>),                            \
@@ -1757,7 +1765,7 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
     MTRSSM_WGRAD_PART((size_t)grid.x * cogroups * set_floats * sizeof(float))
 #define MTRSSM_WGRES_LAUNCH(SP_, C_, W_)                                                                                         \
   {                                                                                                                             \
-    static bool attr_done = false; /* once per instantiation: never while another stream may be running the kernel */       \
+    static bool attr_done_dev[64] = {}; bool& attr_done = attr_done_dev[device_slot()]; /* once per instantiation: never while another stream may be running the kernel */       \
     constexpr int lds_b = wgres_lds_bytes<SP_, C_, W_>();                                                                       \
     if (!attr_done) {                                                                                                           \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_resident_kernel<SP_, C_, W_>),                       \
@@ -1821,7 +1829,7 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
     MTRSSM_WGRAD_PART((size_t)grid.x * kWgThinSetFloats * sizeof(float))
 #define MTRSSM_WGTHIN_LAUNCH(SP_, W_)                                                                                            \
   {                                                                                                                             \
-    static bool attr_done = false; /* once per instantiation: never while another stream may be running the kernel */       \
+    static bool attr_done_dev[64] = {}; bool& attr_done = attr_done_dev[device_slot()]; /* once per instantiation: never while another stream may be running the kernel */       \
     constexpr int lds_b = wgthin_lds_bytes<SP_, W_>();                                                                          \
     if (!attr_done) {                                                                                                           \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3s2_thin_wgrad_staged_kernel<SP_, W_>),                      \
@@ -1852,7 +1860,7 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
     MTRSSM_WGRAD_PART((size_t)grid.x * kWgThinTSetFloats * sizeof(float))
 #define MTRSSM_WGTHINT_LAUNCH(SP_, W_)                                                                                           \
   {                                                                                                                             \
-    static bool attr_done = false; /* once per instantiation: never while another stream may be running the kernel */       \
+    static bool attr_done_dev[64] = {}; bool& attr_done = attr_done_dev[device_slot()]; /* once per instantiation: never while another stream may be running the kernel */       \
     constexpr int lds_b = wgthint_lds_bytes<SP_, W_>();                                                                         \
     if (!attr_done) {                                                                                                           \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convt4s2_thin_wgrad_staged_kernel<SP_, W_>),                       \
@@ -1902,7 +1910,7 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
     MTRSSM_WGRAD_PART((size_t)grid.x * kWgS2SetFloats * sizeof(float))
 #define MTRSSM_WGS2_LAUNCH(SP_, W_)                                                                                              \
   {                                                                                                                             \
-    static bool attr_done = false; /* once per instantiation: never while another stream may be running the kernel */       \
+    static bool attr_done_dev[64] = {}; bool& attr_done = attr_done_dev[device_slot()]; /* once per instantiation: never while another stream may be running the kernel */       \
     constexpr int lds_b = wgs2_lds_bytes<SP_, W_>();                                                                            \
     if (!attr_done) {                                                                                                           \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3s2_wgrad_staged_kernel<SP_, W_>),                           \
@@ -1933,7 +1941,7 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
     MTRSSM_WGRAD_PART((size_t)grid.x * kWgT4SetFloats * sizeof(float))
 #define MTRSSM_WGT4_LAUNCH(SP_, W_)                                                                                              \
   {                                                                                                                             \
-    static bool attr_done = false; /* once per instantiation: never while another stream may be running the kernel */       \
+    static bool attr_done_dev[64] = {}; bool& attr_done = attr_done_dev[device_slot()]; /* once per instantiation: never while another stream may be running the kernel */       \
     constexpr int lds_b = wgt4_lds_bytes<SP_, W_>();                                                                            \
     if (!attr_done) {                                                                                                           \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convt4s2_wgrad_staged_kernel<SP_, W_>),                            \
@@ -1964,7 +1972,7 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
     MTRSSM_WGRAD_PART((size_t)grid.x * kWgT4bSetFloats * sizeof(float))
 #define MTRSSM_WGT4B_LAUNCH(SP_, W_)                                                                                             \
   {                                                                                                                             \
-    static bool attr_done = false; /* once per instantiation: never while another stream may be running the kernel */       \
+    static bool attr_done_dev[64] = {}; bool& attr_done = attr_done_dev[device_slot()]; /* once per instantiation: never while another stream may be running the kernel */       \
     constexpr int lds_b = wgt4b_lds_bytes<SP_, W_>();                                                                           \
     if (!attr_done) {                                                                                                           \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convt4s2b_wgrad_staged_kernel<SP_, W_>),                           \
@@ -2049,7 +2057,7 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
         dim3 grid((unsigned)splits, cotiles);
 #define MTRSSM_WG_SPLIT_LAUNCH(NT_, SP_)                                                                                       \
   {                                                                                                                             \
-    static bool attr_done = false; /* once per instantiation: never while another stream may be running the kernel */       \
+    static bool attr_done_dev[64] = {}; bool& attr_done = attr_done_dev[device_slot()]; /* once per instantiation: never while another stream may be running the kernel */       \
     if (!attr_done) {                                                                                                           \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_weight_grad_split_kernel<NT_, SP_>),                         \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);                                        \
@@ -2199,7 +2207,7 @@ int conv_convt_quad_launch(const MtrssmConvGeom* ga4, const float* srca, const u
   const dim3 grid((unsigned)(qa.nx + qb.nx));
 #define MTRSSM_QUAD_LAUNCH(CIN_, COUT_, PLANE_, EPI_)                                                                \
   {                                                                                                                   \
-    static bool attr_done = false;                                                                                    \
+    static bool attr_done_dev[64] = {}; bool& attr_done = attr_done_dev[device_slot()];                                                                                    \
     const size_t ql = quad_lds_bytes<CIN_, PLANE_>();                                                                 \
     if (!attr_done) {                                                                                                 \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convt_quad_resident_kernel<CIN_, COUT_, PLANE_, EPI_>), \

@@ -12,7 +12,12 @@ Replaces the ``nn.Linear`` / ``torchrl.modules.MLP`` calls around the recurrence
   that input (the gradient has already been accumulated where the optimizer reads it) -- the arrangement Megatron calls
   gradient-accumulation fusion.  Outside a ``FlatParameters`` module the gradients are returned as usual.
 
-Numerics: each output element is a k-ordered fp32 fma chain (``v_mfma_f32_32x32x2_f32``), the reference's fp32 nn.Linear.
+Numerics: with the reduction in one slice each output element is a k-ordered fp32 fma chain (``v_mfma_f32_32x32x2_f32``), the
+reference's fp32 nn.Linear; the large layers run bf16-piece MFMA tiles (``SPLIT_PIECES`` = 3: operands exact to 2^-24, fp32
+accumulation; the conv stacks' Linear layers 2 pieces like the convolutions around them).  NOT bitwise reproducible run to run
+wherever the library splits the reduction (small grids, every weight gradient): the slices meet by fp32 atomics, whose order
+varies, so such sums differ in the last bits between runs (~1e-7 relative; the parity tolerances are 2e-4 of a tensor's
+largest entry).  ``mtrssm_gemm``'s ``split_r = 1`` forces one slice per tile -- ordered sums, at the cost of the grid fill.
 """
 
 from __future__ import annotations
