@@ -223,10 +223,11 @@ def _gather_gemm(geom: C.Structure, src: Tensor, src2: Tensor | None, wpq: tuple
 
 
 def _job_work(job: tuple) -> tuple[float, float]:
-    geom, actgrad_in = job[0], job[6]
+    geom, actgrad_in, add_in = job[0], job[6], job[7]
     pixels = geom.N * geom.Hq * geom.Wq
     flops = 2.0 * pixels * geom.Cout * geom.KH * geom.KW * (geom.C + geom.C2)
-    nbytes = 4.0 * (geom.N * geom.C * geom.Hs * geom.Ws + pixels * geom.Cout * (2 if actgrad_in is not None else 1))
+    # source once + output once + each epilogue operand (act' input, skip / skip gradient) once
+    nbytes = 4.0 * (geom.N * geom.C * geom.Hs * geom.Ws + pixels * geom.Cout * (1 + (actgrad_in is not None) + (add_in is not None)))
     return flops, nbytes
 
 
