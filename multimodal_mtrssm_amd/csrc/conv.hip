@@ -23,6 +23,7 @@
 //
 // The weight-gradient kernel is the transposed problem: dWp[co][tap][c] += sum_pixels A[co][pix] G[pix][c],
 // reduction over all N*H*W pixels split across workgroups, partial tiles combined with fp32 atomics.
+#include <map>
 #include <mutex>
 #include <unordered_map>
 #include <utility>
@@ -706,7 +707,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const ReduceBat
 // between two flushes; reduce_record flushes first in that case (the sums are plain read-modify-writes).
 static thread_local bool tl_defer_reduce = false;
 static std::mutex g_reduce_mutex;
-static std::unordered_map<hipStream_t, std::vector<ReduceJob>> g_reduce_jobs;
+// keyed by (device, stream): the null stream of two devices is the same handle
+static std::map<std::pair<int, hipStream_t>, std::vector<ReduceJob>> g_reduce_jobs;
+static std::pair<int, hipStream_t> reduce_key(hipStream_t stream) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return {dev, stream};
+}
 
 static int reduce_flush_locked(std::vector<ReduceJob>& jobs, hipStream_t stream) {
   size_t at = 0;
@@ -730,7 +737,7 @@ static int reduce_flush_locked(std::vector<ReduceJob>& jobs, hipStream_t stream)
 
 int conv_weight_grad_reduce_flush(hipStream_t stream) {
   std::lock_guard<std::mutex> lock(g_reduce_mutex);
-  auto it = g_reduce_jobs.find(stream);
+  auto it = g_reduce_jobs.find(reduce_key(stream));
   if (it == g_reduce_jobs.end() || it->second.empty()) return MTRSSM_OK;
   return reduce_flush_locked(it->second, stream);
 }
@@ -740,7 +747,7 @@ static int reduce_now_or_later(int variant, dim3 rgrid, const float* part, int S
   ReduceJob j{reinterpret_cast<const float4*>(part), dwp, dbias, S, cpad, variant, (int)rgrid.x, (int)rgrid.y};
   if (tl_defer_reduce) {
     std::lock_guard<std::mutex> lock(g_reduce_mutex);
-    auto& jobs = g_reduce_jobs[stream];
+    auto& jobs = g_reduce_jobs[reduce_key(stream)];
     for (const ReduceJob& o : jobs)
       if (o.dwp == dwp || o.part == j.part) {  // the same target (or workspace) again: keep the order
         if (int rc = reduce_flush_locked(jobs, stream)) return rc;

@@ -618,9 +618,9 @@ CONV_CASES = [
     (700, 64, 16, 4, 128, 3, 1, 1, True, False),  # ... three frames per workgroup (odd run), two co groups, 16x4 plane; 1300 above: six / five
     (5, 64, 8, 8, 64, 3, 1, 1, False, False),   # ... no activation
     (3, 8, 64, 16, 16, 3, 2, 1, True, False),   # second encoder layer, audio plane (32x8 output): staged stride-2 weight gradient (conv3x3s2_wgrad_staged_kernel<2, 8>); (2, 8, 32, 32, 16, ...) above is the vision plane (<2, 16>)
-    (1500, 8, 32, 32, 16, 3, 2, 1, True, False),  # ... six frames per workgroup: the three raw register sets and both image buffers go round
+    (1500, 8, 32, 32, 16, 3, 2, 1, True, False),  # ... six frames per workgroup: the three raw register sets and both image buffers go round; forward: conv3x3s2_band_kernel<8, 0> with three tiles per workgroup (both register sets of requests in use); backward-data: convt_quad_resident_kernel<16, 8, 256, true>
     (700, 8, 64, 16, 16, 3, 2, 1, False, False),  # ... three frames per workgroup, no activation
-    (700, 1, 64, 64, 8, 3, 2, 1, True, True),   # first encoder layer, staged (conv3x3s2_thin_wgrad_staged_kernel<2, 32>): three frames per workgroup, activation on frame and coordinate channels; (4, 1, 64, 64, 8, ...) / (3, 1, 128, 32, 8, ...) above are its one-frame cases
+    (700, 1, 64, 64, 8, 3, 2, 1, True, True),   # first encoder layer (forward: conv3x3s2_band_kernel<1, 2>, 2800 band tiles, coordinate channels from the frame-independent planes), staged (conv3x3s2_thin_wgrad_staged_kernel<2, 32>): three frames per workgroup, activation on frame and coordinate channels; (4, 1, 64, 64, 8, ...) / (3, 1, 128, 32, 8, ...) above are its one-frame cases
     (300, 1, 128, 32, 8, 3, 2, 1, False, True),  # ... audio plane (<2, 16>), two frames per workgroup
     (700, 16, 16, 16, 32, 3, 2, 1, True, False),  # third encoder layer, staged (conv3x3s2c_wgrad_staged_kernel<2, 8>): three frames per workgroup; (3, 16, 16, 16, 32, ...) above is its one-frame case
     (300, 16, 32, 8, 32, 3, 2, 1, False, False),  # ... audio plane (16x4 output, <2, 4>), two frames per workgroup, no activation
