@@ -13,8 +13,8 @@ Replaces the ``nn.Linear`` / ``torchrl.modules.MLP`` calls around the recurrence
   gradient-accumulation fusion.  Outside a ``FlatParameters`` module the gradients are returned as usual.
 
 Numerics: with the reduction in one slice each output element is a k-ordered fp32 fma chain (``v_mfma_f32_32x32x2_f32``), the
-reference's fp32 nn.Linear; the large layers run bf16-piece MFMA tiles (``SPLIT_PIECES`` = 3: operands exact to 2^-24, fp32
-accumulation; the conv stacks' Linear layers 2 pieces like the convolutions around them).  NOT bitwise reproducible run to run
+reference's fp32 nn.Linear; the large layers run bf16-piece MFMA tiles (``SPLIT_PIECES`` = 2: 16 significant bits per operand,
+fp32 accumulation, like the convolutions; 3 = operands exact to 2^-24).  NOT bitwise reproducible run to run
 wherever the library splits the reduction (small grids, every weight gradient): the slices meet by fp32 atomics, whose order
 varies, so such sums differ in the last bits between runs (~1e-7 relative; the parity tolerances are 2e-4 of a tensor's
 largest entry).  ``mtrssm_gemm``'s ``split_r = 1`` forces one slice per tile -- ordered sums, at the cost of the grid fill.
@@ -88,14 +88,18 @@ def _ld(t: Tensor) -> int:
     return int(t.stride(0)) if t.shape[0] > 1 else max(int(t.stride(0)), int(t.shape[1]))
 
 
-# MFMA operand format of the LARGE GEMMs (>= SPLIT_MIN_FLOPS) when the caller does not say: 3 = every fp32 operand as three bf16
-# pieces, six bf16 MFMA products, fp32 accumulation (exact to 2^-24: fp32-grade) on the 128 x {128, 64}-tile kernel of
-# csrc/gemm_tile.h where the shape is made of full tiles, else the fp32 MFMA kernel; 2 = two pieces, three products (16
-# significant bits: what the Linear layers INSIDE the conv stacks use, like the convolutions around them -- cnn.py passes
-# ``pieces=conv.gemm_pieces()``); 0 = fp32 MFMA always.  Everything smaller -- the scan's projections at the base dims, init_proj,
-# the prior head, the small weight gradients -- runs the fp32 MFMA kernel (latency-bound launches: the operand format is not
-# what they wait for).
-SPLIT_PIECES = 3
+# MFMA operand format of the LARGE GEMMs (>= SPLIT_MIN_FLOPS) when the caller does not say: 2 (default, MTRSSM_GEMM_PIECES) =
+# every fp32 operand as two bf16 pieces, three bf16 MFMA products, fp32 accumulation -- 16 significant bits per operand, the
+# arithmetic of the convolutions and of the wide scans -- on the 128 x {128, 64}-tile kernel of csrc/gemm_tile.h where the shape
+# is made of full tiles, else the fp32 MFMA kernel; 3 = three pieces, six products (exact to 2^-24, 1.5x the time); 0 = fp32
+# MFMA always.  Measured at BASELINE configs[4] dims, B = 32, T = 100, against the one-CU fp32 scan with fp32-MFMA GEMMs
+# (tools/wide_pieces_error.py; the tolerances are 1e-5 on posterior probabilities, 1e-4 on the losses, 2e-4 of a gradient
+# tensor's largest entry): two pieces everywhere 3.9e-7 / 5.4e-7 / 5.5e-6 with identical samples; three pieces 1.6e-7 / 4.3e-7 /
+# 4.0e-6.  Everything smaller -- the scan's projections at the base dims, init_proj, the prior head, the small weight
+# gradients -- runs the fp32 MFMA kernel (latency-bound launches: the operand format is not what they wait for).
+import os as _os  # noqa: E402
+
+SPLIT_PIECES = int(_os.environ.get("MTRSSM_GEMM_PIECES", "2"))
 SPLIT_MIN_FLOPS = 5.0e8
 
 

@@ -52,7 +52,10 @@ DEFER_SCAN_GRADS = True  # the scan's weight gradients join the end-of-backward 
 #   weights resident (csrc/mrssm_cluster.hip) -- MTRSSM_SCAN_CLUSTER=0 switches it off;
 # * large models (D or H >= 256: BASELINE configs[4]): ALL CUs on one tile of 32 batch rows, MFMA products, a grid barrier
 #   between the layers of a timestep (csrc/mrssm_wide.hip) -- MTRSSM_SCAN_WIDE=0 switches it off, MTRSSM_WIDE_PIECES = 2 | 3
-#   picks the bf16 pieces per fp32 operand (3 = fp32-grade, the default).
+#   picks the bf16 pieces per fp32 operand: 2 (default: 16 significant bits, the conv kernels' arithmetic; against the one-CU
+#   fp32 scan at full size -- tools/wide_pieces_error.py -- posterior probabilities differ by <= 2.4e-6, losses by 1.2e-6
+#   relative, gradients by 1.2e-5 of a tensor's max, samples identical; the stated tolerances are 1e-5 / 1e-4 / 2e-4) or 3 (exact
+#   to 2^-24: 1.8e-7 / 3e-7 / 8e-7, 7 % slower at configs[4] dims).
 # Otherwise one CU per row streams the weights from L2 every step (csrc/mrssm_scan.hip).
 # Every cooperative launch takes its workspace from `_workspace()`: ONE buffer per (device, stream) whose first int32 is a
 # STICKY status word -- a launch whose exchange gave up stores a non-zero code there, no launch clears it.  The fused AdamW
@@ -64,7 +67,7 @@ import os as _os  # noqa: E402
 CLUSTER_SCAN = _os.environ.get("MTRSSM_SCAN_CLUSTER", "1") != "0"
 WIDE_SCAN = _os.environ.get("MTRSSM_SCAN_WIDE", "1") != "0"
 WIDE_BWD = _os.environ.get("MTRSSM_SCAN_WIDE_BWD", "1") != "0"
-WIDE_PIECES = int(_os.environ.get("MTRSSM_WIDE_PIECES", "3"))
+WIDE_PIECES = int(_os.environ.get("MTRSSM_WIDE_PIECES", "2"))
 _WS: dict[tuple, Tensor] = {}
 _WS_RETIRED: list[Tensor] = []
 
