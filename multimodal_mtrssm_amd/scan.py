@@ -243,6 +243,9 @@ class _MrssmScan(torch.autograd.Function):
         ctx, cfg: ScanConfig, xa, pa, pv, deter0, stoch0, u_post, u_prior,  # noqa: ANN001
         w1, w2, b2, wih, bih, whh, bhh, w3, b3, w4, b4, wa1, wa2, ba2, wv1, wv2, bv2,  # noqa: ANN001
     ):
+        # outputs the loss does not touch get NO gradient tensor (autograd would materialise zeros: a fill kernel per unused output
+        # and a read of it in the backward scan); the kernels take null pointers for absent gradients
+        ctx.set_materialize_grads(False)
         lib = _lib.load()
         B, T, H = xa.shape
         D = deter0.shape[1]
@@ -562,6 +565,9 @@ class _MmtrssmScan(torch.autograd.Function):
         u_post_l, u_post_h, u_prior_l, u_prior_h,  # noqa: ANN001
         wxl, wdl, wxh, wdh, bh, wlp1, blp1, wlp2, blp2, wa1, wa2, ba2, wv1, wv2, bv2, whp1, bhp1, whp2, bhp2, whq1, bhq1, whq2, bhq2,  # noqa: ANN001
     ):
+        # outputs the loss does not touch get NO gradient tensor (autograd would materialise zeros: a fill kernel per unused output
+        # and a read of it in the backward scan); the kernels take null pointers for absent gradients
+        ctx.set_materialize_grads(False)
         lib = _lib.load()
         B, T, LD = xl.shape
         HD = deter_h0.shape[1]
