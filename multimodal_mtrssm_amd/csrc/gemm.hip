@@ -592,7 +592,9 @@ static int tile_kernel_columns(const MtrssmGemm* p) {
   if ((!p->a_rmajor && ((p->lda & 3) || ((uintptr_t)p->A & 15))) || (!p->b_rmajor && ((p->ldb & 3) || ((uintptr_t)p->B & 15)))) return 0;
   // a short reduction (<= 16 k-steps) is prologue + epilogue: 64-column tiles put two workgroups on a CU, one's request
   // latency and output stores under the other's steps (3200 x 4096 x 256: 101 -> 54 us; x 64: 48 -> 27)
-  if (p->N % 128 == 0 && p->R > 512) return 128;
+  // two pieces and a wide output: 64-column tiles too (61 KB of LDS: two workgroups per CU; 3200 x 4096 x 1024: 204 -> 142 us,
+  // 3200 x 1024 x 1024: 47 -> 39); narrow outputs (N <= 512) keep the 128-column tile's operand reuse
+  if (p->N % 128 == 0 && p->R > 512 && !(p->mfma_split == 2 && p->N >= 1024)) return 128;
   if (p->N % 64 == 0) return 64;
   return 0;
 }
