@@ -116,7 +116,7 @@ class _PackPlan:
             self.table = torch.tensor(rows, dtype=torch.int64).to(device)
             self.table_serials = serials
         _lib.check(_lib.TIMERS.call("mtrssm_pack_conv_weights", _lib.load().mtrssm_pack_conv_weights, _lib.raw_ptr(self.table), len(live),
-                                    8, _lib.stream_ptr(device)), "mtrssm_pack_conv_weights")
+                                    32, _lib.stream_ptr(device)), "mtrssm_pack_conv_weights")
         for _, e in live:
             e[3], e[4] = e[0]._version, self.epoch
 
@@ -489,7 +489,7 @@ class _ConvGradSink:
             self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
             self.retired.append(self.table)
         _lib.check(_lib.TIMERS.call("mtrssm_unpack_conv_grads", _lib.load().mtrssm_unpack_conv_grads, _lib.raw_ptr(self.table),
-                                    len(self.entries), 8, _lib.stream_ptr(dev)), "mtrssm_unpack_conv_grads")
+                                    len(self.entries), 32, _lib.stream_ptr(dev)), "mtrssm_unpack_conv_grads")
 
 
 _GRAD_SINK = _ConvGradSink()

@@ -1170,9 +1170,18 @@ __global__ void channel_sum_kernel(const float* __restrict__ x, int N, int C, in
   if ((HW & 3) == 0 && !((uintptr_t)x & 15)) {
     const int hw4 = HW >> 2;
     const int quads = (nend - nbeg) * hw4;  // < 2^31: host checks N * HW
-    for (int q = threadIdx.x; q < quads; q += blockDim.x) {
+    auto quad = [&](int q) {
       const int n = nbeg + q / hw4, r4 = q % hw4;
-      const float4 v = reinterpret_cast<const float4*>(x + ((size_t)n * C + c) * HW)[r4];
+      return reinterpret_cast<const float4*>(x + ((size_t)n * C + c) * HW)[r4];
+    };
+    int q = threadIdx.x;
+    const int bd = blockDim.x;
+    for (; q + 3 * bd < quads; q += 4 * bd) {  // four quads in flight per thread
+      const float4 a = quad(q), b = quad(q + bd), d = quad(q + 2 * bd), e = quad(q + 3 * bd);
+      acc += (((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w))) + (((d.x + d.y) + (d.z + d.w)) + ((e.x + e.y) + (e.z + e.w)));
+    }
+    for (; q < quads; q += bd) {
+      const float4 v = quad(q);
       acc += (v.x + v.y) + (v.z + v.w);
     }
   } else {
@@ -2238,6 +2247,7 @@ int channel_sum_launch(const float* x, int N, int C, int HW, float* out, hipStre
   if (total >= (1L << 31)) { set_error("channel_sum: N * HW must be below 2^31"); return MTRSSM_EINVAL; }
   int splits = (int)((total + 16383) / 16384);  // ~2048 blocks over all channels: enough loads in flight to stream from HBM
   if (splits > 2048 / C) splits = 2048 / C;
+  if (splits > 256) splits = 256;  // one atomic per workgroup on out[c]: ~25 ns each when they queue up on one word
   if (splits > N) splits = N;
   if (splits < 1) splits = 1;
   { set_last_kernel("mtrssm::channel_sum_kernel"); hipLaunchKernelGGL(channel_sum_kernel, dim3(C, splits), dim3(256), 0, stream, x, N, C, HW, out); }

@@ -24,6 +24,10 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return t;  // valid in wave 0
 }
 
+// tanh on the hardware exponential: 1 - 2 / (exp(2x) + 1), absolute error ~1e-7 (as the GEMM / conv epilogues), saturates
+// cleanly.  libm's tanhf made the two NLL kernels VALU-bound (41 / 25 us for a 105 MB stream).
+__device__ __forceinline__ float tanh_fast(float x) { return 1.f - 2.f / (__expf(2.f * x) + 1.f); }
+
 // out += scale * sum 0.5 (t - p)^2   (+ the constant on block 0)
 template <bool TANH>
 __global__ void nll_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ target, int64_t n,
@@ -33,16 +37,24 @@ __global__ void nll_fwd_kernel(const float* __restrict__ pred, const float* __re
   const float4* p4 = reinterpret_cast<const float4*>(pred);
   const float4* t4 = reinterpret_cast<const float4*>(target);
   float acc = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-    float4 p = p4[i];
-    const float4 t = t4[i];
-    if (TANH) { p.x = tanhf(p.x); p.y = tanhf(p.y); p.z = tanhf(p.z); p.w = tanhf(p.w); }
+  auto term = [](float4 p, const float4 t) {
+    if (TANH) { p.x = tanh_fast(p.x); p.y = tanh_fast(p.y); p.z = tanh_fast(p.z); p.w = tanh_fast(p.w); }
     const float a = t.x - p.x, b = t.y - p.y, c = t.z - p.z, d = t.w - p.w;
-    acc += 0.5f * (a * a) + 0.5f * (b * b) + 0.5f * (c * c) + 0.5f * (d * d);
+    return 0.5f * (a * a) + 0.5f * (b * b) + 0.5f * (c * c) + 0.5f * (d * d);
+  };
+  // four quads per thread and iteration in flight; few workgroups (the launch picks 512): every workgroup ends in ONE atomic
+  // on the same word, ~25 ns each when they queue up (2048 of them were 40 us of a 41 us kernel)
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    const float4 pa = p4[i], pb = p4[i + stride], pc = p4[i + 2 * stride], pd = p4[i + 3 * stride];
+    const float4 ta = t4[i], tb = t4[i + stride], tc = t4[i + 2 * stride], td = t4[i + 3 * stride];
+    acc += (term(pa, ta) + term(pb, tb)) + (term(pc, tc) + term(pd, td));
   }
+  for (; i < n4; i += stride) acc += term(p4[i], t4[i]);
   if (blockIdx.x == 0) {
     for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) {
-      const float a = target[i] - (TANH ? tanhf(pred[i]) : pred[i]);
+      const float a = target[i] - (TANH ? tanh_fast(pred[i]) : pred[i]);
       acc += 0.5f * a * a;
     }
   }
@@ -64,14 +76,14 @@ __global__ void nll_bwd_kernel(const float* __restrict__ pred, const float* __re
     const float4 t = t4[i];
     float4 d = make_float4(1.f, 1.f, 1.f, 1.f);
     if (TANH) {
-      p.x = tanhf(p.x); p.y = tanhf(p.y); p.z = tanhf(p.z); p.w = tanhf(p.w);
+      p.x = tanh_fast(p.x); p.y = tanh_fast(p.y); p.z = tanh_fast(p.z); p.w = tanh_fast(p.w);
       d = make_float4(1.f - p.x * p.x, 1.f - p.y * p.y, 1.f - p.z * p.z, 1.f - p.w * p.w);
     }
     o4[i] = make_float4(g * (p.x - t.x) * d.x, g * (p.y - t.y) * d.y, g * (p.z - t.z) * d.z, g * (p.w - t.w) * d.w);
   }
   if (blockIdx.x == 0)
     for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) {
-      const float p = TANH ? tanhf(pred[i]) : pred[i];
+      const float p = TANH ? tanh_fast(pred[i]) : pred[i];
       g_pred[i] = g * (p - target[i]) * (TANH ? 1.f - p * p : 1.f);
     }
 }
@@ -204,11 +216,12 @@ int nll_fwd_launch(const float* pred, const float* target, int64_t frames, int64
   if (int rc = clear_async(out, sizeof(float), s)) return rc;
   const int64_t n = frames * event;
   const float constant = 0.5f * 1.8378770664093453f * (float)event;  // 0.5 log(2 pi) per element
+  const int sum_grid = grid_for(n / 4) < 512 ? grid_for(n / 4) : 512;
   set_last_kernel("mtrssm::nll_fwd_kernel");
   if (act == MTRSSM_ACT_TANH)
-    hipLaunchKernelGGL(nll_fwd_kernel<true>, dim3(grid_for(n / 4)), dim3(kThreads), 0, s, pred, target, n, 1.f / (float)frames, constant, out);
+    hipLaunchKernelGGL(nll_fwd_kernel<true>, dim3(sum_grid), dim3(kThreads), 0, s, pred, target, n, 1.f / (float)frames, constant, out);
   else
-    hipLaunchKernelGGL(nll_fwd_kernel<false>, dim3(grid_for(n / 4)), dim3(kThreads), 0, s, pred, target, n, 1.f / (float)frames, constant, out);
+    hipLaunchKernelGGL(nll_fwd_kernel<false>, dim3(sum_grid), dim3(kThreads), 0, s, pred, target, n, 1.f / (float)frames, constant, out);
   return check_launch("gaussian_nll_fwd");
 }
 
@@ -230,7 +243,7 @@ int sumsq_launch(const float* x, int64_t n, float* out, hipStream_t s) {
   if ((uintptr_t)x & 15) { set_error("sumsq: x must be 16-byte aligned"); return MTRSSM_EINVAL; }
   if (int rc = clear_async(out, sizeof(float), s)) return rc;
   set_last_kernel("mtrssm::sumsq_kernel");
-  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n / 4)), dim3(kThreads), 0, s, x, n, out);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n / 4) < 512 ? grid_for(n / 4) : 512), dim3(kThreads), 0, s, x, n, out);  // one same-address atomic per workgroup
   return check_launch("sumsq");
 }
 
@@ -249,7 +262,7 @@ int adamw_prepare_launch(const float* g, int64_t n, float* sumsq, float* state, 
   if ((uintptr_t)g & 15) { set_error("adamw_prepare: grad must be 16-byte aligned"); return MTRSSM_EINVAL; }
   if (int rc = clear_async(sumsq, sizeof(float), s)) return rc;
   set_last_kernel("mtrssm::sumsq_tick_kernel");
-  hipLaunchKernelGGL(sumsq_tick_kernel, dim3(grid_for(n / 4)), dim3(kThreads), 0, s, g, n, sumsq, state, status, b1, b2);
+  hipLaunchKernelGGL(sumsq_tick_kernel, dim3(grid_for(n / 4) < 512 ? grid_for(n / 4) : 512), dim3(kThreads), 0, s, g, n, sumsq, state, status, b1, b2);  // (as sumsq)
   return check_launch("adamw_prepare");
 }
 
