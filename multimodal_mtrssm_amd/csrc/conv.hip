@@ -1741,7 +1741,7 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
     else { if (sp == 2) MTRSSM_WG1_LAUNCH(2, 128) else MTRSSM_WG1_LAUNCH(1, 128) }
 #undef MTRSSM_WG1_LAUNCH
     if (part) {
-      const dim3 rgrid((unsigned)(2 * (g->C / 32) * 256 / 8 + (dbias ? 2 : 0)), cogroups);  // + the two bias blocks
+      const dim3 rgrid((unsigned)(2 * (g->C / 32) * 256 / 32 + (dbias ? 1 : 0)), cogroups);  // + the bias block
       if (int rc = reduce_now_or_later(g->C == 64 ? kRed1x1_64 : kRed1x1_128, rgrid, part, (int)grid.x, g->Cpad, dwp, dbias, stream)) return rc;
     }
     return launched("conv_weight_grad(1x1 staged)");
@@ -1802,7 +1802,7 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
     }
 #undef MTRSSM_WGRES_LAUNCH
     if (part) {
-      const dim3 rgrid((unsigned)(wgres_tile_floats(g->C) / 4 / 8 + (dbias ? 2 : 0)), cogroups);  // + the two bias blocks
+      const dim3 rgrid((unsigned)(wgres_tile_floats(g->C) / 4 / 32 + (dbias ? 1 : 0)), cogroups);  // + the bias block
       if (int rc = reduce_now_or_later(g->C == 64 ? kRedRes64 : kRedRes32, rgrid, part, (int)grid.x, g->Cpad, dwp, dbias, stream)) return rc;
     }
     return launched("conv_weight_grad(3x3 resident)");

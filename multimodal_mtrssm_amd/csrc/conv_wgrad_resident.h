@@ -331,18 +331,20 @@ __global__ __launch_bounds__(64 * 2 * (C / 32), 1) void conv3x3_wgrad_resident_k
 }
 
 // Sum of the S partial tile sets of every co group (part [cogroups][S][set floats], accumulator order) into dwp.  Thread =
-// one float4 of the set (rows r .. r + 3 of one accumulator column) x one of 32 slices of S (four loads in flight), the
-// slices met in LDS; 8 lanes read one 128-byte line.  dwp is read-modified-written without atomics: launches that
-// accumulate into one dwp chunk are ordered by their stream.
+// one float4 of the set (rows r .. r + 3 of one accumulator column) x one of 8 slice groups of S (four loads in flight), the
+// groups met in LDS; 32 lanes read 512 contiguous bytes of a set (with 128-byte pieces 147 KB apart the 520 MB of these sets
+// streamed at 3 TB/s).  dwp is read-modified-written without atomics: launches that accumulate into one dwp chunk are ordered
+// by their stream.
 template <int C>
 __device__ __forceinline__ void wgrad_reduce_partials_body(const float4* __restrict__ part, const int S, const int cpad,
                                                                     float* __restrict__ dwp, float* __restrict__ dbias, const int bx, const int by) {
   constexpr int SET4 = wgres_set_floats(C) / 4, TILE4 = wgres_tile_floats(C) / 4;
-  constexpr int NL = 8, NG = 32;  // 8 float4 columns (one 128-byte line per set) x 32 slices of S per workgroup
+  constexpr int NL = 32, NG = 8;  // 32 float4 columns (512 bytes of a set) x 8 slice groups of S per workgroup
+  static_assert(TILE4 % NL == 0, "whole blocks");
   __shared__ float4 red[NG][NL];
   const int li = threadIdx.x & (NL - 1), sg = threadIdx.x / NL;
-  const int f = bx * NL + li;  // host: grid.x * 8 == TILE4 (+ 16: the two bias blocks, launched when dbias != NULL)
-  const float4* const p = part + (size_t)by * S * SET4 + f;
+  const int f = bx * NL + li;  // host: grid.x * 32 == TILE4 (+ 32: the bias block, 16 float4 of it in use, launched when dbias != NULL)
+  const float4* const p = part + (size_t)by * S * SET4 + (f < SET4 ? f : SET4 - 1);
   float4 acc4[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) acc4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -365,9 +367,11 @@ __device__ __forceinline__ void wgrad_reduce_partials_body(const float4* __restr
     float4 t = red[0][li];
 #pragma unroll
     for (int k = 1; k < NG; ++k) { t.x += red[k][li].x; t.y += red[k][li].y; t.z += red[k][li].z; t.w += red[k][li].w; }
-    if (f >= TILE4) {  // block-uniform: the bias sums of channels 4 (f - TILE4) .. + 3 of this co group
-      float* const o = dbias + by * 64 + 4 * (f - TILE4);
-      o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w;
+    if (f >= TILE4) {  // block-uniform: the bias sums of channels 4 (f - TILE4) .. + 3 of this co group (16 float4)
+      if (f - TILE4 < 16) {
+        float* const o = dbias + by * 64 + 4 * (f - TILE4);
+        o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w;
+      }
       return;
     }
     // f = ((wave * 9 + j) * 4 + gq) * 64 + lane  ->  rows cot + 8 gq + 4 kl + {0..3}, tap, ci (the kernel's tile assignment)
@@ -561,13 +565,13 @@ template <int C>
 __device__ __forceinline__ void wgrad_reduce_partials1x1_body(const float4* __restrict__ part, const int S, const int cpad,
                                                                        float* __restrict__ dwp, float* __restrict__ dbias, const int bx, const int by) {
   constexpr int NTILE = 2 * (C / 32), KS = 8 / NTILE, TILE4 = 256, SET4 = kWg1x1SetFloats / 4;
-  constexpr int NL = 8, NG = 32;  // 8 float4 columns (one 128-byte line per slice) x 32 slice groups per workgroup
+  constexpr int NL = 32, NG = 8;  // 32 float4 columns (512 bytes of a slice) x 8 slice groups per workgroup
   __shared__ float4 red[NG][NL];
   const int li = threadIdx.x & (NL - 1), sg = threadIdx.x / NL;
-  const int f = bx * NL + li;  // float4 of the NTILE tiles; host: grid.x * 8 == NTILE * 256 (+ 16: two bias blocks)
+  const int f = bx * NL + li;  // float4 of the NTILE tiles; host: grid.x * 32 == NTILE * 256 (+ 32: the bias block, 16 float4 in use)
   const bool bias = f >= NTILE * TILE4;  // block-uniform
   const int tile = f / TILE4, ft = f - tile * TILE4;
-  const float4* const p = part + (size_t)by * S * SET4 + (bias ? (size_t)(8 * TILE4 + (f - NTILE * TILE4)) : (size_t)tile * TILE4 + ft);
+  const float4* const p = part + (size_t)by * S * SET4 + (bias ? (size_t)(8 * TILE4 + (f - NTILE * TILE4 < 16 ? f - NTILE * TILE4 : 15)) : (size_t)tile * TILE4 + ft);
   float4 acc4[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) acc4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -594,8 +598,10 @@ __device__ __forceinline__ void wgrad_reduce_partials1x1_body(const float4* __re
 #pragma unroll
     for (int k = 1; k < NG; ++k) { v.x += red[k][li].x; v.y += red[k][li].y; v.z += red[k][li].z; v.w += red[k][li].w; }
     if (bias) {
-      float* const o = dbias + by * 64 + 4 * (f - NTILE * TILE4);
-      o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w;
+      if (f - NTILE * TILE4 < 16) {
+        float* const o = dbias + by * 64 + 4 * (f - NTILE * TILE4);
+        o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w;
+      }
       return;
     }
     const int lane = ft & 63, gq = ft >> 6, il = lane & 31, kl = lane >> 5;
