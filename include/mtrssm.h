@@ -512,6 +512,13 @@ int mtrssm_convt_quad(const MtrssmConvGeom* ga4, const float* srca, const uint16
  * source element. */
 int mtrssm_convt_k4s2_thin(int32_t N, int32_t C, int32_t Hs, int32_t Ws, int32_t Cout, const float* src, const float* w,
                            const float* bias, int32_t pre_act, int32_t act, float* out, void* stream);
+/* The same layer on the MFMA for the reference's shapes (16 input channels, Cout <= 2, frames of 1024 positions: 64 x 16 or
+ * 32 x 32; two bf16 pieces per operand, fp32 accumulation = the bf16x2 conv mode): the four output parity classes of an input
+ * position are rows of an MFMA tile, a frame is staged once (csrc/conv_s2_band.h: convt4s2_band_kernel).  _supported: 1 / 0, a
+ * host-side query. */
+int mtrssm_convt_k4s2_band_supported(int32_t N, int32_t C, int32_t Hs, int32_t Ws, int32_t Cout);
+int mtrssm_convt_k4s2_band(int32_t N, int32_t C, int32_t Hs, int32_t Ws, int32_t Cout, const float* src, const float* w,
+                           const float* bias, int32_t pre_act, int32_t act, float* out, void* stream);
 /* Conv2d backward-data / ConvTranspose2d forward with <= 8 output channels, all output parity classes in ONE pass (the general
  * path, mtrssm_conv_gather_gemm, takes one launch per parity class of a strided layer; replaces the backward-data of the
  * encoders' second conv, cnn.Encoder at mrssm core.py:179-180):

@@ -119,6 +119,8 @@ SYMBOLS: dict[str, tuple[type | None, list[type]]] = {
     "mtrssm_conv_weight_grad_workspace_bytes": (C.c_int64, [C.POINTER(ConvGeom), _i]),
     "mtrssm_channel_sum": (C.c_int, [_p, _i, _i, _i, _p, _p]),
     "mtrssm_convt_k4s2_thin": (C.c_int, [_i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _p, _p]),
+    "mtrssm_convt_k4s2_band_supported": (C.c_int, [_i, _i, _i, _i, _i]),
+    "mtrssm_convt_k4s2_band": (C.c_int, [_i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _p, _p]),
     "mtrssm_convt_quad_supported": (C.c_int, [C.POINTER(ConvGeom)]),
     "mtrssm_convt_quad": (C.c_int, [C.POINTER(ConvGeom), _p, C.POINTER(C.c_void_p), _p, _p, _p, C.POINTER(ConvGeom), _p, C.POINTER(C.c_void_p),
                                     _p, _p, _p, _p]),

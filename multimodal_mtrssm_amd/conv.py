@@ -345,6 +345,13 @@ def _conv_transposed_gather(y: Tensor, w: Tensor, bias: Tensor | None, stride: i
         # the decoders' last layer: all four parity classes in one pass (csrc/conv.hip: convt_k4s2_thin_kernel)
         lib = _lib.load()
         wc = w.contiguous()
+        if _MFMA_SPLIT == 2 and CONVT_BAND and lib.mtrssm_convt_k4s2_band_supported(n, o, hs, ws, c):  # noqa: PLR2004
+            # the reference's shapes in the default operand format: on the MFMA, a frame staged once (csrc/conv_s2_band.h)
+            _lib.check(_lib.TIMERS.call(
+                "mtrssm_convt_k4s2_band", lib.mtrssm_convt_k4s2_band, n, o, hs, ws, c, _lib.ptr(y), _lib.ptr(wc), _lib.ptr(bias),
+                int(pre_act), act, _lib.ptr(out), _lib.stream_ptr(y.device), flops=2.0 * n * ho * wo * c * 4 * o,
+                nbytes=4.0 * (y.numel() + out.numel())), "mtrssm_convt_k4s2_band")
+            return out
         _lib.check(_lib.TIMERS.call(
             "mtrssm_convt_k4s2_thin", lib.mtrssm_convt_k4s2_thin, n, o, hs, ws, c, _lib.ptr(y), _lib.ptr(wc), _lib.ptr(bias),
             int(pre_act), act, _lib.ptr(out), _lib.stream_ptr(y.device), flops=2.0 * n * ho * wo * c * 4 * o,
@@ -410,7 +417,8 @@ def _conv_transposed_gather(y: Tensor, w: Tensor, bias: Tensor | None, stride: i
 # never handed out twice and is freed by the allocator when the last view of it dies.
 TGATHER_THIN = os.environ.get("MTRSSM_TGATHER_THIN", "1") != "0"  # A/B switch of conv_tgather_thin_kernel
 CONVT_QUAD = os.environ.get("MTRSSM_CONVT_QUAD", "1") != "0"  # A/B switch of convt_quad_resident_kernel
-CONVT_QUAD_BWD = os.environ.get("MTRSSM_CONVT_QUAD_BWD", "1") != "0"  # its use for a k=3 s=2 conv's backward-data (see there)
+CONVT_QUAD_BWD = os.environ.get("MTRSSM_CONVT_QUAD_BWD", "1") != "0"
+CONVT_BAND = os.environ.get("MTRSSM_CONVT_BAND", "1") != "0"  # A/B switch of convt4s2_band_kernel (the decoders' last layer on the MFMA)  # its use for a k=3 s=2 conv's backward-data (see there)
 _ZERO_CHUNK_FLOATS = 2 << 20
 _ZERO_CHUNKS: dict[tuple, list] = {}
 

@@ -33,6 +33,8 @@ int conv_weight_grad_launch(const MtrssmConvGeom*, const float*, const float*, c
 int conv_weight_grad_deferred_launch(const MtrssmConvGeom*, const float*, const float*, const float*, int, float*, float*, void*, size_t, hipStream_t);
 int conv_weight_grad_reduce_flush(hipStream_t);
 int channel_sum_launch(const float*, int, int, int, float*, hipStream_t);
+int convt_k4s2_band_supported(int, int, int, int, int);
+int convt_k4s2_band_launch(int, int, int, int, int, const float*, const float*, const float*, int, int, float*, hipStream_t);
 int convt_k4s2_thin_launch(int, int, int, int, int, const float*, const float*, const float*, int, int, float*, hipStream_t);
 int conv_convt_quad_supported(const MtrssmConvGeom*);
 int conv_convt_quad_launch(const MtrssmConvGeom*, const float*, const unsigned short* const*, const float*, const float*, float*,
@@ -240,6 +242,13 @@ MTRSSM_API int mtrssm_convt_quad(const MtrssmConvGeom* ga4, const float* srca, c
   return conv_convt_quad_launch(ga4, srca, reinterpret_cast<const unsigned short* const*>(wqa4), biasa, actgrada, outa, gb4, srcb,
                                 reinterpret_cast<const unsigned short* const*>(wqb4), biasb, actgradb, outb,
                                 static_cast<hipStream_t>(stream));
+}
+MTRSSM_API int mtrssm_convt_k4s2_band_supported(int32_t N, int32_t C, int32_t Hs, int32_t Ws, int32_t Cout) {
+  return convt_k4s2_band_supported(N, C, Hs, Ws, Cout);
+}
+MTRSSM_API int mtrssm_convt_k4s2_band(int32_t N, int32_t C, int32_t Hs, int32_t Ws, int32_t Cout, const float* src, const float* w,
+                                     const float* bias, int32_t pre_act, int32_t act, float* out, void* stream) {
+  return convt_k4s2_band_launch(N, C, Hs, Ws, Cout, src, w, bias, pre_act, act, out, static_cast<hipStream_t>(stream));
 }
 MTRSSM_API int mtrssm_convt_k4s2_thin(int32_t N, int32_t C, int32_t Hs, int32_t Ws, int32_t Cout, const float* src, const float* w,
                                       const float* bias, int32_t pre_act, int32_t act, float* out, void* stream) {

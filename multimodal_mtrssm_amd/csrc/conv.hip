@@ -2125,6 +2125,37 @@ int conv_weight_grad_launch(const MtrssmConvGeom* g, const float* a, const float
   return launched("conv_weight_grad");
 }
 
+// The decoders' last layer on the MFMA (conv_s2_band.h: convt4s2_band_kernel): 16 input channels, <= 2 output channels, frames
+// of 1024 positions (64 x 16 or 32 x 32); two bf16 pieces per operand.  Returns MTRSSM_EINVAL outside these shapes (the caller
+// takes mtrssm_convt_k4s2_thin then).
+int convt_k4s2_band_supported(int N, int C, int Hs, int Ws, int Cout) {
+  return N > 0 && C == 16 && Cout >= 1 && Cout <= 2 && Hs * Ws == 1024 && (Ws == 16 || Ws == 32) && (long)N * C * 1024 < (1L << 29) ? 1 : 0;
+}
+int convt_k4s2_band_launch(int N, int C, int Hs, int Ws, int Cout, const float* src, const float* w, const float* bias, int pre_act,
+                           int act, float* out, hipStream_t stream) {
+  if (!convt_k4s2_band_supported(N, C, Hs, Ws, Cout) || !src || !w || !out) {
+    set_error("convt_k4s2_band: needs 16 input channels, 1-2 output channels and 1024-position frames (64 x 16 or 32 x 32)");
+    return MTRSSM_EINVAL;
+  }
+  if (act < MTRSSM_ACT_IDENTITY || act > MTRSSM_ACT_TANH) { set_error("convt_k4s2_band: unknown activation id %d", act); return MTRSSM_EINVAL; }
+  if (((uintptr_t)out & 7) || ((uintptr_t)src & 15)) { set_error("convt_k4s2_band: src must be 16-byte, out 8-byte aligned"); return MTRSSM_EINVAL; }
+  ConvtBandProblem p{}, none{};
+  p.src = src; p.w = w; p.bias = bias; p.out = out; p.N = N; p.Hs = Hs; p.Ws = Ws; p.Cout = Cout; p.pre_act = pre_act; p.act = act;
+  const int slots = 2 * cu_count();   // two workgroups per CU
+  p.nx = N < slots ? N : slots;
+  none.nx = 0;
+  const size_t lds = (size_t)convt_band_lds_bytes(Hs, Ws);
+  static bool attr_done_dev[64] = {};
+  bool& attr_done = attr_done_dev[device_slot()];
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convt4s2_band_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    attr_done = true;
+  }
+  set_last_kernel("mtrssm::convt4s2_band_kernel");
+  hipLaunchKernelGGL(convt4s2_band_kernel, dim3((unsigned)p.nx), dim3(256), lds, stream, p, none);
+  return launched("convt_k4s2_band");
+}
+
 int convt_k4s2_thin_launch(int N, int C, int Hs, int Ws, int Cout, const float* src, const float* w, const float* bias, int pre_act,
                            int act, float* out, hipStream_t stream) {
   if (N <= 0 || C <= 0 || Hs <= 0 || Ws <= 0 || Cout <= 0 || Cout > 2 || !src || !w || !out) {

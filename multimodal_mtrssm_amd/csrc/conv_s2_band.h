@@ -227,4 +227,186 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_band_kernel(const GatherProb
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// ConvTranspose2d(k = 4, s = 2, p = 1) forward with 16 input channels and ONE or two output channels (the decoders' last layer,
+// default.yaml:70-74) on the staged recipe.  convt_k4s2_thin_kernel (VALU: 256 fmas + 144 LDS reads per thread for a 2 x 2
+// output block) is issue-bound at 2.4 TB/s.  Here the four output parity classes of an input position are the rows of an MFMA
+// tile: out[2 iy + qy][2 ix + qx] = sum over the 3 x 3 neighbourhood (dy, dx) and ci of A[q][(dy, dx)][ci] * act(x)[ci][iy + dy][ix + dx]
+// with A[q][(dy, dx)][ci] = w[ci][co][qy + 1 - 2 dy][qx + 1 - 2 dx] where that tap exists (four of the nine per class), else 0:
+// 5 k-steps (two neighbours of 16 channels each) x 3 products of v_mfma_f32_16x16x32_bf16 per 16 positions.  A tile = one frame (1024
+// input positions: 64 x 16 or 32 x 32), staged once: 16-byte requests (wave w = channels 4 w .. 4 w + 3, a lane = four groups of
+// four positions; two register sets: the next frame is requested before this one is converted), converted once into
+// [piece][channel half][haloed position] 16-byte rows -- the 32 positions of a unit read consecutive rows for every neighbour,
+// the zero border is written once per launch.  Rows 0 .. 4 Cout - 1 of the 16 x 16 accumulator are the 2 x 2 output blocks.
+// ------------------------------------------------------------------------------------------------
+struct ConvtBandProblem {
+  const float* src;   // [N][16][Hs][Ws]
+  const float* w;     // [16][Cout][4][4]
+  const float* bias;  // [Cout] or null
+  float* out;         // [N][Cout][2 Hs][2 Ws]
+  int N, Hs, Ws, Cout, pre_act, act, nx;
+};
+
+__host__ __device__ constexpr int convt_band_lds_bytes(int Hs, int Ws) { return 2 * 2 * ((Hs + 2) * (Ws + 2) + 1) * 16; }
+
+__global__ __launch_bounds__(256, 2) void convt4s2_band_kernel(const ConvtBandProblem pa, const ConvtBandProblem pb) {
+  const bool second = blockIdx.x >= (unsigned)pa.nx;  // workgroup-uniform
+  const ConvtBandProblem& P = second ? pb : pa;
+  const int wg = second ? (int)blockIdx.x - pa.nx : (int)blockIdx.x, nwg = P.nx;
+  constexpr int C = 16, PLANE = 1024;
+  const int Ws = P.Ws, Hs = P.Hs, Cout = P.Cout;            // host: Hs * Ws == 1024, Ws in {16, 32}, Cout <= 2
+  const int wsh = 31 - __builtin_clz(Ws);
+  const int ntiles = P.N;
+  const int PW = Ws + 2;                                    // haloed row: positions -1 .. Ws
+  const int NPOS = (Hs + 2) * PW + 1;
+  const int HALF = NPOS * 16, IMG = 2 * HALF;               // one channel half / one piece
+  const int Wo = 2 * Ws;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (wg >= ntiles) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char band_lds[];  // [2 pieces][2 channel halves][NPOS] x 16 B
+
+  // A operands of v_mfma_f32_16x16x32_bf16: row = lane & 15 = class q = row & 3 of output channel row >> 2; a k-step s holds two
+  // neighbours (dy, dx) = (t / 3 - 1, t % 3 - 1), t = 2 s and 2 s + 1, of 16 channels each: lane group g = lane >> 4 has
+  // neighbour 2 s + (g >> 1), channels 8 (g & 1) .. + 7.  (The 32 x 32 x 16 shape spent 27 MFMAs of 32 cycles per 32 positions
+  // on 4 live rows of 32; this one 15 of 16 cycles per 16 positions.)
+  const int lg = lane >> 4, lrow = lane & 15;
+  bf16x8 a[5][2];
+  {
+    const int q = lrow & 3, co = lrow >> 2, qy = q >> 1, qx = q & 1;
+#pragma unroll
+    for (int ss = 0; ss < 5; ++ss) {
+      const int t = 2 * ss + (lg >> 1);
+      const int dy = t / 3 - 1, dx = t % 3 - 1;
+      const int ky = qy + 1 - 2 * dy, kx = qx + 1 - 2 * dx;
+      const bool live = t < 9 && co < Cout && ky >= 0 && ky < 4 && kx >= 0 && kx < 4;
+      const int wofs = live ? co * 16 + ky * 4 + kx : 0;   // (unconditional requests from a valid address, selected afterwards)
+      u16x8 h0, h1;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float wv = P.w[(size_t)(8 * (lg & 1) + j) * Cout * 16 + wofs];
+        const float v = live ? wv : 0.f;
+        unsigned short hh[2];
+        split_bf16<2>(v, hh);
+        h0[j] = hh[0];
+        h1[j] = hh[1];
+      }
+      a[ss][0] = __builtin_bit_cast(bf16x8, h0);
+      a[ss][1] = __builtin_bit_cast(bf16x8, h1);
+    }
+  }
+  for (int o = tid * 16; o < 2 * IMG; o += 256 * 16) *reinterpret_cast<u32x4*>(band_lds + o) = u32x4{0u, 0u, 0u, 0u};
+
+  band_f4 pv[1][4][4];  // [position group l + 64 k][channel 4 wave + c] (ONE set: two would not leave two workgroups per CU their registers)
+  auto request = [&](int tile, auto set_tag) {
+    constexpr int SET = decltype(set_tag)::value;
+    const __amdgpu_buffer_rsrc_t rsf =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.src + ((size_t)tile * C + 4 * wave) * PLANE), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        pv[SET][k][c] = __builtin_bit_cast(band_f4, __builtin_amdgcn_raw_buffer_load_b128(rsf, (lane + 64 * k) * 16, c * PLANE * 4, 0));
+  };
+  const int act = P.act;
+  const int mode = P.pre_act == 0 ? 0 : (act == MTRSSM_ACT_ELU ? 1 : 2);
+  const int hf = wave >> 1, cofs = (wave & 1) * 8;   // channels 4 wave .. + 3: half hf, byte offset cofs inside the 16-byte row
+  auto stage_as = [&](auto mode_tag, auto set_tag) {
+    constexpr int MODE = decltype(mode_tag)::value, SET = decltype(set_tag)::value;
+    auto activate = [&](float v) {
+      if (MODE == 1) v = elu_fast(v);
+      if (MODE == 2) v = act_fwd(v, act);
+      return v;
+    };
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int p = (lane + 64 * k) * 4, r = p >> wsh, x = p & (Ws - 1);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        unsigned short h[4][2];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) split_bf16<2>(activate(pv[SET][k][c][e]), h[c]);
+        unsigned char* d = band_lds + hf * HALF + ((r + 1) * PW + x + e + 1) * 16 + cofs;
+        *reinterpret_cast<uint2*>(d) = make_uint2((unsigned)h[0][0] | ((unsigned)h[1][0] << 16), (unsigned)h[2][0] | ((unsigned)h[3][0] << 16));
+        *reinterpret_cast<uint2*>(d + IMG) = make_uint2((unsigned)h[0][1] | ((unsigned)h[1][1] << 16), (unsigned)h[2][1] | ((unsigned)h[3][1] << 16));
+      }
+    }
+  };
+  auto stage = [&](auto set_tag) {
+    if (mode == 0) stage_as(std::integral_constant<int, 0>{}, set_tag);
+    else if (mode == 1) stage_as(std::integral_constant<int, 1>{}, set_tag);
+    else stage_as(std::integral_constant<int, 2>{}, set_tag);
+  };
+
+  float b0 = 0.f, b1 = 0.f;
+  if (P.bias) {
+    b0 = P.bias[0];
+    b1 = Cout > 1 ? P.bias[1] : 0.f;
+  }
+  const float bme = lg == 0 ? b0 : (lg == 1 ? b1 : 0.f);   // accumulator registers 0..3 of lane group g = rows 4 g + r = the classes of output channel g
+  // per-lane neighbour offsets of the five k-steps (neighbour 9 does not exist: its weights are zero, any valid row will do)
+  int toff[5];
+#pragma unroll
+  for (int ss = 0; ss < 5; ++ss) {
+    const int t = 2 * ss + (lg >> 1) < 9 ? 2 * ss + (lg >> 1) : 8;
+    toff[ss] = ((t / 3 - 1) * PW + (t % 3 - 1)) * 16;
+  }
+  using f32x4v = __attribute__((ext_vector_type(4))) float;
+  auto compute = [&](int tile) {
+    float* const o = P.out + ((size_t)tile * Cout + (lg < Cout ? lg : 0)) * (4 * PLANE);
+    // this wave's sixteen 16-position units, four at a time (four independent MFMA chains): position j = 16 u + (lane & 15)
+#pragma unroll 1
+    for (int up = 0; up < 4; ++up) {
+      unsigned bb[4];
+      int opx[4];
+#pragma unroll
+      for (int uu = 0; uu < 4; ++uu) {
+        const int j = (16 * wave + 4 * up + uu) * 16 + lrow, iy = j >> wsh, ix = j & (Ws - 1);
+        bb[uu] = (unsigned)((lg & 1) * HALF + ((iy + 1) * PW + ix + 1) * 16);
+        opx[uu] = (2 * iy) * Wo + 2 * ix;
+      }
+      f32x4v acc[4];
+#pragma unroll
+      for (int uu = 0; uu < 4; ++uu) acc[uu] = f32x4v{bme, bme, bme, bme};
+#pragma unroll
+      for (int ss = 0; ss < 5; ++ss) {
+        bf16x8 q0[4], q1[4];
+#pragma unroll
+        for (int uu = 0; uu < 4; ++uu) {
+          q0[uu] = *reinterpret_cast<const bf16x8*>(band_lds + bb[uu] + toff[ss]);
+          q1[uu] = *reinterpret_cast<const bf16x8*>(band_lds + bb[uu] + toff[ss] + IMG);
+        }
+#pragma unroll
+        for (int uu = 0; uu < 4; ++uu) acc[uu] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ss][0], q1[uu], acc[uu], 0, 0, 0);
+#pragma unroll
+        for (int uu = 0; uu < 4; ++uu) acc[uu] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ss][1], q0[uu], acc[uu], 0, 0, 0);
+#pragma unroll
+        for (int uu = 0; uu < 4; ++uu) acc[uu] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ss][0], q0[uu], acc[uu], 0, 0, 0);
+      }
+      if (lg < Cout) {
+#pragma unroll
+        for (int uu = 0; uu < 4; ++uu) {
+          *reinterpret_cast<float2*>(o + opx[uu]) = make_float2(acc[uu][0], acc[uu][1]);
+          *reinterpret_cast<float2*>(o + opx[uu] + Wo) = make_float2(acc[uu][2], acc[uu][3]);
+        }
+      }
+    }
+  };
+  // Two workgroups per CU: one converts (VALU) while the other multiplies -- a single wave per SIMD issues both in turn (counters
+  // of the one-workgroup form: 41 us of MFMA + 29 us of VALU + 30 us of waits per wave in a 102 us launch).  The next frame is
+  // requested right after this one's conversion and flies under its products.
+  const int last = wg + ((ntiles - 1 - wg) / nwg) * nwg;
+  const std::integral_constant<int, 0> s0{};
+  request(wg, s0);
+  __syncthreads();  // the zero fill
+  for (int tile = wg; tile < ntiles; tile += nwg) {
+    stage(s0);
+    const int nx = tile + nwg;
+    request(nx < last ? nx : last, s0);
+    lds_barrier();
+    compute(tile);
+    lds_barrier();
+  }
+}
+
 }  // namespace mtrssm
