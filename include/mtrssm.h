@@ -545,6 +545,15 @@ int mtrssm_channel_sum(const float* x, int32_t N, int32_t C, int32_t HW, float* 
 int mtrssm_episode_gather(const float* store, const int64_t* idx, const float* noise, int64_t n_episodes, int64_t B, int64_t T,
                           int64_t Tfull, int64_t E, float std_, float* input, float* target, void* stream);
 
+/* Categorical head of the initial state (core.py:121-135, mmtrssm core.py:321-362): `logits` [rows][K * C] flat (K categoricals
+ * of C classes, softmax over classes), `u` [rows][K] uniforms -> logp, probs [rows][K][C] and the inverse-CDF one-hot sample
+ * onehot [rows][K * C] (index = #{c <= C - 2 : cumulative probability <= u}, the cumulative sum a left fold).  The straight-through
+ * sample of the reference is onehot + probs - probs.detach(): its gradient arrives as g_probs of the backward call,
+ *   d_logits[c] = p_c (g_probs[c] - sum_j p_j g_probs[j]) + g_logp[c] - p_c sum_j g_logp[j]   (either gradient may be NULL). */
+int mtrssm_categorical_sample_fwd(const float* logits, const float* u, int64_t rows, int32_t K, int32_t C, float* logp, float* probs,
+                                  float* onehot, void* stream);
+int mtrssm_categorical_sample_bwd(const float* probs, const float* g_probs, const float* g_logp, int64_t rows, int32_t K, int32_t C,
+                                  float* d_logits, void* stream);
 /* ------------------------------------------------------------------------------------------
  * Gaussian NLL with unit scale, fused reduction.  Replaces objective.likelihood
  * (objective.py:7-23) as used by compute_reconstruction_loss (mrssm/mopoe_mrssm/core.py:279-308):

@@ -20,7 +20,7 @@ import torch
 from torch import Tensor, nn
 
 from multimodal_mtrssm_amd import cnn, conv, scan
-from multimodal_mtrssm_amd.distributions import MultiOneHot, MultiOneHotFactory, kl_divergence, onehot_from_uniforms
+from multimodal_mtrssm_amd.distributions import MultiOneHot, MultiOneHotFactory, draw_uniforms, kl_divergence, onehot_from_uniforms
 from multimodal_mtrssm_amd.networks import MTRNN, Representation, Transition
 from multimodal_mtrssm_amd.objective import likelihood
 from multimodal_mtrssm_amd.state import MTState, State
@@ -55,6 +55,58 @@ def _st_onehot(dist: MultiOneHot, u: Tensor | None) -> Tensor:
         return dist.rsample()
     onehot = onehot_from_uniforms(dist.probs.detach(), u.to(dist.probs))
     return (onehot + (dist.probs - dist.probs.detach())).flatten(start_dim=-2)
+
+
+class _CategoricalHead(torch.autograd.Function):
+    """Initial-state categorical head in ONE launch (``mtrssm_categorical_sample_fwd``): flat logits + uniforms ->
+    (straight-through sample, log-probabilities, probabilities).  Same values as ``factory(logits)`` + ``_st_onehot`` -- a dozen
+    eager launches per level --, same gradients: the sample's gradient flows into the probabilities (``onehot + p - p.detach()``)."""
+
+    @staticmethod
+    def forward(ctx, logits: Tensor, u: Tensor, cats: int, classes: int):  # noqa: ANN001, ANN205
+        from multimodal_mtrssm_amd import _lib  # noqa: PLC0415
+
+        ctx.set_materialize_grads(False)
+        logits, u = logits.contiguous().float(), u.contiguous().float()
+        rows = logits.numel() // (cats * classes)
+        logp = torch.empty(*logits.shape[:-1], cats, classes, device=logits.device, dtype=torch.float32)
+        probs, onehot = torch.empty_like(logp), torch.empty_like(logits)
+        _lib.check(_lib.load().mtrssm_categorical_sample_fwd(_lib.ptr(logits), _lib.ptr(u), rows, cats, classes, _lib.ptr(logp), _lib.ptr(probs),
+                                                             _lib.ptr(onehot), _lib.stream_ptr(logits.device)), "mtrssm_categorical_sample_fwd")
+        ctx.save_for_backward(probs)
+        ctx.dims = (rows, cats, classes)
+        return onehot, logp, probs
+
+    @staticmethod
+    def backward(ctx, g_stoch, g_logp, g_probs):  # noqa: ANN001, ANN205
+        from multimodal_mtrssm_amd import _lib  # noqa: PLC0415
+
+        (probs,) = ctx.saved_tensors
+        rows, cats, classes = ctx.dims
+        gp = None
+        if g_stoch is not None:
+            gp = g_stoch.reshape(probs.shape)
+        if g_probs is not None:
+            gp = g_probs if gp is None else gp + g_probs
+        if gp is None and g_logp is None:
+            return None, None, None, None
+        gp = None if gp is None else gp.contiguous().float()
+        gl = None if g_logp is None else g_logp.contiguous().float()
+        d = torch.empty(*probs.shape[:-2], cats * classes, device=probs.device, dtype=torch.float32)
+        _lib.check(_lib.load().mtrssm_categorical_sample_bwd(_lib.ptr(probs), _lib.ptr(gp), _lib.ptr(gl), rows, cats, classes, _lib.ptr(d),
+                                                             _lib.stream_ptr(probs.device)), "mtrssm_categorical_sample_bwd")
+        return d, None, None, None
+
+
+def _sampled_head(factory, logits: Tensor, u: Tensor | None) -> tuple[MultiOneHot, Tensor]:  # noqa: ANN001
+    """``(factory(logits), straight-through sample)``: one fused launch on the GPU when the uniforms are given."""
+    if not logits.is_cuda:
+        dist = factory(logits)
+        return dist, _st_onehot(dist, u)
+    if u is None:  # (the draw MultiOneHot.rsample would make: injected noise tape or the device generator)
+        u = draw_uniforms((*logits.shape[:-1], factory.category_size), logits)
+    stoch, logp, probs = _CategoricalHead.apply(logits, u.to(logits), factory.category_size, factory.class_size)
+    return MultiOneHot(logp, probs), stoch
 
 
 def _rand(like: Tensor, *shape: int) -> Tensor:
@@ -150,8 +202,8 @@ class MoPoE_MRSSM(_Base):  # noqa: N801
     def _initial_from_embed(self, obs_embed: Tensor, u_init: Tensor | None) -> State:
         deter = self.init_proj(obs_embed)
         logits = self.transition.rnn_to_prior_projector(deter)
-        dist = self.representation.distribution_factory(logits)
-        return State(deter=deter, distribution=dist, stoch=_st_onehot(dist, u_init))
+        dist, stoch = _sampled_head(self.representation.distribution_factory, logits, u_init)
+        return State(deter=deter, distribution=dist, stoch=stoch)
 
     def initial_state(self, observation: tuple[Tensor, Tensor] | Tensor, noise: Noise | None = None) -> State:
         """``core.py:121-135``: fused embedding -> ``init_proj`` -> prior head -> sampled State."""
@@ -306,12 +358,12 @@ class MoPoE_MMTRSSM(MoPoE_MRSSM):  # noqa: N801
     def _initial_from_embed(self, obs_embed: Tensor, noise: Noise | None) -> MTState:  # type: ignore[override]
         h = self.init_proj(obs_embed)
         higher, lower = h[..., : self.hd_dim], h[..., self.hd_dim :]
-        h_dist = self.h_dist(self.h_prior(higher))
-        l_dist = self.l_dist(self.l_prior(lower))
         noise = noise or {}
+        h_dist, stoch_h = _sampled_head(self.h_dist, self.h_prior(higher), noise.get("u_init_h"))
+        l_dist, stoch_l = _sampled_head(self.l_dist, self.l_prior(lower), noise.get("u_init_l"))
         return MTState(
             deter_h=higher, deter_l=lower, distribution_h=h_dist, distribution_l=l_dist, hidden_h=higher, hidden_l=lower,
-            stoch_h=_st_onehot(h_dist, noise.get("u_init_h")), stoch_l=_st_onehot(l_dist, noise.get("u_init_l")),
+            stoch_h=stoch_h, stoch_l=stoch_l,
         )
 
     def initial_state(self, observation: tuple[Tensor, Tensor] | Tensor, noise: Noise | None = None) -> MTState:  # type: ignore[override]

@@ -41,6 +41,8 @@ int conv_convt_quad_launch(const MtrssmConvGeom*, const float*, const unsigned s
                            const MtrssmConvGeom*, const float*, const unsigned short* const*, const float*, const float*, float*, hipStream_t);
 int conv_tgather_thin_launch(int, int, int, int, int, int, int, int, int, int, int, const float*, const float*, const float*, int, int, const float*,
                              const float*, float*, hipStream_t);
+int categorical_sample_fwd_launch(const float*, const float*, int64_t, int, int, float*, float*, float*, hipStream_t);
+int categorical_sample_bwd_launch(const float*, const float*, const float*, int64_t, int, int, float*, hipStream_t);
 int nll_fwd_launch(const float*, const float*, int64_t, int64_t, int, float*, hipStream_t);
 int nll_bwd_launch(const float*, const float*, const float*, int64_t, int64_t, int, float*, hipStream_t);
 int sumsq_launch(const float*, int64_t, float*, hipStream_t);
@@ -106,6 +108,14 @@ MTRSSM_API int mtrssm_mmtrssm_rollout_fwd(const MtrssmMmtrssmDims* d, const Mtrs
 }
 MTRSSM_API int mtrssm_mmtrssm_rollout_bwd(const MtrssmMmtrssmDims* d, const MtrssmMmtrssmBwdWeights* w, const MtrssmMmtrssmBwdIO* io, void* stream) {
   return mmtrssm_bwd_launch(d, w, io, static_cast<hipStream_t>(stream));
+}
+MTRSSM_API int mtrssm_categorical_sample_fwd(const float* logits, const float* u, int64_t rows, int32_t K, int32_t C, float* logp, float* probs,
+                                            float* onehot, void* stream) {
+  return categorical_sample_fwd_launch(logits, u, rows, K, C, logp, probs, onehot, static_cast<hipStream_t>(stream));
+}
+MTRSSM_API int mtrssm_categorical_sample_bwd(const float* probs, const float* g_probs, const float* g_logp, int64_t rows, int32_t K, int32_t C,
+                                            float* d_logits, void* stream) {
+  return categorical_sample_bwd_launch(probs, g_probs, g_logp, rows, K, C, d_logits, static_cast<hipStream_t>(stream));
 }
 MTRSSM_API int mtrssm_gaussian_nll_fwd(const float* pred, const float* target, int64_t frames, int64_t event, int32_t act, float* out, void* stream) {
   return nll_fwd_launch(pred, target, frames, event, act, out, static_cast<hipStream_t>(stream));

@@ -209,6 +209,74 @@ static int check_launch(const char* what) {
   return MTRSSM_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Categorical head of the INITIAL state (core.py:121-135; mmtrssm core.py:321-362): flat logits [rows][K * C] + one uniform per
+// categorical -> log-probabilities, probabilities and the inverse-CDF one-hot sample, one thread per (row, categorical), the
+// classes walked in order (the cumulative sum is a left fold, as torch's on the host).  Replaces a dozen eager launches per
+// level (softmax, log_softmax, cumsum, compare, sum, one_hot, the straight-through add / sub).
+// ------------------------------------------------------------------------------------------------
+__global__ void categorical_sample_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ u, int64_t n, int C,
+                                              float* __restrict__ logp, float* __restrict__ probs, float* __restrict__ onehot) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // (row, categorical)
+  if (i >= n) return;
+  const float* x = logits + i * C;
+  float m = x[0];
+  for (int c = 1; c < C; ++c) m = fmaxf(m, x[c]);
+  float sum = 0.f;
+  for (int c = 0; c < C; ++c) sum += expf(x[c] - m);
+  const float ls = logf(sum), uu = u[i];
+  float acc = 0.f;
+  int idx = 0;
+  for (int c = 0; c < C; ++c) {
+    const float p = expf(x[c] - m) / sum;
+    probs[i * C + c] = p;
+    logp[i * C + c] = (x[c] - m) - ls;
+    acc += p;
+    if (c + 1 < C && acc <= uu) ++idx;
+  }
+  for (int c = 0; c < C; ++c) onehot[i * C + c] = c == idx ? 1.f : 0.f;
+}
+
+// d logits of the same head: through the probabilities (g_p: the straight-through sample's gradient plus any gradient of the
+// probabilities themselves; may be null) and through the log-probabilities (g_l, may be null):
+//   d x_c = p_c (g_p[c] - sum_j p_j g_p[j]) + g_l[c] - p_c sum_j g_l[j]
+__global__ void categorical_sample_bwd_kernel(const float* __restrict__ probs, const float* __restrict__ g_p, const float* __restrict__ g_l,
+                                              int64_t n, int C, float* __restrict__ d_logits) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float dot = 0.f, sl = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float p = probs[i * C + c];
+    if (g_p) dot += p * g_p[i * C + c];
+    if (g_l) sl += g_l[i * C + c];
+  }
+  for (int c = 0; c < C; ++c) {
+    const float p = probs[i * C + c];
+    float d = 0.f;
+    if (g_p) d += p * (g_p[i * C + c] - dot);
+    if (g_l) d += g_l[i * C + c] - p * sl;
+    d_logits[i * C + c] = d;
+  }
+}
+
+int categorical_sample_fwd_launch(const float* logits, const float* u, int64_t rows, int K, int C, float* logp, float* probs, float* onehot,
+                                  hipStream_t s) {
+  if (!logits || !u || !logp || !probs || !onehot || rows <= 0 || K <= 0 || C <= 0) { set_error("categorical_sample_fwd: bad argument"); return MTRSSM_EINVAL; }
+  const int64_t n = rows * K;
+  set_last_kernel("mtrssm::categorical_sample_fwd_kernel");
+  hipLaunchKernelGGL(categorical_sample_fwd_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, logits, u, n, C, logp, probs, onehot);
+  return check_launch("categorical_sample_fwd");
+}
+
+int categorical_sample_bwd_launch(const float* probs, const float* g_p, const float* g_l, int64_t rows, int K, int C, float* d_logits,
+                                  hipStream_t s) {
+  if (!probs || !d_logits || rows <= 0 || K <= 0 || C <= 0) { set_error("categorical_sample_bwd: bad argument"); return MTRSSM_EINVAL; }
+  const int64_t n = rows * K;
+  set_last_kernel("mtrssm::categorical_sample_bwd_kernel");
+  hipLaunchKernelGGL(categorical_sample_bwd_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, probs, g_p, g_l, n, C, d_logits);
+  return check_launch("categorical_sample_bwd");
+}
+
 int nll_fwd_launch(const float* pred, const float* target, int64_t frames, int64_t event, int act, float* out, hipStream_t s) {
   if (!pred || !target || !out || frames <= 0 || event <= 0) { set_error("gaussian_nll_fwd: bad argument"); return MTRSSM_EINVAL; }
   if (act != MTRSSM_ACT_IDENTITY && act != MTRSSM_ACT_TANH) { set_error("gaussian_nll: the fused output activation is Identity or Tanh (got %d)", act); return MTRSSM_EINVAL; }
