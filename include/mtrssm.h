@@ -545,6 +545,13 @@ int mtrssm_channel_sum(const float* x, int32_t N, int32_t C, int32_t HW, float* 
 int mtrssm_episode_gather(const float* store, const int64_t* idx, const float* noise, int64_t n_episodes, int64_t B, int64_t T,
                           int64_t Tfull, int64_t E, float std_, float* input, float* target, void* stream);
 
+/* The scalar end of shared_step (core.py:187-221; mmtrssm core.py:563-606) in one launch each way:
+ *   recon = nll_a + nll_v;  kl_j = c_j * mean_i kl_j[i], i < n (kl1 may be NULL);  loss = recon + kl_0 + kl_1, written to four scalars (o_k1 may be NULL).
+ * bwd: scalar gradients of those four (each may be NULL = 0) -> g_nll_a = g_nll_v = g_recon + g_loss, g_kl_j[i] = (g_kl_j + g_loss) c_j / n. */
+int mtrssm_elbo_combine_fwd(const float* nll_a, const float* nll_v, const float* kl0, const float* kl1, int64_t n, float c0, float c1,
+                            float* o_recon, float* o_k0, float* o_k1, float* o_loss, void* stream);
+int mtrssm_elbo_combine_bwd(const float* g_recon, const float* g_k0, const float* g_k1, const float* g_loss, int64_t n, float c0, float c1,
+                            float* g_nll_a, float* g_nll_v, float* g_kl0, float* g_kl1, void* stream);
 /* Categorical head of the initial state (core.py:121-135, mmtrssm core.py:321-362): `logits` [rows][K * C] flat (K categoricals
  * of C classes, softmax over classes), `u` [rows][K] uniforms -> logp, probs [rows][K][C] and the inverse-CDF one-hot sample
  * onehot [rows][K * C] (index = #{c <= C - 2 : cumulative probability <= u}, the cumulative sum a left fold).  The straight-through

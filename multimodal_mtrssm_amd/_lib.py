@@ -126,6 +126,8 @@ SYMBOLS: dict[str, tuple[type | None, list[type]]] = {
                                     _p, _p, _p, _p]),
     "mtrssm_conv_tgather_thin": (C.c_int, [_i] * 11 + [_p, _p, _p, _i, _i, _p, _p, _p, _p]),
     "mtrssm_episode_gather": (C.c_int, [_p, _p, _p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _f, _p, _p, _p]),
+    "mtrssm_elbo_combine_fwd": (C.c_int, [_p, _p, _p, _p, C.c_int64, C.c_float, C.c_float, _p, _p, _p, _p, _p]),
+    "mtrssm_elbo_combine_bwd": (C.c_int, [_p, _p, _p, _p, C.c_int64, C.c_float, C.c_float, _p, _p, _p, _p, _p]),
     "mtrssm_categorical_sample_fwd": (C.c_int, [_p, _p, C.c_int64, _i, _i, _p, _p, _p, _p]),
     "mtrssm_categorical_sample_bwd": (C.c_int, [_p, _p, _p, C.c_int64, _i, _i, _p, _p]),
     "mtrssm_gaussian_nll_fwd": (C.c_int, [_p, _p, C.c_int64, C.c_int64, _i, _p, _p]),

@@ -98,6 +98,53 @@ class _CategoricalHead(torch.autograd.Function):
         return d, None, None, None
 
 
+class _ElboCombine(torch.autograd.Function):
+    """``recon = nll_a + nll_v; kl_j = coeff_j mean(kl_bt_j); loss = recon + sum kl_j`` in one launch each way
+    (``mtrssm_elbo_combine_fwd / _bwd``) instead of the eager add / mean / mul / add chain and its autograd nodes."""
+
+    @staticmethod
+    def forward(ctx, nll_a: Tensor, nll_v: Tensor, kl0: Tensor, kl1: Tensor | None, c0: float, c1: float):  # noqa: ANN001, ANN205, PLR0913
+        from multimodal_mtrssm_amd import _lib  # noqa: PLC0415
+
+        ctx.set_materialize_grads(False)
+        nll_a, nll_v, kl0 = nll_a.contiguous().float(), nll_v.contiguous().float(), kl0.contiguous().float()
+        kl1 = None if kl1 is None else kl1.contiguous().float()
+        outs = [torch.empty((), device=kl0.device, dtype=torch.float32) for _ in range(4)]
+        _lib.check(_lib.load().mtrssm_elbo_combine_fwd(_lib.ptr(nll_a), _lib.ptr(nll_v), _lib.ptr(kl0), _lib.ptr(kl1), kl0.numel(), float(c0), float(c1),
+                                                       _lib.ptr(outs[0]), _lib.ptr(outs[1]), _lib.ptr(outs[2]) if kl1 is not None else None,
+                                                       _lib.ptr(outs[3]), _lib.stream_ptr(kl0.device)), "mtrssm_elbo_combine_fwd")
+        ctx.meta = (kl0.shape, None if kl1 is None else kl1.shape, float(c0), float(c1))
+        ctx.dev = kl0.device
+        return outs[0], outs[1], outs[2], outs[3]
+
+    @staticmethod
+    def backward(ctx, g_recon, g_k0, g_k1, g_loss):  # noqa: ANN001, ANN205
+        from multimodal_mtrssm_amd import _lib  # noqa: PLC0415
+
+        shape0, shape1, c0, c1 = ctx.meta
+        n = 1
+        for d in shape0:
+            n *= d
+        g_a, g_v = (torch.empty((), device=ctx.dev, dtype=torch.float32) for _ in range(2))
+        g_kl0 = torch.empty(shape0, device=ctx.dev, dtype=torch.float32)
+        g_kl1 = None if shape1 is None else torch.empty(shape1, device=ctx.dev, dtype=torch.float32)
+        opt = lambda t: None if t is None else _lib.ptr(t.contiguous().float())  # noqa: E731
+        _lib.check(_lib.load().mtrssm_elbo_combine_bwd(opt(g_recon), opt(g_k0), opt(g_k1) if shape1 is not None else None, opt(g_loss), n, c0, c1,
+                                                       _lib.ptr(g_a), _lib.ptr(g_v), _lib.ptr(g_kl0), _lib.ptr(g_kl1), _lib.stream_ptr(ctx.dev)),
+                   "mtrssm_elbo_combine_bwd")
+        return g_a, g_v, g_kl0, g_kl1, None, None
+
+
+def _elbo(nll_a: Tensor, nll_v: Tensor, kl0: Tensor, c0: float, kl1: Tensor | None = None, c1: float = 0.0) -> tuple[Tensor, Tensor, Tensor, Tensor]:
+    """``(recon, kl_0, kl_1, loss)``; on the GPU one fused launch, elsewhere the eager arithmetic of the reference."""
+    if kl0.is_cuda and nll_a.dim() == 0 and nll_v.dim() == 0:
+        return _ElboCombine.apply(nll_a, nll_v, kl0, kl1, c0, c1)
+    recon = nll_a + nll_v
+    k0 = kl0.mean().mul(c0)
+    k1 = kl1.mean().mul(c1) if kl1 is not None else torch.zeros((), device=kl0.device)
+    return recon, k0, k1, recon + k0 + (k1 if kl1 is not None else 0.0)
+
+
 def _sampled_head(factory, logits: Tensor, u: Tensor | None) -> tuple[MultiOneHot, Tensor]:  # noqa: ANN001
     """``(factory(logits), straight-through sample)``: one fused launch on the GPU when the uniforms are given."""
     if not logits.is_cuda:
@@ -175,6 +222,8 @@ class MoPoE_MRSSM(_Base):  # noqa: N801
     def compute_reconstruction_loss(reconstructions: dict[str, Tensor], targets: dict[str, Tensor]) -> dict[str, Tensor]:
         audio = likelihood(prediction=reconstructions["recon/audio"], target=targets["recon/audio"], event_ndims=3)
         vision = likelihood(prediction=reconstructions["recon/vision"], target=targets["recon/vision"], event_ndims=3)
+        if not sum_recon:  # (shared_step adds them in its fused scalar epilogue)
+            return {"recon/audio": audio, "recon/vision": vision}
         return {"recon": audio + vision, "recon/audio": audio, "recon/vision": vision}
 
     def _encode_both(self, audio_obs: Tensor, vision_obs: Tensor) -> tuple[Tensor, Tensor]:
@@ -183,7 +232,7 @@ class MoPoE_MRSSM(_Base):  # noqa: N801
             return cnn.encode_pair(self.audio_encoder, self.vision_encoder, audio_obs, vision_obs)
         return self.audio_encoder(audio_obs), self.vision_encoder(vision_obs)
 
-    def _reconstruction_losses(self, feature: Tensor, targets: dict[str, Tensor]) -> dict[str, Tensor]:
+    def _reconstruction_losses(self, feature: Tensor, targets: dict[str, Tensor], *, sum_recon: bool = True) -> dict[str, Tensor]:
         """``decode_state`` + ``compute_reconstruction_loss`` (``mrssm core.py:262-308``).  With this package's decoders the
         out_activation (Tanh) is applied inside the NLL kernels: the activated reconstructions are never written in training."""
         da, dv = self.audio_decoder, self.vision_decoder
@@ -196,6 +245,8 @@ class MoPoE_MRSSM(_Base):  # noqa: N801
             pa, pv = da(feature), dv(feature)
         audio = likelihood(prediction=pa, target=targets["recon/audio"], event_ndims=3, out_act=da.out_act_id if fused else 0)
         vision = likelihood(prediction=pv, target=targets["recon/vision"], event_ndims=3, out_act=dv.out_act_id if fused else 0)
+        if not sum_recon:  # (shared_step adds them in its fused scalar epilogue)
+            return {"recon/audio": audio, "recon/vision": vision}
         return {"recon": audio + vision, "recon/audio": audio, "recon/vision": vision}
 
     # -- states ---------------------------------------------------------------------------------
@@ -276,11 +327,9 @@ class MoPoE_MRSSM(_Base):  # noqa: N801
         state0 = self._initial_from_embed((audio_embed[:, 0] + vision_embed[:, 0]) / 2.0, u_init)
         out = self._rollout_embedded(action_input, audio_embed, vision_embed, state0, noise, sample_prior=False)
         feature = torch.cat([out["deter"], out["post_stoch"]], dim=-1)
-        loss_dict = self._reconstruction_losses(feature, self.get_targets_from_batch(batch))
-        kl_div = out["kl"].mean().mul(self.kl_coeff)
-        loss_dict["kl"] = kl_div
-        loss_dict["loss"] = loss_dict["recon"] + kl_div
-        return loss_dict
+        parts = self._reconstruction_losses(feature, self.get_targets_from_batch(batch), sum_recon=False)
+        recon, kl_div, _, loss = _elbo(parts["recon/audio"], parts["recon/vision"], out["kl"], float(self.kl_coeff))
+        return {"recon": recon, **parts, "kl": kl_div, "loss": loss}
 
     def _step(self, batch: tuple[Tensor, ...], prefix: str, *, with_loss_key: bool) -> dict[str, Tensor]:
         loss_dict = self.shared_step(batch)
@@ -440,13 +489,10 @@ class MoPoE_MMTRSSM(MoPoE_MRSSM):  # noqa: N801
         state0 = self._initial_from_embed((audio_embed[:, 0] + vision_embed[:, 0]) / 2.0, noise)
         out = self._rollout_embedded(action_input, audio_embed, vision_embed, state0, noise, sample_prior=False)
         feature = torch.cat([out["deter_h"], out["post_stoch_h"], out["deter_l"], out["post_stoch_l"]], dim=-1)
-        loss_dict = self._reconstruction_losses(feature, self.get_targets_from_batch(batch))
-        kl_div_l = out["kl_l"].mean().mul(self.kl_coeff)
-        kl_div_h = out["kl_h"].mean().mul(self.kl_coeff * self.w_kl_h)
-        loss_dict["kl"] = kl_div_l
-        loss_dict["kl_h"] = kl_div_h
-        loss_dict["loss"] = loss_dict["recon"] + kl_div_l + kl_div_h
-        return loss_dict
+        parts = self._reconstruction_losses(feature, self.get_targets_from_batch(batch), sum_recon=False)
+        recon, kl_div_l, kl_div_h, loss = _elbo(parts["recon/audio"], parts["recon/vision"], out["kl_l"], float(self.kl_coeff), out["kl_h"],
+                                                float(self.kl_coeff * self.w_kl_h))
+        return {"recon": recon, **parts, "kl": kl_div_l, "kl_h": kl_div_h, "loss": loss}
 
 
 __all__ = ["MoPoE_MMTRSSM", "MoPoE_MRSSM", "kl_divergence"]

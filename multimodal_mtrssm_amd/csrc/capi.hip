@@ -43,6 +43,8 @@ int conv_tgather_thin_launch(int, int, int, int, int, int, int, int, int, int, i
                              const float*, float*, hipStream_t);
 int categorical_sample_fwd_launch(const float*, const float*, int64_t, int, int, float*, float*, float*, hipStream_t);
 int categorical_sample_bwd_launch(const float*, const float*, const float*, int64_t, int, int, float*, hipStream_t);
+int elbo_combine_fwd_launch(const float*, const float*, const float*, const float*, int64_t, float, float, float*, float*, float*, float*, hipStream_t);
+int elbo_combine_bwd_launch(const float*, const float*, const float*, const float*, int64_t, float, float, float*, float*, float*, float*, hipStream_t);
 int nll_fwd_launch(const float*, const float*, int64_t, int64_t, int, float*, hipStream_t);
 int nll_bwd_launch(const float*, const float*, const float*, int64_t, int64_t, int, float*, hipStream_t);
 int sumsq_launch(const float*, int64_t, float*, hipStream_t);
@@ -116,6 +118,14 @@ MTRSSM_API int mtrssm_categorical_sample_fwd(const float* logits, const float* u
 MTRSSM_API int mtrssm_categorical_sample_bwd(const float* probs, const float* g_probs, const float* g_logp, int64_t rows, int32_t K, int32_t C,
                                             float* d_logits, void* stream) {
   return categorical_sample_bwd_launch(probs, g_probs, g_logp, rows, K, C, d_logits, static_cast<hipStream_t>(stream));
+}
+MTRSSM_API int mtrssm_elbo_combine_fwd(const float* nll_a, const float* nll_v, const float* kl0, const float* kl1, int64_t n, float c0, float c1,
+                                      float* o_recon, float* o_k0, float* o_k1, float* o_loss, void* stream) {
+  return elbo_combine_fwd_launch(nll_a, nll_v, kl0, kl1, n, c0, c1, o_recon, o_k0, o_k1, o_loss, static_cast<hipStream_t>(stream));
+}
+MTRSSM_API int mtrssm_elbo_combine_bwd(const float* g_recon, const float* g_k0, const float* g_k1, const float* g_loss, int64_t n, float c0,
+                                      float c1, float* g_nll_a, float* g_nll_v, float* g_kl0, float* g_kl1, void* stream) {
+  return elbo_combine_bwd_launch(g_recon, g_k0, g_k1, g_loss, n, c0, c1, g_nll_a, g_nll_v, g_kl0, g_kl1, static_cast<hipStream_t>(stream));
 }
 MTRSSM_API int mtrssm_gaussian_nll_fwd(const float* pred, const float* target, int64_t frames, int64_t event, int32_t act, float* out, void* stream) {
   return nll_fwd_launch(pred, target, frames, event, act, out, static_cast<hipStream_t>(stream));

@@ -277,6 +277,59 @@ int categorical_sample_bwd_launch(const float* probs, const float* g_p, const fl
   return check_launch("categorical_sample_bwd");
 }
 
+// ------------------------------------------------------------------------------------------------
+// The scalar end of shared_step (core.py:187-221; mmtrssm core.py:563-606) in one launch each way:
+//   recon = nll_a + nll_v;  kl_j = coeff_j * mean(kl_bt_j)  (j < nkl <= 2);  loss = recon + sum_j kl_j
+// Four scalar outputs (o_k1 may be null).  Backward: g = { g_recon, g_kl_0, g_kl_1, g_loss } (any may be null = 0) ->
+// g_nll_a = g_nll_v = g_recon + g_loss;  g_kl_bt_j[i] = (g_kl_j + g_loss) * coeff_j / n.
+// ------------------------------------------------------------------------------------------------
+__global__ void elbo_combine_fwd_kernel(const float* __restrict__ nll_a, const float* __restrict__ nll_v, const float* __restrict__ kl0,
+                                        const float* __restrict__ kl1, int64_t n, float c0, float c1, float* __restrict__ o_recon, float* __restrict__ o_k0,
+                                        float* __restrict__ o_k1, float* __restrict__ o_loss) {
+  __shared__ float red[kThreads / kWave];
+  float a0 = 0.f, a1 = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+    a0 += kl0[i];
+    if (kl1) a1 += kl1[i];
+  }
+  const float s0 = block_sum(a0, red);
+  __syncthreads();
+  const float s1 = block_sum(a1, red);
+  if (threadIdx.x == 0) {
+    const float recon = nll_a[0] + nll_v[0];
+    const float k0 = s0 / (float)n * c0, k1 = kl1 ? s1 / (float)n * c1 : 0.f;
+    o_recon[0] = recon; o_k0[0] = k0; if (o_k1) o_k1[0] = k1; o_loss[0] = recon + k0 + k1;
+  }
+}
+__global__ void elbo_combine_bwd_kernel(const float* __restrict__ g_recon, const float* __restrict__ g_k0, const float* __restrict__ g_k1,
+                                        const float* __restrict__ g_loss, int64_t n, float c0, float c1, float* __restrict__ g_nll_a,
+                                        float* __restrict__ g_nll_v, float* __restrict__ g_kl0, float* __restrict__ g_kl1) {
+  const float gl = g_loss ? g_loss[0] : 0.f;
+  const float gn = (g_recon ? g_recon[0] : 0.f) + gl;
+  const float v0 = ((g_k0 ? g_k0[0] : 0.f) + gl) * c0 / (float)n, v1 = ((g_k1 ? g_k1[0] : 0.f) + gl) * c1 / (float)n;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) { g_nll_a[0] = gn; g_nll_v[0] = gn; }
+  if (i < n) {
+    g_kl0[i] = v0;
+    if (g_kl1) g_kl1[i] = v1;
+  }
+}
+int elbo_combine_fwd_launch(const float* nll_a, const float* nll_v, const float* kl0, const float* kl1, int64_t n, float c0, float c1,
+                            float* o_recon, float* o_k0, float* o_k1, float* o_loss, hipStream_t s) {
+  if (!nll_a || !nll_v || !kl0 || !o_recon || !o_k0 || !o_loss || n <= 0) { set_error("elbo_combine_fwd: bad argument"); return MTRSSM_EINVAL; }
+  set_last_kernel("mtrssm::elbo_combine_fwd_kernel");
+  hipLaunchKernelGGL(elbo_combine_fwd_kernel, dim3(1), dim3(kThreads), 0, s, nll_a, nll_v, kl0, kl1, n, c0, c1, o_recon, o_k0, o_k1, o_loss);
+  return check_launch("elbo_combine_fwd");
+}
+int elbo_combine_bwd_launch(const float* g_recon, const float* g_k0, const float* g_k1, const float* g_loss, int64_t n, float c0, float c1,
+                            float* g_nll_a, float* g_nll_v, float* g_kl0, float* g_kl1, hipStream_t s) {
+  if (!g_nll_a || !g_nll_v || !g_kl0 || n <= 0) { set_error("elbo_combine_bwd: bad argument"); return MTRSSM_EINVAL; }
+  set_last_kernel("mtrssm::elbo_combine_bwd_kernel");
+  hipLaunchKernelGGL(elbo_combine_bwd_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, g_recon, g_k0, g_k1, g_loss, n,
+                     c0, c1, g_nll_a, g_nll_v, g_kl0, g_kl1);
+  return check_launch("elbo_combine_bwd");
+}
+
 int nll_fwd_launch(const float* pred, const float* target, int64_t frames, int64_t event, int act, float* out, hipStream_t s) {
   if (!pred || !target || !out || frames <= 0 || event <= 0) { set_error("gaussian_nll_fwd: bad argument"); return MTRSSM_EINVAL; }
   if (act != MTRSSM_ACT_IDENTITY && act != MTRSSM_ACT_TANH) { set_error("gaussian_nll: the fused output activation is Identity or Tanh (got %d)", act); return MTRSSM_EINVAL; }

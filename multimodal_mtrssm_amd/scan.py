@@ -327,7 +327,7 @@ class _MrssmScan(torch.autograd.Function):
                                   sv["sv_gates"], sv["sv_heads"], sv["sv_la"], sv["sv_lv"], w1s_t, wh1,
                                   w1, w2, wih, whh, w4, wa1, wa2, wv1, wv2)
         ctx.has_prior_stoch = prior_stoch is not None
-        outs = (deter, prior_logits, post_logits, post_stoch, prior_stoch if prior_stoch is not None else deter.new_zeros(()), kl)
+        outs = (deter, prior_logits, post_logits, post_stoch, prior_stoch if prior_stoch is not None else deter.new_empty(()), kl)  # (placeholder, never read: no fill launch)
         return outs
 
     @staticmethod
@@ -639,7 +639,7 @@ class _MmtrssmScan(torch.autograd.Function):
                 o["post_logits_l"], o["post_logits_h"], o["post_stoch_l"], o["post_stoch_h"], sv["sv_l1"], sv["sv_h1"],
                 sv["sv_la"], sv["sv_lv"], wxl_s_t, wxh_t, wl1, wh1, wxl, wdl, wxh, wdh, wlp2, wa1, wa2, wv1, wv2, whp2, whq1, whq2)
         ctx.has_prior = (o["prior_stoch_l"] is not None, o["prior_stoch_h"] is not None)
-        z = o["deter_l"].new_zeros(())
+        z = o["deter_l"].new_empty(())  # placeholder for absent prior samples, never read: no fill launch
         return (o["deter_l"], o["deter_h"], o["hidden_l"], o["hidden_h"], o["prior_logits_l"], o["prior_logits_h"],
                 o["post_logits_l"], o["post_logits_h"], o["post_stoch_l"], o["post_stoch_h"],
                 o["prior_stoch_l"] if o["prior_stoch_l"] is not None else z,

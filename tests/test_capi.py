@@ -95,6 +95,8 @@ def test_invalid_arguments_are_rejected_without_a_launch() -> None:
     assert lib.mtrssm_convt_k4s2_band(0, 16, 64, 16, 1, None, None, None, 1, 2, None, None) == -1
     assert lib.mtrssm_categorical_sample_fwd(None, None, 4, 6, 5, None, None, None, None) == -1
     assert lib.mtrssm_categorical_sample_bwd(None, None, None, 4, 6, 5, None, None) == -1
+    assert lib.mtrssm_elbo_combine_fwd(None, None, None, None, 10, 1.0, 0.0, None, None, None, None, None) == -1
+    assert lib.mtrssm_elbo_combine_bwd(None, None, None, None, 10, 1.0, 0.0, None, None, None, None, None) == -1
     large = _lib.MrssmDims(32, 100, 1024, 1024, 16, 8, 2, 1, 0.2, 0.8, 0, 0)
     assert lib.mtrssm_mrssm_wide_supported(C.byref(large), 3) == 0  # no device here: the grid cannot be sized
     assert lib.mtrssm_mrssm_wide_workspace_bytes(C.byref(large), 3) > 60e6  # six bytes per weight of the ~10 M scan weights
