@@ -265,10 +265,7 @@ class _MrssmScan(torch.autograd.Function):
         # forward layouts (include/mtrssm.h: wide outputs stream W^T, narrow outputs stream W)
         w1s_t = _c(w1[:, A:].t())
         wh1 = torch.cat([w3, wa1[:, :D], wv1[:, :D]], dim=0)  # [3H, D]
-        fw = _lib.fill(
-            _lib.MrssmFwdWeights(), w1s_t=w1s_t, w2_t=_c(w2.t()), b2=_c(b2), wih_t=_c(wih.t()), bih=_c(bih), whh_t=_c(whh.t()),
-            bhh=_c(bhh), wh1_t=_c(wh1.t()), b3=_c(b3), w4=_c(w4), b4=_c(b4), wa2=_c(wa2), ba2=_c(ba2), wv2=_c(wv2), bv2=_c(bv2),
-        )
+        whh_t, wh1_t = _c(whh.t()), _c(wh1.t())
         deter = _new(xa, B, T, D)
         prior_logits, post_logits, post_stoch = (_new(xa, B, T, S) for _ in range(3))
         prior_stoch = _new(xa, B, T, S) if u_prior is not None else None
@@ -299,8 +296,8 @@ class _MrssmScan(torch.autograd.Function):
             gemm(w2, wih, wf_t, a_rmajor=True, b_rmajor=False)            # wf_t[k][j] = sum_h W2[h][k] W_ih[j][h]
             bf = _new(xa, 1, 3 * D)
             gemm(b2.reshape(1, H), wih, bf, a_rmajor=False, b_rmajor=False, bias=_c(bih))
-            cw = _lib.fill(_lib.MrssmClusterWeights(), w1s_t=w1s_t, wf_t=wf_t, bf=bf.reshape(-1), whh_t=fw._refs["whh_t"], bhh=_c(bhh),  # noqa: SLF001
-                           wh1_t=fw._refs["wh1_t"], b3=_c(b3), w4=_c(w4), b4=_c(b4), wa2=_c(wa2), ba2=_c(ba2), wv2=_c(wv2), bv2=_c(bv2))  # noqa: SLF001
+            cw = _lib.fill(_lib.MrssmClusterWeights(), w1s_t=w1s_t, wf_t=wf_t, bf=bf.reshape(-1), whh_t=whh_t, bhh=_c(bhh),
+                           wh1_t=wh1_t, b3=_c(b3), w4=_c(w4), b4=_c(b4), wa2=_c(wa2), ba2=_c(ba2), wv2=_c(wv2), bv2=_c(bv2))
             io.sv_h2 = None  # not produced on this path: recomputed in the backward where dW_ih needs it
             stream = _lib.stream_ptr(xa.device)
             if cluster:
@@ -314,9 +311,14 @@ class _MrssmScan(torch.autograd.Function):
                                             C.byref(io), WIDE_PIECES, _lib.raw_ptr(ws), ws.numel() * 8, stream,
                                             flops=2.0 * B * T * macs, nbytes=4.0 * B * T * per_bt), "mtrssm_mrssm_rollout_fwd_wide")
             sv["sv_h2"] = None
-            ctx.cluster_w = (wf_t, fw._refs["whh_t"], fw._refs["wh1_t"])  # noqa: SLF001
+            ctx.cluster_w = (wf_t, whh_t, wh1_t)
         else:
             ctx.cluster_w = None
+            # (the one-CU kernel takes W2 and W_ih themselves, transposed: two copies the fused-path kernels never need)
+            fw = _lib.fill(
+                _lib.MrssmFwdWeights(), w1s_t=w1s_t, w2_t=_c(w2.t()), b2=_c(b2), wih_t=_c(wih.t()), bih=_c(bih), whh_t=whh_t,
+                bhh=_c(bhh), wh1_t=wh1_t, b3=_c(b3), w4=_c(w4), b4=_c(b4), wa2=_c(wa2), ba2=_c(ba2), wv2=_c(wv2), bv2=_c(bv2),
+            )
             _lib.check(_lib.TIMERS.call("mtrssm_mrssm_rollout_fwd", lib.mtrssm_mrssm_rollout_fwd, C.byref(dims), C.byref(fw), C.byref(io),
                                         _lib.stream_ptr(xa.device), flops=2.0 * B * T * macs, nbytes=4.0 * B * T * per_bt),
                        "mtrssm_mrssm_rollout_fwd")
