@@ -1303,12 +1303,12 @@ static SplitPlan plan_split(const MtrssmConvGeom* g, bool has_wq) {
       (g->Ws == 4 || g->Ws == 8 || g->Ws == 16) && g->Hs * g->Ws == 64 && g->Hq == g->Hs && g->Wq == g->Ws && g->Ho == g->Hs && g->Wo == g->Ws && g->Cpad == g->C && g->OFFY == -g->TS &&
       g->OFFX == -g->TS && (long)g->N * g->C * 64 < (1L << 31) && g->act != MTRSSM_ACT_TANH) {
     const int key = g->C * 1000 + g->Cout;
-    const int fpt = key == 64064 || key == 32064 ? 2 : 1;  // frames per tile: whole tiles only
-    if ((key == 64064 || key == 64128 || key == 128064 || key == 32064) && g->N % fpt == 0) {
+    const int fpt = key == 64064 || key == 32064 || key == 64032 ? 2 : 1;  // frames per tile: whole tiles only
+    if ((key == 64064 || key == 64128 || key == 128064 || key == 32064 || key == 64032) && g->N % fpt == 0) {
       pl.kind = 3;
       pl.res = key;
       pl.nx = g->N;  // frames; launch_split turns them into workgroups
-      pl.lds = key == 64064 ? res_lds_bytes<64, 2, 1>() : key == 64128 ? res_lds_bytes<64, 4, 1>() : key == 128064 ? res_lds_bytes<128, 2, 2>()
+      pl.lds = key == 64032 ? res_lds_bytes<64, 1, 2>() : key == 64064 ? res_lds_bytes<64, 2, 1>() : key == 64128 ? res_lds_bytes<64, 4, 1>() : key == 128064 ? res_lds_bytes<128, 2, 2>()
                                                                                                      : res_lds_bytes<32, 2, 1>();
       return pl;
     }
@@ -1357,7 +1357,7 @@ static int launch_split(const SplitPlan& pl, size_t lds, const GatherProblem& pa
       if (int rc = launch_split(pl, lds, pa, none, stream)) return rc;
       return launch_split(pl, lds, pb, none, stream);
     }
-    const int fpt = pl.res == 64064 || pl.res == 32064 ? 2 : 1;  // frames per tile
+    const int fpt = pl.res == 64064 || pl.res == 32064 || pl.res == 64032 ? 2 : 1;  // frames per tile
     const long ta = (pa.nx + fpt - 1) / fpt, tb = (pb.nx + fpt - 1) / fpt;
     const int ncu = cu_count();
     GatherProblem qa = pa, qb = pb;
@@ -1390,6 +1390,7 @@ static int launch_split(const SplitPlan& pl, size_t lds, const GatherProblem& pa
     if (pl.res == 64128) MTRSSM_RES_LAUNCH(64, 4, 1)
     if (pl.res == 128064) MTRSSM_RES_LAUNCH(128, 2, 2)
     if (pl.res == 32064) MTRSSM_RES_LAUNCH(32, 2, 1)
+    if (pl.res == 64032) MTRSSM_RES_LAUNCH(64, 1, 2)   // the first stack conv's backward-data: 32 output channels, K split over wave pairs, two frames per tile
 #undef MTRSSM_RES_LAUNCH_E
 #undef MTRSSM_RES_LAUNCH
     set_error("conv_gather_gemm: no resident kernel for this plan");

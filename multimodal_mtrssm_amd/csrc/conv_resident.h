@@ -67,7 +67,7 @@ template <int CIN, int NCT, int KS>
 __host__ __device__ constexpr size_t res_lds_bytes() {
   constexpr int NPG = 4 / (NCT * KS);
   constexpr size_t run = (size_t)4 * NPG * kResPos * res_row_bytes(CIN) + (size_t)NCT * 32 * sizeof(float) +
-                         (KS == 2 ? (size_t)NCT * 2 * 16 * 64 * sizeof(float) : 0);
+                         (KS == 2 ? (size_t)NPG * NCT * 2 * 16 * 64 * sizeof(float) : 0);
   constexpr size_t stage = (size_t)res_group_rows(CIN) * res_wrow_bytes(CIN);
   return run > stage ? run : stage;
 }
@@ -100,12 +100,13 @@ __global__ __launch_bounds__(kResThreads, 1) void conv3x3_resident_kernel(const 
 
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   unsigned char* patch = lds_raw;                                            // [2 buffers][2 pieces][IMG]
-  float* red = reinterpret_cast<float*>(lds_raw + (size_t)4 * IMG);          // KS == 2: [NCT][2][8][64]
+  float* red = reinterpret_cast<float*>(lds_raw + (size_t)4 * IMG);          // KS == 2: [NPG][NCT][2][8][64]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kl = lane >> 5, il = lane & 31;
-  const int ct = KS == 2 ? (wave & 1) : (wave % NCT);
-  const int kh = KS == 2 ? (wave >> 1) : 0;
-  const int pgi = KS == 2 ? 0 : (wave / NCT);
+  // wave -> (output-channel tile, half of K, frame of the tile): <128, 2, 2>: (w & 1, w >> 1, 0); <64, 1, 2>: (0, w & 1, w >> 1)
+  const int ct = wave % NCT;
+  const int kh = (wave / NCT) % KS;
+  const int pgi = wave / (NCT * KS);
 
   unsigned long long* prof = (blockIdx.x == 0 && tid == 0) ? g_res_prof : nullptr;
   if (prof) prof[0] = __builtin_readcyclecounter();
@@ -362,8 +363,8 @@ __global__ __launch_bounds__(kResThreads, 1) void conv3x3_resident_kernel(const 
       }
       if (h == 0) MTRSSM_RES_STAMP(1);
       if (KS == 2) {  // the two halves of K meet: each wave hands over the rows it does not finish
-        float* mine = red + ((size_t)(ct * 2 + kh) * 8) * 64 + lane;
-        const float* theirs = red + ((size_t)(ct * 2 + (kh ^ 1)) * 8) * 64 + lane;
+        float* mine = red + ((size_t)((pgi * NCT + ct) * 2 + kh) * 8) * 64 + lane;
+        const float* theirs = red + ((size_t)((pgi * NCT + ct) * 2 + (kh ^ 1)) * 8) * 64 + lane;
 #pragma unroll
         for (int j = 0; j < 8; ++j) mine[j * 64] = kh == 0 ? acc[8 + j] : acc[j];
 #pragma unroll
