@@ -306,3 +306,52 @@ def test_conv_grad_sink_recovers_from_a_backward_that_raised() -> None:
     packed.fill_(2.0)
     sink.discard()  # nothing pending: a no-op (gradient accumulation across several backwards keeps its sums)
     assert float(packed.min()) == 2.0
+
+
+def test_scalar_epilogue_and_sampled_head_host_paths_follow_the_reference_arithmetic() -> None:
+    """``core._elbo`` and ``core._sampled_head`` off the GPU (the fused launches exist for CUDA tensors only): the eager arithmetic of
+    ``core.py:187-221`` / ``mmtrssm core.py:563-606`` and ``factory(logits)`` + the straight-through inverse-CDF sample."""
+    from multimodal_mtrssm_amd import core
+
+    g = torch.Generator().manual_seed(3)
+    nll_a, nll_v = torch.rand((), generator=g) * 100, torch.rand((), generator=g) * 100
+    kl0, kl1 = torch.rand(4, 7, generator=g), torch.rand(4, 7, generator=g)
+    recon, k0, k1, loss = core._elbo(nll_a, nll_v, kl0, 0.3, kl1, 0.6)  # noqa: SLF001
+    torch.testing.assert_close(recon, nll_a + nll_v)
+    torch.testing.assert_close(k0, kl0.mean().mul(0.3))
+    torch.testing.assert_close(k1, kl1.mean().mul(0.6))
+    torch.testing.assert_close(loss, nll_a + nll_v + kl0.mean().mul(0.3) + kl1.mean().mul(0.6))
+    recon1, k01, _, loss1 = core._elbo(nll_a, nll_v, kl0, 0.3)  # noqa: SLF001
+    torch.testing.assert_close(loss1, recon1 + k01)
+
+    factory = mt.MultiOneHotFactory(class_size=5, category_size=6)
+    logits = torch.randn(3, 30, generator=g, requires_grad=True)
+    u = torch.rand(3, 6, generator=g)
+    dist, stoch = core._sampled_head(factory, logits, u)  # noqa: SLF001
+    ref = ref_dists.MultiOneHotFactory(5, 6)(logits.detach())
+    torch.testing.assert_close(dist.probs, ref.probs)
+    ref_dists.TAPE.clear()
+    ref_dists.TAPE.push(u)
+    torch.testing.assert_close(stoch.detach(), ref.rsample())
+    weights = torch.randn(3, 30, generator=g)
+    (stoch * weights).sum().backward()  # the straight-through gradient reaches the logits through the probabilities
+    probs = dist.probs.detach()
+    gw = weights.reshape(3, 6, 5)
+    want = (probs * (gw - (probs * gw).sum(-1, keepdim=True))).reshape(3, 30)
+    torch.testing.assert_close(logits.grad, want)
+
+
+def test_pack_descriptor_of_a_view_that_fills_the_leading_taps_of_its_grid() -> None:
+    """``conv._pack_row``: the sub-kernels of a 3 x 3 kernel run as a zero-padded 4 x 4 transposed convolution are strided views of
+    the parameter with 2x2 / 2x1 / 1x2 / 1x1 taps, packed into a 2 x 2 tap grid -- descriptor words 5, 6 = the grid, 14, 15 = the
+    taps the view holds (0, 0 = all of them: an ordinary weight)."""
+    from multimodal_mtrssm_amd import conv
+
+    w = torch.randn(32, 16, 3, 3)
+    sub = w[:, :, 1::2, 0::2].permute(1, 0, 2, 3)   # one tap row, two tap columns
+    wp, wq = torch.zeros(32, 4, 32), None
+    row = conv._pack_row(sub, wp, wq, (2, 2))  # noqa: SLF001
+    assert row[3:7] == [16, 32, 2, 2] and row[14:16] == [1, 2] and len(row) == 16
+    assert row[7:11] == list(sub.stride())
+    full = conv._pack_row(w, torch.zeros(32, 9, 16), None, None)  # noqa: SLF001
+    assert full[5:7] == [3, 3] and full[14:16] == [0, 0]
