@@ -1543,13 +1543,18 @@ static int launch_s2_band(const GatherProblem& pa, const GatherProblem* pb, hipS
   return launched("conv_gather_gemm(s2 band)");
 }
 
-// conv4s2_band_kernel's shape: Conv2d(k 4, s 2, p 1) gather, 16 -> 32 channels, frames of 1024 positions (the backward-data of the
-// decoders' second ConvTranspose layer); MTRSSM_CONV_S2_BAND=0 switches it off with the other band kernels
-static bool s2k4_band_covers(const MtrssmConvGeom* g, bool has_wq, bool has_add) {
-  return s2_band_enabled() && g->mfma_split == 2 && has_wq && !has_add && g->KH == 4 && g->KW == 4 && g->SS == 2 && g->TS == 1 &&
-         g->OFFY == -1 && g->OFFX == -1 && g->OS == 1 && g->QY == 0 && g->QX == 0 && g->C == 16 && g->C2 == 0 && g->Cout == 32 &&
-         g->CoutPad == 32 && g->Cpad == 16 && g->Hs * g->Ws == 1024 && (g->Ws == 16 || g->Ws == 32) && g->Hq * 2 == g->Hs &&
-         g->Wq * 2 == g->Ws && g->Ho == g->Hq && g->Wo == g->Wq && g->act != MTRSSM_ACT_TANH && (long)g->N * 16 * 1024 < (1L << 29);
+// conv4s2_band_kernel's shapes: Conv2d(k 4, s 2, p 1) gather, 16 -> 32 channels on frames of 1024 positions and 32 -> 64 on frames of
+// 256 (the backward-data of the decoders' second and first ConvTranspose layers); MTRSSM_CONV_S2_BAND=0 switches it off with the
+// other band kernels
+static int s2k4_band_covers(const MtrssmConvGeom* g, bool has_wq, bool has_add) {   // 0: no; 1: 16 -> 32 on 1024 positions; 2: 32 -> 64 on 256
+  if (!(s2_band_enabled() && g->mfma_split == 2 && has_wq && !has_add && g->KH == 4 && g->KW == 4 && g->SS == 2 && g->TS == 1 &&
+        g->OFFY == -1 && g->OFFX == -1 && g->OS == 1 && g->QY == 0 && g->QX == 0 && g->C2 == 0 && g->Hq * 2 == g->Hs && g->Wq * 2 == g->Ws &&
+        g->Ho == g->Hq && g->Wo == g->Wq && g->act != MTRSSM_ACT_TANH && g->Cpad == g->C && g->CoutPad == g->Cout &&
+        (long)g->N * g->C * g->Hs * g->Ws < (1L << 29)))
+    return 0;
+  if (g->C == 16 && g->Cout == 32 && g->Hs * g->Ws == 1024 && (g->Ws == 16 || g->Ws == 32)) return 1;
+  if (g->C == 32 && g->Cout == 64 && g->Hs * g->Ws == 256 && (g->Ws == 8 || g->Ws == 16)) return 2;
+  return 0;
 }
 static int launch_s2k4_band(const GatherProblem& pa, const GatherProblem* pb, hipStream_t stream) {
   const long ta = pa.g.N, tb = pb ? pb->g.N : 0;
@@ -1565,16 +1570,28 @@ static int launch_s2k4_band(const GatherProblem& pa, const GatherProblem* pb, hi
     qa.nx = (int)(na < ta ? na : ta);
     qb.nx = (int)(slots - na < tb ? slots - na : tb);
   }
-  const int la = convt_band_lds_bytes(pa.g.Hs, pa.g.Ws), lb = pb ? convt_band_lds_bytes(pb->g.Hs, pb->g.Ws) : 0;
+  const int kind = s2k4_band_covers(&pa.g, true, false);
+  const int oct = pa.g.C / 8;
+  auto lds_of = [&](const MtrssmConvGeom& q) { return 2 * oct * ((q.Hs + 2) * (q.Ws + 2) + 1) * 16; };
+  const int la = lds_of(pa.g), lb = pb ? lds_of(pb->g) : 0;
   const size_t lds = (size_t)(la > lb ? la : lb);
-  static bool attr_done_dev[64] = {};
-  bool& attr_done = attr_done_dev[device_slot()];
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv4s2_band_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    attr_done = true;
+  static bool attr_done_dev[64][2] = {};
+  bool& attr_done = attr_done_dev[device_slot()][kind - 1];
+  if (kind == 1) {
+    if (!attr_done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv4s2_band_kernel<16, 32, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      attr_done = true;
+    }
+    set_last_kernel("mtrssm::conv4s2_band_kernel<16, 32, 1024>");
+    hipLaunchKernelGGL((conv4s2_band_kernel<16, 32, 1024>), dim3((unsigned)(qa.nx + qb.nx)), dim3(512), lds, stream, qa, qb);
+  } else {
+    if (!attr_done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv4s2_band_kernel<32, 64, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      attr_done = true;
+    }
+    set_last_kernel("mtrssm::conv4s2_band_kernel<32, 64, 256>");
+    hipLaunchKernelGGL((conv4s2_band_kernel<32, 64, 256>), dim3((unsigned)(qa.nx + qb.nx)), dim3(256), lds, stream, qa, qb);
   }
-  set_last_kernel("mtrssm::conv4s2_band_kernel");
-  hipLaunchKernelGGL(conv4s2_band_kernel, dim3((unsigned)(qa.nx + qb.nx)), dim3(512), lds, stream, qa, qb);
   return launched("conv_gather_gemm(s2 k4 band)");
 }
 
@@ -1654,7 +1671,7 @@ int conv_gather_pair_merges(const MtrssmConvGeom* ga, const MtrssmConvGeom* gb, 
   if (!ga || !gb || check_geom(ga, "conv_gather_gemm_pair") || check_geom(gb, "conv_gather_gemm_pair")) return 0;
   // (the band kernel's pair: epilogue operands are checked again at launch, where a pair with one falls back to two launches)
   if (s2_band_covers(ga, has_wq, false) && s2_band_covers(gb, has_wq, false) && ga->C == gb->C) return 1;
-  if (s2k4_band_covers(ga, has_wq, false) && s2k4_band_covers(gb, has_wq, false)) return 1;
+  if (s2k4_band_covers(ga, has_wq, false) && s2k4_band_covers(ga, has_wq, false) == s2k4_band_covers(gb, has_wq, false)) return 1;
   const bool thin_a = (ga->Cout <= 8 || ga->C + ga->C2 <= 2) && ga->Cout <= 16;
   const bool thin_b = (gb->Cout <= 8 || gb->C + gb->C2 <= 2) && gb->Cout <= 16;
   if (thin_a || thin_b) return 0;
@@ -1674,7 +1691,8 @@ int conv_gather_gemm_pair_launch(const MtrssmConvGeom* ga, const float* srca, co
     return launch_s2_band(p, &q, stream);
   }
   if (srca && srcb && outa && outb && ga && gb && !check_geom(ga, "conv_gather_gemm_pair") && !check_geom(gb, "conv_gather_gemm_pair") &&
-      s2k4_band_covers(ga, wqa != nullptr, adda != nullptr) && s2k4_band_covers(gb, wqb != nullptr, addb != nullptr)) {
+      s2k4_band_covers(ga, wqa != nullptr, adda != nullptr) &&
+      s2k4_band_covers(ga, wqa != nullptr, adda != nullptr) == s2k4_band_covers(gb, wqb != nullptr, addb != nullptr)) {
     GatherProblem p{}, q{};
     p.g = *ga; p.src = srca; p.wq = wqa; p.bias = biasa; p.actgrad_in = actgrada; p.out = outa;
     q.g = *gb; q.src = srcb; q.wq = wqb; q.bias = biasb; q.actgrad_in = actgradb; q.out = outb;
@@ -1683,7 +1701,7 @@ int conv_gather_gemm_pair_launch(const MtrssmConvGeom* ga, const float* srca, co
   if (srca && srcb && outa && outb && !(ga && ga->C2 > 0 && !src2a) && !(gb && gb->C2 > 0 && !src2b) &&
       conv_gather_pair_merges(ga, gb, wqa != nullptr && wqb != nullptr) &&
       !(s2_band_covers(ga, true, false) && s2_band_covers(gb, true, false) && ga->C == gb->C) &&
-      !(s2k4_band_covers(ga, true, false) && s2k4_band_covers(gb, true, false))) {
+      !(s2k4_band_covers(ga, true, false) && s2k4_band_covers(ga, true, false) == s2k4_band_covers(gb, true, false))) {
     const SplitPlan pa = plan_split(ga, true), pb = plan_split(gb, true);
     return launch_split(pa, pa.lds > pb.lds ? pa.lds : pb.lds, make_problem(ga, pa, srca, src2a, wqa, biasa, actgrada, adda, outa),
                         make_problem(gb, pb, srcb, src2b, wqb, biasb, actgradb, addb, outb), stream);

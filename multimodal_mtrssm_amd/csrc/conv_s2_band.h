@@ -415,52 +415,60 @@ __global__ __launch_bounds__(256, 2) void convt4s2_band_kernel(const ConvtBandPr
 // split kernel re-stages weights and patch per 16-channel step (two barriers a step) and ran it at 3.4 TB/s; here the frame is
 // staged once exactly as in convt4s2_band_kernel ([piece][channel half][haloed position] 16-byte rows, zero border written once),
 // a tap is a k-block (16 taps x 3 products per 32 output pixels, all 32 accumulator rows live), the weights are A operands in
-// registers for the whole launch.  512 threads, one workgroup per CU: wave w stages channels 4 (w & 3) .. + 3 of half the
-// positions and multiplies ONE of the frame's eight 32-pixel units; the next frame's requests fly under the products and the
-// epilogue (act' operand + stores).
+// registers for the whole launch.  One workgroup per CU: every thread stages two (4 positions x 4 channels) items, a wave
+// multiplies ONE (32-pixel unit, 32-channel tile) job of the frame; the next frame's requests fly under the products and the
+// epilogue (act' operand + stores).  Second instance: 32 -> 64 channels on 256-position frames (the FIRST ConvTranspose layer's
+// backward-data): four waves = 2 units x 2 channel tiles, 32 k-blocks, 256 weight registers per lane.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 1) void conv4s2_band_kernel(const GatherProblem pa, const GatherProblem pb) {
+template <int CIN, int COUT, int PLANE>   // <16, 32, 1024>: eight waves, one 32-pixel unit each; <32, 64, 256>: four waves = 2 units x 2 channel tiles
+__global__ __launch_bounds__(64 * (PLANE / 128) * (COUT / 32), 1) void conv4s2_band_kernel(const GatherProblem pa, const GatherProblem pb) {
+  constexpr int OPX = PLANE / 4, UNITS = OPX / 32, CTS = COUT / 32, NW = UNITS * CTS, NT = 64 * NW;
+  constexpr int OCT = CIN / 8, GPT = CIN / 16, KB = 16 * GPT;     // 8-channel octets per position; 16-channel groups per tap; k-blocks
+  constexpr int NITEM = (PLANE / 4) * (CIN / 4) / NT;             // (4 positions x 4 channels) items per thread
+  static_assert(NITEM * NT == (PLANE / 4) * (CIN / 4) && NITEM >= 1, "whole items");
   const bool second = blockIdx.x >= (unsigned)pa.nx;  // workgroup-uniform
   const GatherProblem& P = second ? pb : pa;
   const MtrssmConvGeom g = P.g;
   const int wg = second ? (int)blockIdx.x - pa.nx : (int)blockIdx.x, nwg = P.nx;
-  constexpr int C = 16, PLANE = 1024, CO = 32, OPX = 256;
-  const int Ws = g.Ws, Hs = g.Hs, Wq = g.Wq;                // host: Hs * Ws == 1024, Ws in {16, 32}, Wq = Ws / 2, Hq = Hs / 2
+  const int Ws = g.Ws, Hs = g.Hs, Wq = g.Wq;                // host: Hs * Ws == PLANE, Ws a power of two, Wq = Ws / 2, Hq = Hs / 2
   const int wsh = 31 - __builtin_clz(Ws), qsh = wsh - 1;
   const int ntiles = g.N;
   const int PW = Ws + 2;
   const int NPOS = (Hs + 2) * PW + 1;
-  const int HALF = NPOS * 16, IMG = 2 * HALF;
+  const int OSZ = NPOS * 16, IMG = OCT * OSZ;               // one octet plane / one piece
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, il = lane & 31, kl = lane >> 5;
   if (wg >= ntiles) return;
-  extern __shared__ __attribute__((aligned(16))) unsigned char band_lds[];  // [2 pieces][2 channel halves][NPOS] x 16 B
+  extern __shared__ __attribute__((aligned(16))) unsigned char band_lds[];  // [2 pieces][OCT][NPOS] x 16 B
+  const int unit = wave % UNITS, ct = wave / UNITS;
 
-  // A operands: row il = output channel, k-block t = tap (ky, kx) = (t >> 2, t & 3), this lane's 8 k-values = input channels 8 kl .. + 7
-  bf16x8 a[16][2];
+  // A operands: row il = output channel 32 ct + il, k-block kb = (tap kb / GPT, channel group kb % GPT), this lane's 8 k-values =
+  // input channels 16 (kb % GPT) + 8 kl .. + 7
+  bf16x8 a[KB][2];
   {
-    const size_t piece = (size_t)g.CoutPad * 16 * g.Cpad;  // host: CoutPad == 32, Cpad == 16
+    const size_t piece = (size_t)g.CoutPad * 16 * g.Cpad;  // host: CoutPad == COUT, Cpad == CIN
 #pragma unroll
-    for (int t = 0; t < 16; ++t)
+    for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
       for (int s = 0; s < 2; ++s)
-        a[t][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(P.wq + s * piece + ((size_t)il * 16 + t) * g.Cpad + 8 * kl));
+        a[kb][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(P.wq + s * piece + ((size_t)(32 * ct + il) * 16 + kb / GPT) * CIN +
+                                                                                    16 * (kb % GPT) + 8 * kl));
   }
-  for (int o = tid * 16; o < 2 * IMG; o += 512 * 16) *reinterpret_cast<u32x4*>(band_lds + o) = u32x4{0u, 0u, 0u, 0u};
+  for (int o = tid * 16; o < 2 * IMG; o += NT * 16) *reinterpret_cast<u32x4*>(band_lds + o) = u32x4{0u, 0u, 0u, 0u};
 
-  const int cq = wave & 3, ph = wave >> 2;   // channels 4 cq .. + 3, position groups 128 ph + lane + 64 k
-  band_f4 pv[2][4];
+  band_f4 pv[NITEM][4];
   auto request = [&](int tile) {
     const __amdgpu_buffer_rsrc_t rsf =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.src + ((size_t)tile * C + 4 * cq) * PLANE), 0, 0x7fffffff, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.src + (size_t)tile * CIN * PLANE), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < NITEM; ++k) {
+      const int it = tid + NT * k, pg = it % (PLANE / 4), cq = it / (PLANE / 4);
 #pragma unroll
       for (int c = 0; c < 4; ++c)
-        pv[k][c] = __builtin_bit_cast(band_f4, __builtin_amdgcn_raw_buffer_load_b128(rsf, (128 * ph + lane + 64 * k) * 16, c * PLANE * 4, 0));
+        pv[k][c] = __builtin_bit_cast(band_f4, __builtin_amdgcn_raw_buffer_load_b128(rsf, ((4 * cq + c) * PLANE + 4 * pg) * 4, 0, 0));
+    }
   };
   const int act = g.act;
   const int mode = g.pre_act == 0 ? 0 : (act == MTRSSM_ACT_ELU ? 1 : 2);
-  const int hf = cq >> 1, cofs = (cq & 1) * 8;
   auto stage_as = [&](auto mode_tag) {
     constexpr int MODE = decltype(mode_tag)::value;
     auto activate = [&](float v) {
@@ -469,14 +477,15 @@ __global__ __launch_bounds__(512, 1) void conv4s2_band_kernel(const GatherProble
       return v;
     };
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int p = (128 * ph + lane + 64 * k) * 4, r = p >> wsh, x = p & (Ws - 1);
+    for (int k = 0; k < NITEM; ++k) {
+      const int it = tid + NT * k, pg = it % (PLANE / 4), cq = it / (PLANE / 4);
+      const int p = pg * 4, r = p >> wsh, x = p & (Ws - 1);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         unsigned short h[4][2];
 #pragma unroll
         for (int c = 0; c < 4; ++c) split_bf16<2>(activate(pv[k][c][e]), h[c]);
-        unsigned char* d = band_lds + hf * HALF + ((r + 1) * PW + x + e + 1) * 16 + cofs;
+        unsigned char* d = band_lds + (cq >> 1) * OSZ + ((r + 1) * PW + x + e + 1) * 16 + (cq & 1) * 8;
         *reinterpret_cast<uint2*>(d) = make_uint2((unsigned)h[0][0] | ((unsigned)h[1][0] << 16), (unsigned)h[2][0] | ((unsigned)h[3][0] << 16));
         *reinterpret_cast<uint2*>(d + IMG) = make_uint2((unsigned)h[0][1] | ((unsigned)h[1][1] << 16), (unsigned)h[2][1] | ((unsigned)h[3][1] << 16));
       }
@@ -488,17 +497,18 @@ __global__ __launch_bounds__(512, 1) void conv4s2_band_kernel(const GatherProble
     else stage_as(std::integral_constant<int, 2>{});
   };
 
-  // this wave's unit: output pixel j = 32 wave + il -> (oy, ox); tap (ky, kx) reads source (2 oy - 1 + ky, 2 ox - 1 + kx) = image (2 oy + ky, 2 ox + kx)
-  const int j = 32 * wave + il, oy = j >> qsh, ox = j & (Wq - 1);
-  const unsigned bb = (unsigned)(kl * HALF + ((2 * oy) * PW + 2 * ox) * 16);
+  // this wave's unit: output pixel j = 32 unit + il -> (oy, ox); tap (ky, kx) reads source (2 oy - 1 + ky, 2 ox - 1 + kx) = image (2 oy + ky, 2 ox + kx)
+  const int j = 32 * unit + il, oy = j >> qsh, ox = j & (Wq - 1);
+  const unsigned bb = (unsigned)(kl * OSZ + ((2 * oy) * PW + 2 * ox) * 16);
   const float* __restrict__ actgrad = P.actgrad_in;
   const float* __restrict__ bias = P.bias;
   const bool act_elu = act == MTRSSM_ACT_ELU, act_relu = act == MTRSSM_ACT_RELU;
   float bv[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) bv[r] = bias ? bias[4 * kl + (r & 3) + 8 * (r >> 2)] : 0.f;
+  for (int r = 0; r < 16; ++r) bv[r] = bias ? bias[32 * ct + 4 * kl + (r & 3) + 8 * (r >> 2)] : 0.f;
+  auto frag_off = [&](int kb) { return (unsigned)(((kb / GPT) >> 2) * PW + ((kb / GPT) & 3)) * 16u + (unsigned)(2 * (kb % GPT)) * (unsigned)OSZ; };
   auto compute = [&](int tile) {
-    const size_t obase = (size_t)tile * CO * OPX + (size_t)(4 * kl) * OPX + j;
+    const size_t obase = (size_t)tile * COUT * OPX + (size_t)(32 * ct + 4 * kl) * OPX + j;
     float gv[16];
     if (actgrad) {
 #pragma unroll
@@ -508,19 +518,18 @@ __global__ __launch_bounds__(512, 1) void conv4s2_band_kernel(const GatherProble
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = bv[r];
     bf16x8 q0[2], q1[2];
-    q0[0] = *reinterpret_cast<const bf16x8*>(band_lds + bb);
-    q1[0] = *reinterpret_cast<const bf16x8*>(band_lds + bb + IMG);
+    q0[0] = *reinterpret_cast<const bf16x8*>(band_lds + bb + frag_off(0));
+    q1[0] = *reinterpret_cast<const bf16x8*>(band_lds + bb + frag_off(0) + IMG);
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const int st = t & 1;
-      if (t + 1 < 16) {
-        const int toff = (((t + 1) >> 2) * PW + ((t + 1) & 3)) * 16;
-        q0[st ^ 1] = *reinterpret_cast<const bf16x8*>(band_lds + bb + toff);
-        q1[st ^ 1] = *reinterpret_cast<const bf16x8*>(band_lds + bb + toff + IMG);
+    for (int kb = 0; kb < KB; ++kb) {
+      const int st = kb & 1;
+      if (kb + 1 < KB) {
+        q0[st ^ 1] = *reinterpret_cast<const bf16x8*>(band_lds + bb + frag_off(kb + 1));
+        q1[st ^ 1] = *reinterpret_cast<const bf16x8*>(band_lds + bb + frag_off(kb + 1) + IMG);
       }
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][0], q1[st], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][1], q0[st], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][0], q0[st], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kb][0], q1[st], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kb][1], q0[st], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kb][0], q0[st], acc, 0, 0, 0);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
