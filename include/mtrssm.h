@@ -461,6 +461,20 @@ int mtrssm_conv_gather_gemm_pair(const MtrssmConvGeom* ga, const float* srca, co
 /* 1 if mtrssm_conv_gather_gemm_pair would run the two problems as one grid (same split-bf16 kernel for both; has_wq: both
  * have bf16 pieces), 0 if it would fall back to two launches -- a host-side query, nothing is launched. */
 int mtrssm_conv_gather_pair_merges(const MtrssmConvGeom* ga, const MtrssmConvGeom* gb, int32_t has_wq);
+/* Forward of a whole residual block of the encoders' / decoders' stacks (the builder's `cnn` stand-in, oracle/ref_cnn.py:57-58:
+ * `x + conv1(act(conv3(act(x))))`; called through cnn.Encoder / cnn.Decoder at mrssm core.py:179-180,215-216) in ONE launch:
+ *   h[n, m, p] = b3[m] + sum_{tap, c} wq3[m][tap][c] * act(x)[n, c, p + tap]          (stored: the backward pass reads it)
+ *   y[n, c, p] = x[n, c, p] + b1[c] + sum_m w1[c][m] * act(h[n, m, p])
+ * g3 is the 3x3's geometry exactly as mtrssm_conv_gather_gemm takes it (pre_act = 1, mfma_split = 2), wq3 its packed bf16 pieces
+ * (mtrssm_pack_conv_weight(s)), w1 [C][Cout] and b1 [C] the 1x1 module's own fp32 parameters (contiguous); two bf16 pieces per
+ * operand and fp32 accumulation in both products, as the two separate launches compute.  A second block on another tensor
+ * (gb != NULL: the other modality) rides in the same grid.  _supported: 1 when the shape has a fused instance (64 channels,
+ * 128 intermediate channels, 64-pixel planes), else 0 -- a host-side query; mtrssm_residual_block_fwd on an unsupported shape
+ * returns MTRSSM_EINVAL. */
+int mtrssm_residual_block_fwd_supported(const MtrssmConvGeom* g3);
+int mtrssm_residual_block_fwd(const MtrssmConvGeom* ga, const float* xa, const uint16_t* wq3a, const float* b3a, const float* w1a,
+                              const float* b1a, float* ha, float* ya, const MtrssmConvGeom* gb, const float* xb, const uint16_t* wq3b,
+                              const float* b3b, const float* w1b, const float* b1b, float* hb, float* yb, void* stream);
 /* Packs a conv weight view w[O][I][KH][KW] (element strides so, si, sh, sw: any permuted / strided view of the module's
  * parameter, e.g. the per-parity-class tap subset of a ConvTranspose2d weight) into the kernels' layout:
  *   wp fp32 [OPad][KH*KW][IPad], zero padded;

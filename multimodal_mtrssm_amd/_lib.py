@@ -110,6 +110,8 @@ SYMBOLS: dict[str, tuple[type | None, list[type]]] = {
     "mtrssm_conv_gather_gemm_pair": (C.c_int, [C.POINTER(ConvGeom), _p, _p, _p, _p, _p, _p, _p, _p,
                                                C.POINTER(ConvGeom), _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "mtrssm_conv_gather_pair_merges": (C.c_int, [C.POINTER(ConvGeom), C.POINTER(ConvGeom), _i]),
+    "mtrssm_residual_block_fwd_supported": (C.c_int, [C.POINTER(ConvGeom)]),
+    "mtrssm_residual_block_fwd": (C.c_int, [C.POINTER(ConvGeom), _p, _p, _p, _p, _p, _p, _p, C.POINTER(ConvGeom), _p, _p, _p, _p, _p, _p, _p, _p]),
     "mtrssm_pack_conv_weight": (C.c_int, [_p, _i, _i, _i, _i, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _i, _i, _i, _p, _p, _p]),
     "mtrssm_pack_conv_weights": (C.c_int, [_p, _i, _i, _p]),
     "mtrssm_unpack_conv_grads": (C.c_int, [_p, _i, _i, _p]),

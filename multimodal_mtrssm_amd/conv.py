@@ -693,6 +693,46 @@ class _ConvTranspose2d(torch.autograd.Function):
         return g_x, g_w, g_b, None, None, None, None, None
 
 
+RESBLOCK_FUSE = True  # the blocks' forward as ONE launch where the library has a fused kernel (mtrssm_residual_block_fwd)
+
+
+def _residual_job(x: Tensor, w3: Tensor, b3: Tensor, w1: Tensor, b1: Tensor, act: int, sub: int = 0) -> tuple | None:  # noqa: PLR0913
+    """Arguments of ``mtrssm_residual_block_fwd`` for one block (with fresh ``h`` and ``y``), or None when it has no fused kernel.
+    ``sub``: the pack-buffer slot (``pack_weight``) -- the second block of a paired launch must not re-use the first's."""
+    if not RESBLOCK_FUSE or w3.shape[2:] != (3, 3) or w1.shape[2:] != (1, 1) or w1.shape[:2] != (x.shape[1], w3.shape[0]):
+        return None
+    n, c, hs, ws = x.shape
+    o = w3.shape[0]
+    wp, wq = pack_weight(w3, sub)
+    if wq is None:
+        return None
+    geom = _geom(N=n, C=c, Hs=hs, Ws=ws, C2=0, Cpad=wp.shape[2], KH=3, KW=3, SS=1, TS=1, OFFY=-1, OFFX=-1, Hq=hs, Wq=ws, OS=1, QY=0,
+                 QX=0, Ho=hs, Wo=ws, Cout=o, CoutPad=wp.shape[0], pre_act=1, act=act)
+    if not _lib.load().mtrssm_residual_block_fwd_supported(C.byref(geom)):
+        return None
+    h = torch.empty(n, o, hs, ws, device=x.device, dtype=torch.float32)
+    return (geom, x, wq, b3, w1, b1, h, torch.empty_like(x))
+
+
+def _residual_launch(ja: tuple, jb: tuple | None) -> None:
+    def work(job: tuple) -> tuple[float, float]:
+        g = job[0]
+        pixels = g.N * g.Hq * g.Wq
+        return 2.0 * pixels * g.Cout * (9 * g.C + g.C), 4.0 * pixels * (2 * g.C + g.Cout)
+
+    def args(job: tuple | None) -> tuple:
+        if job is None:
+            return (None,) * 8
+        geom, x, wq, b3, w1, b1, h, y = job
+        return (C.byref(geom), _lib.ptr(x), _lib.raw_ptr(wq), _lib.ptr(b3), _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(h), _lib.ptr(y))
+
+    fa, ba = work(ja)
+    fb, bb = work(jb) if jb is not None else (0.0, 0.0)
+    lib = _lib.load()
+    _lib.check(_lib.TIMERS.call("mtrssm_residual_block_fwd", lib.mtrssm_residual_block_fwd, *args(ja), *args(jb),
+                                _lib.stream_ptr(ja[1].device), flops=fa + fb, nbytes=ba + bb), "mtrssm_residual_block_fwd")
+
+
 class _ResidualBlock(torch.autograd.Function):
     """``y = x + Conv1x1(act(Conv3x3(act(x))))`` as ONE node: the skip add rides in the second conv's epilogue and the
     skip's gradient in the epilogue of the first conv's backward-data (``oracle/ref_cnn.py:ResidualBlock``)."""
@@ -701,8 +741,13 @@ class _ResidualBlock(torch.autograd.Function):
     def forward(ctx, x, w3, b3, w1, b1, act):  # noqa: ANN001, PLR0913
         x, w3, b3, w1, b1 = (t.contiguous() for t in (x, w3, b3, w1, b1))
         p3, p1 = w3.shape[2] // 2, w1.shape[2] // 2
-        h = _conv_forward_gather(x, None, w3, b3, 1, p3, True, act)
-        y = _conv_forward_gather(h, None, w1, b1, 1, p1, True, act, add_in=x)
+        job = _residual_job(x, w3, b3, w1, b1, act)
+        if job is not None:
+            _residual_launch(job, None)
+            h, y = job[6], job[7]
+        else:
+            h = _conv_forward_gather(x, None, w3, b3, 1, p3, True, act)
+            y = _conv_forward_gather(h, None, w1, b1, 1, p1, True, act, add_in=x)
         ctx.save_for_backward(x, h, w3, w1)
         ctx.act, ctx.biases = act, (b3, b1)
         return y
@@ -731,10 +776,16 @@ class _PairResidualBlock(torch.autograd.Function):
     def forward(ctx, xa, w3a, b3a, w1a, b1a, xv, w3v, b3v, w1v, b1v, act):  # noqa: ANN001, PLR0913
         xa, w3a, b3a, w1a, b1a, xv, w3v, b3v, w1v, b1v = (t.contiguous() for t in (xa, w3a, b3a, w1a, b1a, xv, w3v, b3v, w1v, b1v))
         p3, p1 = w3a.shape[2] // 2, w1a.shape[2] // 2
-        ha, hv = paired(lambda: _conv_forward_gather(xa, None, w3a, b3a, 1, p3, True, act),
-                        lambda: _conv_forward_gather(xv, None, w3v, b3v, 1, p3, True, act))
-        ya, yv = paired(lambda: _conv_forward_gather(ha, None, w1a, b1a, 1, p1, True, act, add_in=xa),
-                        lambda: _conv_forward_gather(hv, None, w1v, b1v, 1, p1, True, act, add_in=xv))
+        ja = _residual_job(xa, w3a, b3a, w1a, b1a, act)
+        jv = _residual_job(xv, w3v, b3v, w1v, b1v, act, sub=1) if ja is not None else None
+        if ja is not None and jv is not None:
+            _residual_launch(ja, jv)
+            ha, ya, hv, yv = ja[6], ja[7], jv[6], jv[7]
+        else:
+            ha, hv = paired(lambda: _conv_forward_gather(xa, None, w3a, b3a, 1, p3, True, act),
+                            lambda: _conv_forward_gather(xv, None, w3v, b3v, 1, p3, True, act))
+            ya, yv = paired(lambda: _conv_forward_gather(ha, None, w1a, b1a, 1, p1, True, act, add_in=xa),
+                            lambda: _conv_forward_gather(hv, None, w1v, b1v, 1, p1, True, act, add_in=xv))
         ctx.save_for_backward(xa, ha, w3a, w1a, xv, hv, w3v, w1v)
         ctx.act, ctx.biases = act, (b3a, b1a, b3v, b1v)
         return ya, yv

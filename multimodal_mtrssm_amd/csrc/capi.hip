@@ -26,6 +26,9 @@ int conv_gather_gemm_launch(const MtrssmConvGeom*, const float*, const float*, c
 int episode_gather_launch(const float*, const int64_t*, const float*, int64_t, int64_t, int64_t, int64_t, int64_t, float, float*, float*, hipStream_t);
 int conv_gather_gemm_pair_launch(const MtrssmConvGeom*, const float*, const float*, const float*, const unsigned short*, const float*, const float*, const float*, float*,
                                  const MtrssmConvGeom*, const float*, const float*, const float*, const unsigned short*, const float*, const float*, const float*, float*, hipStream_t);
+int conv_residual_fwd_supported(const MtrssmConvGeom*);
+int conv_residual_fwd_launch(const MtrssmConvGeom*, const float*, const unsigned short*, const float*, const float*, const float*, float*, float*,
+                             const MtrssmConvGeom*, const float*, const unsigned short*, const float*, const float*, const float*, float*, float*, hipStream_t);
 int pack_conv_weight_launch(const float*, int, int, int, int, long, long, long, long, int, int, int, float*, unsigned short*, hipStream_t);
 int pack_conv_weights_launch(const int64_t*, int, int, hipStream_t);
 int conv_gather_pair_merges(const MtrssmConvGeom*, const MtrssmConvGeom*, bool);
@@ -219,6 +222,12 @@ MTRSSM_API int mtrssm_conv_gather_gemm_pair(const MtrssmConvGeom* ga, const floa
                                             const float* biasb, const float* actgradb, const float* addb, float* outb, void* stream) {
   return conv_gather_gemm_pair_launch(ga, srca, src2a, wpa, wqa, biasa, actgrada, adda, outa, gb, srcb, src2b, wpb, wqb, biasb, actgradb, addb,
                                       outb, static_cast<hipStream_t>(stream));
+}
+MTRSSM_API int mtrssm_residual_block_fwd_supported(const MtrssmConvGeom* g3) { return conv_residual_fwd_supported(g3) != 0; }
+MTRSSM_API int mtrssm_residual_block_fwd(const MtrssmConvGeom* ga, const float* xa, const uint16_t* wq3a, const float* b3a, const float* w1a,
+                                         const float* b1a, float* ha, float* ya, const MtrssmConvGeom* gb, const float* xb, const uint16_t* wq3b,
+                                         const float* b3b, const float* w1b, const float* b1b, float* hb, float* yb, void* stream) {
+  return conv_residual_fwd_launch(ga, xa, wq3a, b3a, w1a, b1a, ha, ya, gb, xb, wq3b, b3b, w1b, b1b, hb, yb, static_cast<hipStream_t>(stream));
 }
 MTRSSM_API int mtrssm_pack_conv_weight(const float* w, int32_t O, int32_t I, int32_t KH, int32_t KW, int64_t so, int64_t si, int64_t sh,
                                        int64_t sw, int32_t OPad, int32_t IPad, int32_t pieces, float* wp, uint16_t* wq, void* stream) {

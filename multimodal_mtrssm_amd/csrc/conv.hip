@@ -1710,6 +1710,88 @@ int conv_gather_gemm_pair_launch(const MtrssmConvGeom* ga, const float* srca, co
   return conv_gather_gemm_launch(gb, srcb, src2b, wpb, wqb, biasb, actgradb, addb, outb, stream);
 }
 
+// MTRSSM_RESBLOCK_FUSE=0: the residual blocks' forward as two launches (3x3, then 1x1 + skip) instead of the fused kernel
+static bool resblock_fuse_enabled() {
+  static const bool on = [] { const char* e = getenv("MTRSSM_RESBLOCK_FUSE"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
+// Forward of a whole residual block  y = x + Conv1x1(act(h)),  h = b3 + Conv3x3(act(x))  in one launch
+// (conv3x3_resident_kernel<..., FUSE>): g is the 3x3's geometry exactly as for conv_gather_gemm (pre_act = 1), w1 [C][Cout] and
+// b1 [C] the 1x1 module's own fp32 parameters.  Returns the kernel key (> 0) when the shape has a fused instance.
+int conv_residual_fwd_supported(const MtrssmConvGeom* g) {
+  if (!g || !resblock_fuse_enabled() || g->pre_act == 0 || g->mfma_split != 2 || g->C2 != 0) return 0;
+  const SplitPlan pl = plan_split(g, true);
+  return pl.kind == 3 && pl.res == 64128 ? pl.res : 0;
+}
+
+static int residual_fwd_one_grid(const GatherProblem& pa, const GatherProblem& pb, int key, hipStream_t stream) {
+  const long ta = pa.nx, tb = pb.nx;  // one frame per tile
+  const int ncu = cu_count();
+  GatherProblem qa = pa, qb = pb;
+  if (tb == 0) {
+    qa.nx = (int)(ta < ncu ? ta : ncu);
+    qb.nx = 0;
+  } else {
+    long na = (ncu * ta + (ta + tb) / 2) / (ta + tb);
+    na = na < 1 ? 1 : (na > ncu - 1 ? ncu - 1 : na);
+    qa.nx = (int)(na < ta ? na : ta);
+    qb.nx = (int)(ncu - na < tb ? ncu - na : tb);
+  }
+  const dim3 rgrid((unsigned)(qa.nx + qb.nx));
+  if (key == 64128) {
+    static bool attr_done_dev[64] = {};
+    bool& attr_done = attr_done_dev[device_slot()];
+    const size_t rl = res_lds_bytes<64, 4, 1>() + res_fuse_bytes<64, 4>();
+    if (!attr_done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_resident_kernel<64, 4, 1, false, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl);
+      attr_done = true;
+    }
+    set_last_kernel("mtrssm::conv3x3_resident_kernel<64, 4, 1, false, true>");
+    hipLaunchKernelGGL((conv3x3_resident_kernel<64, 4, 1, false, true>), rgrid, dim3(kResThreads), rl, stream, qa, qb);
+    return launched("residual_block_fwd");
+  }
+  set_error("residual_block_fwd: no fused kernel for this shape");
+  return MTRSSM_EINVAL;
+}
+
+int conv_residual_fwd_launch(const MtrssmConvGeom* ga, const float* xa, const unsigned short* wq3a, const float* b3a, const float* w1a,
+                             const float* b1a, float* ha, float* ya, const MtrssmConvGeom* gb, const float* xb, const unsigned short* wq3b,
+                             const float* b3b, const float* w1b, const float* b1b, float* hb, float* yb, hipStream_t stream) {
+  if (!ga || !xa || !wq3a || !b3a || !w1a || !b1a || !ha || !ya) {
+    set_error("residual_block_fwd: null argument");
+    return MTRSSM_EINVAL;
+  }
+  if (gb && (!xb || !wq3b || !b3b || !w1b || !b1b || !hb || !yb)) {
+    set_error("residual_block_fwd: null argument in the second problem");
+    return MTRSSM_EINVAL;
+  }
+  if (int rc = check_geom(ga, "residual_block_fwd")) return rc;
+  if (gb)
+    if (int rc = check_geom(gb, "residual_block_fwd")) return rc;
+  const int ka = conv_residual_fwd_supported(ga), kb = gb ? conv_residual_fwd_supported(gb) : ka;
+  if (ka == 0 || kb == 0) {
+    set_error("residual_block_fwd: shape without a fused kernel (query mtrssm_residual_block_fwd_supported first)");
+    return MTRSSM_EINVAL;
+  }
+  auto problem = [](const MtrssmConvGeom* g, const float* x, const unsigned short* wq, const float* b3, const float* w1, const float* b1,
+                    float* h, float* y) {
+    GatherProblem p{};
+    p.g = *g; p.src = x; p.wq = wq; p.bias = b3; p.out = h; p.w1 = w1; p.b1 = b1; p.out2 = y;
+    p.nx = g->N;
+    return p;
+  };
+  const GatherProblem pa = problem(ga, xa, wq3a, b3a, w1a, b1a, ha, ya);
+  GatherProblem none{};
+  none.nx = 0;
+  if (!gb) return residual_fwd_one_grid(pa, none, ka, stream);
+  const GatherProblem pb = problem(gb, xb, wq3b, b3b, w1b, b1b, hb, yb);
+  if (ka == kb) return residual_fwd_one_grid(pa, pb, ka, stream);
+  if (int rc = residual_fwd_one_grid(pa, none, ka, stream)) return rc;
+  return residual_fwd_one_grid(pb, none, kb, stream);
+}
+
 int channel_sum_launch(const float* x, int N, int C, int HW, float* out, hipStream_t stream);
 
 // MTRSSM_NO_DIRECT_WGRAD=1: the patch-staged kernels for every layer (A/B runs of the register-direct 3x3 kernel)

@@ -72,9 +72,23 @@ __host__ __device__ constexpr size_t res_lds_bytes() {
   return run > stage ? run : stage;
 }
 
-template <int CIN, int NCT, int KS, bool EPI>  // EPI: the epilogue has operands (act'(x) input and / or skip gradient)
+// FUSE: the whole residual block  y = x + W1 * act(b3 + W3 (*) act(x)) + b1  in this launch (task 3).  A unit's
+// 32 x 32 accumulator (rows = 32 of the block's intermediate channels, columns = 32 pixels) IS the B operand of the 1x1's MFMAs
+// once activated and split into pieces: a lane's 16 rows are 2 k-blocks of 8 values when the 1x1's K axis is taken in the
+// order (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) -- the A operands (rows of W1, prepared once per workgroup in LDS) are simply
+// gathered in that order.  Every wave multiplies ITS 32 intermediate channels into all CIN output channels (12 more MFMAs on
+// top of the unit's 108), the NCT partial sums meet through LDS, each wave finishes CIN / NCT channels: + b1 + x, stored to
+// out2.  The intermediate is still stored to out (the backward pass reads it); it is no longer read back.
+template <int CIN, int NCT>
+__host__ __device__ constexpr size_t res_fuse_bytes() {
+  // W1 fragments [NCT][CIN / 32 tiles x 2 k-blocks][2 pieces][64 lanes] of 16 bytes + partial sums [4 waves][CIN / 2 rows][64 lanes]
+  return (size_t)NCT * (CIN / 32) * 2 * 2 * 64 * 16 + (size_t)4 * (CIN / 2) * 64 * sizeof(float);
+}
+
+template <int CIN, int NCT, int KS, bool EPI, bool FUSE = false>  // EPI: the epilogue has operands (act'(x) input and / or skip gradient)
 __global__ __launch_bounds__(kResThreads, 1) void conv3x3_resident_kernel(const GatherProblem pa, const GatherProblem pb) {
   static_assert(NCT * KS == 4 || NCT * KS == 2 || NCT * KS == 1, "4 waves");
+  static_assert(!FUSE || (KS == 1 && !EPI && CIN % 32 == 0), "fused block: whole K per wave, no epilogue operands");
   constexpr int NPG = 4 / (NCT * KS);  // frames per tile
   constexpr int CW = CIN / KS;         // input channels per wave
   constexpr int CB = CW / 16;          // 16-channel k-blocks per tap
@@ -160,6 +174,40 @@ __global__ __launch_bounds__(kResThreads, 1) void conv3x3_resident_kernel(const 
   if (prof) prof[56] = __builtin_readcyclecounter();
   // ---- zero both images once (the halo stays zero for the whole launch)
   for (int o = tid * 16; o < 4 * IMG; o += kResThreads * 16) *reinterpret_cast<u32x4*>(patch + o) = u32x4{0u, 0u, 0u, 0u};
+  // ---- FUSE: the 1x1's A operands, in the k order of the accumulator rows (see the kernel's header)
+  constexpr int NOT = CIN / 32;            // output-channel tiles of the 1x1 (its Cout == CIN: a residual block)
+  constexpr int NF = NOT * 2;              // A fragments per wave: (tile, k-block of 16 intermediate channels)
+  constexpr int RF = NOT * 16 / NCT;       // accumulator rows of the 1x1 this wave finishes per unit
+  unsigned char* w1l = lds_raw + res_lds_bytes<CIN, NCT, KS>();                       // behind everything the 3x3 uses
+  float* red2 = reinterpret_cast<float*>(w1l + (size_t)NCT * NF * 2 * 64 * 16);       // [wave][NOT * 16 rows][64 lanes]
+  float* __restrict__ out2 = P.out2;
+  const int co2 = (ct * RF / 16) * 32 + ((ct * RF) % 16 / 4) * 8 + 4 * kl;            // first of this lane's finished channels
+  float b1v[FUSE ? RF : 1];
+  if constexpr (FUSE) {
+    const float* __restrict__ w1 = P.w1;
+    const float* __restrict__ b1 = P.b1;
+    constexpr int CMID = NCT * 32;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const int ot = f / 2, kb2 = f % 2;
+      unsigned hi[4], lo[4];
+#pragma unroll
+      for (int e2 = 0; e2 < 4; ++e2) {
+        unsigned short p0[2], p1[2];
+        const int e = 2 * e2;
+        const int k0 = ct * 32 + 4 * kl + (e & 3) + 8 * (2 * kb2 + (e >> 2));
+        split_bf16<2>(w1[(size_t)(ot * 32 + il) * CMID + k0], p0);
+        split_bf16<2>(w1[(size_t)(ot * 32 + il) * CMID + k0 + 1], p1);
+        hi[e2] = (unsigned)p0[0] | ((unsigned)p1[0] << 16);
+        lo[e2] = (unsigned)p0[1] | ((unsigned)p1[1] << 16);
+      }
+      unsigned char* dst = w1l + ((size_t)((ct * NF + f) * 2) * 64 + lane) * 16;
+      *reinterpret_cast<u32x4*>(dst) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+      *reinterpret_cast<u32x4*>(dst + 64 * 16) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+    }
+#pragma unroll
+    for (int j = 0; j < RF; ++j) b1v[j] = b1[co2 + (j & 3) + 8 * (j >> 2)];
+  }
   // this lane's 16 accumulator rows are output channels cbase + (r & 3) + 8 * (r >> 2) (host: Cout == 32 * NCT, no ragged
   // channel tile); the bias is the accumulators' start value (KS == 2: in the first half of K only)
   const int cbase = ct * 32 + 4 * kl;
@@ -196,6 +244,11 @@ __global__ __launch_bounds__(kResThreads, 1) void conv3x3_resident_kernel(const 
     asm volatile("" : "+v"(e));
     const float neg = act_elu ? e : (act_relu ? 0.f : 1.f);
     return x > 0.f ? 1.f : neg;
+  };
+  auto act_mid_sel = [&](float x) {  // FUSE: the block's activation on the intermediate
+    const float e = __expf(x) - 1.f;
+    const float neg = act_elu ? e : (act_relu ? 0.f : x);
+    return x > 0.f ? x : neg;
   };
 
   // ---- staging of a tile's frames: (frame, 8-channel octet) items per wave, lane = pixel
@@ -305,6 +358,13 @@ __global__ __launch_bounds__(kResThreads, 1) void conv3x3_resident_kernel(const 
       read_frag(fr[1], 1);
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = bv[r];
+      // FUSE: the skip values of the rows this wave finishes, requested a whole unit before their use
+      const unsigned o2base = (unsigned)(tile * NPG + pgi) * (unsigned)(CIN * 64) + (unsigned)(co2 * 64 + il + h * 32);
+      float xs[FUSE ? RF : 1];
+      if constexpr (FUSE) {
+#pragma unroll
+        for (int j = 0; j < RF; ++j) xs[j] = src[o2base + row_off(j)];
+      }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) {
@@ -380,6 +440,54 @@ __global__ __launch_bounds__(kResThreads, 1) void conv3x3_resident_kernel(const 
         for (int j = 0; j < 16; ++j) {
           fin[j] = acc[j];
           asm volatile("" : "+v"(fin[j]));  // architectural VGPRs: a store sourcing an AGPR stalls like the read does
+        }
+      }
+      if constexpr (FUSE) {
+        // ---- the block's 1x1 on this unit: B = pieces of act(intermediate), straight from the accumulator copy
+        bf16x8 mb[2][2];
+#pragma unroll
+        for (int kb2 = 0; kb2 < 2; ++kb2) {
+          unsigned hi[4], lo[4];
+#pragma unroll
+          for (int e2 = 0; e2 < 4; ++e2) {
+            unsigned short p0[2], p1[2];
+            split_bf16<2>(act_mid_sel(fin[8 * kb2 + 2 * e2]), p0);
+            split_bf16<2>(act_mid_sel(fin[8 * kb2 + 2 * e2 + 1]), p1);
+            hi[e2] = (unsigned)p0[0] | ((unsigned)p1[0] << 16);
+            lo[e2] = (unsigned)p0[1] | ((unsigned)p1[1] << 16);
+          }
+          mb[kb2][0] = __builtin_bit_cast(bf16x8, u32x4{hi[0], hi[1], hi[2], hi[3]});
+          mb[kb2][1] = __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], lo[2], lo[3]});
+        }
+        f32x16 acc2[NOT];
+#pragma unroll
+        for (int ot = 0; ot < NOT; ++ot) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc2[ot][r] = 0.f;
+#pragma unroll
+          for (int kb2 = 0; kb2 < 2; ++kb2) {
+            const unsigned char* wf = w1l + ((size_t)((ct * NF + ot * 2 + kb2) * 2) * 64 + lane) * 16;
+            const bf16x8 a_hi = *reinterpret_cast<const bf16x8*>(wf);
+            const bf16x8 a_lo = *reinterpret_cast<const bf16x8*>(wf + 64 * 16);
+            acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, mb[kb2][1], acc2[ot], 0, 0, 0);
+            acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, mb[kb2][0], acc2[ot], 0, 0, 0);
+            acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, mb[kb2][0], acc2[ot], 0, 0, 0);
+          }
+        }
+        lds_barrier();  // the previous unit's partial sums have been read by everyone
+        float* mine = red2 + (size_t)wave * (NOT * 16) * 64 + lane;
+#pragma unroll
+        for (int ot = 0; ot < NOT; ++ot)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mine[(ot * 16 + r) * 64] = acc2[ot][r];
+        lds_barrier();
+        const float* theirs = red2 + ((size_t)(pgi * NCT) * (NOT * 16) + ct * RF) * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < RF; ++j) {
+          float v = b1v[j] + xs[j];
+#pragma unroll
+          for (int w = 0; w < NCT; ++w) v += theirs[((size_t)w * (NOT * 16) + j) * 64];
+          out2[o2base + row_off(j)] = v;
         }
       }
       __builtin_amdgcn_sched_barrier(0);

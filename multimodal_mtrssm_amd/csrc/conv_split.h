@@ -110,6 +110,11 @@ struct GatherProblem {
   const float* add_in;
   float* out;
   int tg, ngroups, nx;
+  // fused residual block (conv3x3_resident_kernel<..., FUSE>): the block's 1x1 weight [C][Cout] and bias (fp32, as the module
+  // holds them) and the block's output; NULL elsewhere
+  const float* w1;
+  const float* b1;
+  float* out2;
 };
 
 // Epilogue of the gather kernels: out = (acc + bias) * act'(actgrad_in) + add_in for one lane's pixel x 32*NT channels,

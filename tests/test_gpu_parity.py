@@ -837,6 +837,73 @@ def test_one_pass_parity_class_kernels_match_the_per_class_launches(lib_loaded: 
         np.testing.assert_allclose(_np(a), _np(b), rtol=2e-5, atol=(5e-6 if i == 7 else 2e-6) * float(b.abs().max()), err_msg=str(i))
 
 
+@pytest.mark.parametrize(("na", "nv", "plane_a", "plane_v", "act"),
+                         [(1, 0, (8, 8), None, 2), (37, 50, (8, 8), (16, 4), 2), (300, 700, (4, 16), (8, 8), 2), (260, 0, (8, 8), None, 1)])
+def test_fused_residual_block_matches_two_launches_and_float64(lib_loaded: None, na: int, nv: int, plane_a: tuple, plane_v: tuple | None,  # noqa: PLR0913
+                                                               act: int) -> None:
+    """mtrssm_residual_block_fwd (3x3 -> act -> 1x1 + skip in one launch, 64 channels / 128 intermediate channels on 64-pixel
+    planes) against the two-launch path (same two-piece products, another summation order in the 1x1) and against float64 on
+    the CPU (`oracle/ref_cnn.py:ResidualBlock` arithmetic), values and every gradient; fewer frames than CUs, uneven pairs
+    and several tiles per workgroup."""
+    import torch.nn.functional as F  # noqa: N812
+
+    from multimodal_mtrssm_amd import _lib, conv
+
+    gen = torch.Generator(device="cpu").manual_seed(5 + na)
+    def rnd(*shape: int, scale: float = 1.0) -> torch.Tensor:
+        return (torch.randn(*shape, generator=gen) * scale).to(DEV).requires_grad_(True)
+    def params() -> tuple:
+        return (rnd(128, 64, 3, 3, scale=0.05), rnd(128, scale=0.1), rnd(64, 128, 1, 1, scale=0.1), rnd(64, scale=0.1))
+    xa, pa = rnd(na, 64, *plane_a), params()
+    xv, pv = (rnd(nv, 64, *plane_v), params()) if nv else (None, None)
+    leaves = [xa, *pa] + ([xv, *pv] if nv else [])
+
+    def run(fused: bool) -> list[torch.Tensor]:
+        conv.RESBLOCK_FUSE = fused
+        conv.invalidate_packs()
+        for t in leaves:
+            t.grad = None
+        try:
+            with torch.no_grad():  # which kernel the forward is
+                conv.residual_block(xa, *pa, act=act)
+            last = _lib.load().mtrssm_last_kernel().decode()
+            assert last.endswith("false, true>") == fused, last
+            if nv:
+                ya, yv = conv.residual_block_pair(xa, pa, xv, pv, act=act)
+                (ya.square().sum() + yv.sin().sum()).backward()
+                outs = [ya.detach(), yv.detach()]
+            else:
+                ya = conv.residual_block(xa, *pa, act=act)
+                ya.square().sum().backward()
+                outs = [ya.detach()]
+            torch.cuda.synchronize()
+        finally:
+            conv.RESBLOCK_FUSE = True
+        return outs + [t.grad.clone() for t in leaves]
+
+    two, one = run(False), run(True)
+    for i, (a, b) in enumerate(zip(one, two, strict=True)):
+        np.testing.assert_allclose(_np(a), _np(b), rtol=2e-5, atol=3e-6 * float(b.abs().max()), err_msg=str(i))
+    # float64 on the CPU
+    def ref(x: torch.Tensor, p: tuple) -> torch.Tensor:
+        w3, b3, w1, b1 = p
+        fn = F.elu if act == 2 else F.relu  # _lib.ACT_IDS
+        return x + F.conv2d(fn(F.conv2d(fn(x), w3, b3, 1, 1)), w1, b1)
+    cpu = [t.detach().double().cpu().requires_grad_(True) for t in leaves]
+    ya64 = ref(cpu[0], tuple(cpu[1:5]))
+    loss = ya64.square().sum()
+    outs64 = [ya64]
+    if nv:
+        yv64 = ref(cpu[5], tuple(cpu[6:10]))
+        loss = loss + yv64.sin().sum()
+        outs64.append(yv64)
+    loss.backward()
+    for i, (a, b) in enumerate(zip(one, [o.detach() for o in outs64] + [t.grad for t in cpu], strict=True)):
+        if act == 1 and i >= len(outs64):
+            break  # ReLU: an intermediate value within rounding of 0 switches its gradient on or off; the values are compared
+        np.testing.assert_allclose(_np(a), b.numpy(), rtol=1e-4, atol=4e-5 * float(b.abs().max()), err_msg=f"float64 {i}")
+
+
 def test_paired_launches_change_nothing(lib_loaded: None) -> None:
     """conv.paired (the audio and the vision stack's equal layers in one launch, the default) against one launch per
     layer: the gathers are the same arithmetic per output tile, so forward values are bit-identical; gradients are equal
