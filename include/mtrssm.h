@@ -469,7 +469,7 @@ int mtrssm_conv_gather_pair_merges(const MtrssmConvGeom* ga, const MtrssmConvGeo
  * (mtrssm_pack_conv_weight(s)), w1 [C][Cout] and b1 [C] the 1x1 module's own fp32 parameters (contiguous); two bf16 pieces per
  * operand and fp32 accumulation in both products, as the two separate launches compute.  A second block on another tensor
  * (gb != NULL: the other modality) rides in the same grid.  _supported: 1 when the shape has a fused instance (64 channels,
- * 128 intermediate channels, 64-pixel planes), else 0 -- a host-side query; mtrssm_residual_block_fwd on an unsupported shape
+ * 128 intermediate channels -- or 64 with an even frame count --, 64-pixel planes), else 0 -- a host-side query; mtrssm_residual_block_fwd on an unsupported shape
  * returns MTRSSM_EINVAL. */
 int mtrssm_residual_block_fwd_supported(const MtrssmConvGeom* g3);
 int mtrssm_residual_block_fwd(const MtrssmConvGeom* ga, const float* xa, const uint16_t* wq3a, const float* b3a, const float* w1a,

@@ -1722,11 +1722,12 @@ static bool resblock_fuse_enabled() {
 int conv_residual_fwd_supported(const MtrssmConvGeom* g) {
   if (!g || !resblock_fuse_enabled() || g->pre_act == 0 || g->mfma_split != 2 || g->C2 != 0) return 0;
   const SplitPlan pl = plan_split(g, true);
-  return pl.kind == 3 && pl.res == 64128 ? pl.res : 0;
+  return pl.kind == 3 && (pl.res == 64128 || pl.res == 64064) ? pl.res : 0;
 }
 
 static int residual_fwd_one_grid(const GatherProblem& pa, const GatherProblem& pb, int key, hipStream_t stream) {
-  const long ta = pa.nx, tb = pb.nx;  // one frame per tile
+  const int fpt = key == 64064 ? 2 : 1;  // frames per tile (the plan takes whole tiles only)
+  const long ta = pa.nx / fpt, tb = pb.nx / fpt;
   const int ncu = cu_count();
   GatherProblem qa = pa, qb = pb;
   if (tb == 0) {
@@ -1739,19 +1740,23 @@ static int residual_fwd_one_grid(const GatherProblem& pa, const GatherProblem& p
     qb.nx = (int)(ncu - na < tb ? ncu - na : tb);
   }
   const dim3 rgrid((unsigned)(qa.nx + qb.nx));
-  if (key == 64128) {
-    static bool attr_done_dev[64] = {};
-    bool& attr_done = attr_done_dev[device_slot()];
-    const size_t rl = res_lds_bytes<64, 4, 1>() + res_fuse_bytes<64, 4>();
-    if (!attr_done) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_resident_kernel<64, 4, 1, false, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl);
-      attr_done = true;
-    }
-    set_last_kernel("mtrssm::conv3x3_resident_kernel<64, 4, 1, false, true>");
-    hipLaunchKernelGGL((conv3x3_resident_kernel<64, 4, 1, false, true>), rgrid, dim3(kResThreads), rl, stream, qa, qb);
-    return launched("residual_block_fwd");
+#define MTRSSM_FUSE_LAUNCH(NCT_)                                                                                        \
+  {                                                                                                                    \
+    static bool attr_done_dev[64] = {};                                                                                \
+    bool& attr_done = attr_done_dev[device_slot()];                                                                    \
+    const size_t rl = res_lds_bytes<64, NCT_, 1>() + res_fuse_bytes<64, NCT_>();                                       \
+    if (!attr_done) {                                                                                                  \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_resident_kernel<64, NCT_, 1, false, true>),      \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl);                                  \
+      attr_done = true;                                                                                                \
+    }                                                                                                                  \
+    set_last_kernel("mtrssm::conv3x3_resident_kernel<64, " #NCT_ ", 1, false, true>");                                  \
+    hipLaunchKernelGGL((conv3x3_resident_kernel<64, NCT_, 1, false, true>), rgrid, dim3(kResThreads), rl, stream, qa, qb); \
+    return launched("residual_block_fwd");                                                                             \
   }
+  if (key == 64128) MTRSSM_FUSE_LAUNCH(4)
+  if (key == 64064) MTRSSM_FUSE_LAUNCH(2)
+#undef MTRSSM_FUSE_LAUNCH
   set_error("residual_block_fwd: no fused kernel for this shape");
   return MTRSSM_EINVAL;
 }

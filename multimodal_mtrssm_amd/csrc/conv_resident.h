@@ -82,7 +82,8 @@ __host__ __device__ constexpr size_t res_lds_bytes() {
 template <int CIN, int NCT>
 __host__ __device__ constexpr size_t res_fuse_bytes() {
   // W1 fragments [NCT][CIN / 32 tiles x 2 k-blocks][2 pieces][64 lanes] of 16 bytes + partial sums [4 waves][CIN / 2 rows][64 lanes]
-  return (size_t)NCT * (CIN / 32) * 2 * 2 * 64 * 16 + (size_t)4 * (CIN / 2) * 64 * sizeof(float);
+  // (NCT == 2: the 16 rows the partner wave finishes)
+  return (size_t)NCT * (CIN / 32) * 2 * 2 * 64 * 16 + (size_t)4 * (NCT == 2 ? 16 : CIN / 2) * 64 * sizeof(float);
 }
 
 template <int CIN, int NCT, int KS, bool EPI, bool FUSE = false>  // EPI: the epilogue has operands (act'(x) input and / or skip gradient)
@@ -475,19 +476,34 @@ __global__ __launch_bounds__(kResThreads, 1) void conv3x3_resident_kernel(const 
           }
         }
         lds_barrier();  // the previous unit's partial sums have been read by everyone
-        float* mine = red2 + (size_t)wave * (NOT * 16) * 64 + lane;
+        if constexpr (NCT == 2) {
+          // two waves per frame, two output tiles: each keeps the tile it finishes and hands the other one over
+          static_assert(NCT != 2 || NOT == 2, "one finished tile per wave");
+          float* mine = red2 + (size_t)wave * 16 * 64 + lane;
 #pragma unroll
-        for (int ot = 0; ot < NOT; ++ot)
+          for (int r = 0; r < 16; ++r) mine[r * 64] = ct ? acc2[0][r] : acc2[NOT - 1][r];
+          lds_barrier();
+          const float* theirs = red2 + (size_t)(pgi * 2 + (ct ^ 1)) * 16 * 64 + lane;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) mine[(ot * 16 + r) * 64] = acc2[ot][r];
-        lds_barrier();
-        const float* theirs = red2 + ((size_t)(pgi * NCT) * (NOT * 16) + ct * RF) * 64 + lane;
+          for (int j = 0; j < 16; ++j) {
+            const float keep = ct ? acc2[NOT - 1][j] : acc2[0][j];
+            out2[o2base + row_off(j)] = (keep + theirs[j * 64]) + (b1v[j] + xs[j]);
+          }
+        } else {
+          float* mine = red2 + (size_t)wave * (NOT * 16) * 64 + lane;
 #pragma unroll
-        for (int j = 0; j < RF; ++j) {
-          float v = b1v[j] + xs[j];
+          for (int ot = 0; ot < NOT; ++ot)
 #pragma unroll
-          for (int w = 0; w < NCT; ++w) v += theirs[((size_t)w * (NOT * 16) + j) * 64];
-          out2[o2base + row_off(j)] = v;
+            for (int r = 0; r < 16; ++r) mine[(ot * 16 + r) * 64] = acc2[ot][r];
+          lds_barrier();
+          const float* theirs = red2 + ((size_t)(pgi * NCT) * (NOT * 16) + ct * RF) * 64 + lane;
+#pragma unroll
+          for (int j = 0; j < RF; ++j) {
+            float v = b1v[j] + xs[j];
+#pragma unroll
+            for (int w = 0; w < NCT; ++w) v += theirs[((size_t)w * (NOT * 16) + j) * 64];
+            out2[o2base + row_off(j)] = v;
+          }
         }
       }
       __builtin_amdgcn_sched_barrier(0);

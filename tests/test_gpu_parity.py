@@ -837,12 +837,14 @@ def test_one_pass_parity_class_kernels_match_the_per_class_launches(lib_loaded: 
         np.testing.assert_allclose(_np(a), _np(b), rtol=2e-5, atol=(5e-6 if i == 7 else 2e-6) * float(b.abs().max()), err_msg=str(i))
 
 
-@pytest.mark.parametrize(("na", "nv", "plane_a", "plane_v", "act"),
-                         [(1, 0, (8, 8), None, 2), (37, 50, (8, 8), (16, 4), 2), (300, 700, (4, 16), (8, 8), 2), (260, 0, (8, 8), None, 1)])
+@pytest.mark.parametrize(("na", "nv", "plane_a", "plane_v", "act", "mid"),
+                         [(1, 0, (8, 8), None, 2, 128), (37, 50, (8, 8), (16, 4), 2, 128), (300, 700, (4, 16), (8, 8), 2, 128),
+                          (260, 0, (8, 8), None, 1, 128), (2, 0, (8, 8), None, 2, 64), (38, 50, (16, 4), (8, 8), 2, 64),
+                          (700, 300, (8, 8), (4, 16), 2, 64), (520, 0, (8, 8), None, 1, 64)])
 def test_fused_residual_block_matches_two_launches_and_float64(lib_loaded: None, na: int, nv: int, plane_a: tuple, plane_v: tuple | None,  # noqa: PLR0913
-                                                               act: int) -> None:
-    """mtrssm_residual_block_fwd (3x3 -> act -> 1x1 + skip in one launch, 64 channels / 128 intermediate channels on 64-pixel
-    planes) against the two-launch path (same two-piece products, another summation order in the 1x1) and against float64 on
+                                                               act: int, mid: int) -> None:
+    """mtrssm_residual_block_fwd (3x3 -> act -> 1x1 + skip in one launch, 64 channels / 128 or 64 intermediate channels on 64-pixel
+    planes: conv3x3_resident_kernel<64, 4 | 2, 1, false, true>) against the two-launch path (same two-piece products, another summation order in the 1x1) and against float64 on
     the CPU (`oracle/ref_cnn.py:ResidualBlock` arithmetic), values and every gradient; fewer frames than CUs, uneven pairs
     and several tiles per workgroup."""
     import torch.nn.functional as F  # noqa: N812
@@ -853,7 +855,7 @@ def test_fused_residual_block_matches_two_launches_and_float64(lib_loaded: None,
     def rnd(*shape: int, scale: float = 1.0) -> torch.Tensor:
         return (torch.randn(*shape, generator=gen) * scale).to(DEV).requires_grad_(True)
     def params() -> tuple:
-        return (rnd(128, 64, 3, 3, scale=0.05), rnd(128, scale=0.1), rnd(64, 128, 1, 1, scale=0.1), rnd(64, scale=0.1))
+        return (rnd(mid, 64, 3, 3, scale=0.05), rnd(mid, scale=0.1), rnd(64, mid, 1, 1, scale=0.1), rnd(64, scale=0.1))
     xa, pa = rnd(na, 64, *plane_a), params()
     xv, pv = (rnd(nv, 64, *plane_v), params()) if nv else (None, None)
     leaves = [xa, *pa] + ([xv, *pv] if nv else [])
