@@ -97,6 +97,22 @@ def test_invalid_arguments_are_rejected_without_a_launch() -> None:
     assert lib.mtrssm_categorical_sample_bwd(None, None, None, 4, 6, 5, None, None) == -1
     assert lib.mtrssm_elbo_combine_fwd(None, None, None, None, 10, 1.0, 0.0, None, None, None, None, None) == -1
     assert lib.mtrssm_elbo_combine_bwd(None, None, None, None, 10, 1.0, 0.0, None, None, None, None, None) == -1
+    assert lib.mtrssm_residual_block_fwd_supported(C.byref(_lib.ConvGeom())) == 0
+    assert lib.mtrssm_residual_block_fwd(C.byref(_lib.ConvGeom()), *([None] * 7), None, *([None] * 7), None) == -1
+    assert b"residual_block_fwd" in lib.mtrssm_last_error()
+
+    def block_geom(n: int, mid: int, act: int = 2, pre: int = 1) -> C.Structure:
+        g = _lib.ConvGeom()
+        for k, v in {"N": n, "C": 64, "Hs": 8, "Ws": 8, "Cpad": 64, "KH": 3, "KW": 3, "SS": 1, "TS": 1, "OFFY": -1, "OFFX": -1, "Hq": 8, "Wq": 8,
+                     "OS": 1, "Ho": 8, "Wo": 8, "Cout": mid, "CoutPad": mid, "pre_act": pre, "act": act, "mfma_split": 2}.items():
+            setattr(g, k, v)
+        return g
+
+    assert lib.mtrssm_residual_block_fwd_supported(C.byref(block_geom(5, 128))) == 1
+    assert lib.mtrssm_residual_block_fwd_supported(C.byref(block_geom(6, 64))) == 1
+    assert lib.mtrssm_residual_block_fwd_supported(C.byref(block_geom(5, 64))) == 0   # two frames per tile: whole tiles only
+    assert lib.mtrssm_residual_block_fwd_supported(C.byref(block_geom(6, 64, act=3))) == 0  # Tanh has no fused instance
+    assert lib.mtrssm_residual_block_fwd_supported(C.byref(block_geom(6, 64, pre=0))) == 0  # not a residual block's first conv
     large = _lib.MrssmDims(32, 100, 1024, 1024, 16, 8, 2, 1, 0.2, 0.8, 0, 0)
     assert lib.mtrssm_mrssm_wide_supported(C.byref(large), 3) == 0  # no device here: the grid cannot be sized
     assert lib.mtrssm_mrssm_wide_workspace_bytes(C.byref(large), 3) > 60e6  # six bytes per weight of the ~10 M scan weights
