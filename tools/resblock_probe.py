@@ -1,3 +1,4 @@
+"""Fused residual-block forward against float64, per frame (GPU box): `python tools/resblock_probe.py`."""
 import torch, torch.nn.functional as F, sys
 sys.path.insert(0, ".")
 from multimodal_mtrssm_amd import conv, _lib
