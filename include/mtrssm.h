@@ -516,7 +516,10 @@ int mtrssm_unpack_conv_grads(const int64_t* table, int32_t count, int32_t blocks
  * the same launch.  actgrad (may be NULL): out *= act'(actgrad[same index]) -- the backward-data of a Conv2d(k = 3, s = 2, p = 1)
  * is this transposed conv with the kernel zero-padded to 4 x 4 (the encoders' third conv).
  * mtrssm_convt_quad_supported: 1 / 2 = the instantiated forward shapes (64 -> 32 on 64-pixel planes, 32 -> 16 on 256-pixel planes),
- * 3 = 32 -> 16 on 64-pixel planes WITH actgrad; 0 = use the general path. */
+ * 3 = 32 -> 16 on 64-pixel planes WITH actgrad, 4 = 16 -> 8 on 256-pixel planes WITH actgrad; 0 = use the general path.
+ * Kernel selection inside: shapes 1 and 3 run one wave per parity class (csrc/conv_resident.h: convt_quad_resident_kernel),
+ * shapes 2 and 4 the classes as rows of the MFMA tile (csrc/conv_s2_band.h: convt4s2_rows_kernel); same arithmetic (two bf16
+ * pieces per operand, fp32 accumulation), another summation order. */
 int mtrssm_convt_quad_supported(const MtrssmConvGeom* g4);
 int mtrssm_convt_quad(const MtrssmConvGeom* ga4, const float* srca, const uint16_t* const* wqa4, const float* biasa, const float* actgrada,
                       float* outa, const MtrssmConvGeom* gb4, const float* srcb, const uint16_t* const* wqb4, const float* biasb,

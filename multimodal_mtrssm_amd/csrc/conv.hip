@@ -2407,6 +2407,37 @@ int conv_convt_quad_launch(const MtrssmConvGeom* ga4, const float* srca, const u
     qb.nx = (int)(ncu - na < tb ? ncu - na : tb);
   }
   const dim3 grid((unsigned)(qa.nx + qb.nx));
+  // The classes as tile rows (convt4s2_rows_kernel) where that form is faster: 32 -> 16 on 256-position frames (198 -> 158 us
+  // paired) and 16 -> 8 with the act' operand (144 -> 100 us); the 64-position frames stay on one wave per class (the rows form
+  // multiplies 2.25 x as much: 124 -> 189 us, 80 -> 103 us).  MTRSSM_CONVT_ROWS=<digits>: the keys (1..4) that use it ("0": none).
+  static const unsigned rows_mask = [] {
+    const char* e = getenv("MTRSSM_CONVT_ROWS");
+    if (!e) return (1u << 2) | (1u << 4);
+    unsigned m = 0;
+    for (; *e; ++e)
+      if (*e >= '1' && *e <= '4') m |= 1u << (*e - '0');
+    return m;
+  }();
+#define MTRSSM_ROWS_LAUNCH(CIN_, COUT_, PLANE_, EPI_)                                                                \
+  {                                                                                                                   \
+    static bool attr_done_dev[64] = {}; bool& attr_done = attr_done_dev[device_slot()];                               \
+    const size_t ql = convt_rows_lds_bytes<CIN_, PLANE_>();                                                           \
+    if (!attr_done) {                                                                                                 \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convt4s2_rows_kernel<CIN_, COUT_, PLANE_, EPI_>),       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ql);                                 \
+      attr_done = true;                                                                                               \
+    }                                                                                                                 \
+    set_last_kernel("mtrssm::convt4s2_rows_kernel<" #CIN_ ", " #COUT_ ", " #PLANE_ ", " #EPI_ ">");                      \
+    hipLaunchKernelGGL((convt4s2_rows_kernel<CIN_, COUT_, PLANE_, EPI_>), grid, dim3(64 * ((PLANE_ + 63) / 64) * (COUT_ / 8)), ql, stream, qa, qb); \
+    return launched("convt_quad(rows)");                                                                              \
+  }
+  if (rows_mask & (1u << key)) {
+    if (key == 1) MTRSSM_ROWS_LAUNCH(64, 32, 64, false)
+    if (key == 2) MTRSSM_ROWS_LAUNCH(32, 16, 256, false)
+    if (key == 3) MTRSSM_ROWS_LAUNCH(32, 16, 64, true)
+    if (key == 4) MTRSSM_ROWS_LAUNCH(16, 8, 256, true)
+  }
+#undef MTRSSM_ROWS_LAUNCH
 #define MTRSSM_QUAD_LAUNCH(CIN_, COUT_, PLANE_, EPI_)                                                                \
   {                                                                                                                   \
     static bool attr_done_dev[64] = {}; bool& attr_done = attr_done_dev[device_slot()];                                                                                    \

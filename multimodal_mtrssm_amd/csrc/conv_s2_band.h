@@ -556,4 +556,212 @@ __global__ __launch_bounds__(64 * (PLANE / 128) * (COUT / 32), 1) void conv4s2_b
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// ConvTranspose2d(k = 4, s = 2, p = 1) with the four output parity classes as ROWS of the MFMA tile (the recipe of
+// convt4s2_band_kernel, for the decoders' first two layers and the backward-data of the encoders' stride-2 convs): a tile row is
+// (output channel, class) = 4 co + q, a column an INPUT position, K runs over the position's 3 x 3 neighbourhood x input
+// channels (a class uses 4 of the 9 neighbours, the other weights are zero: 2.25 x the products, all 32 rows live).  A lane's
+// four consecutive accumulator rows are the 2 x 2 output block of one channel at (2 iy, 2 ix): two 8-byte stores per channel,
+// whole lines per wave -- convt_quad_resident_kernel (one WAVE per class) stores 4-byte words at stride 8 and ran at
+// 2.5-3.2 TB/s.  The frame is staged once ([piece][channel octet][haloed position] 16-byte rows, zero border written once per
+// launch), the weights are A operands in registers for the whole launch (gathered from the four packed 2 x 2 sub-kernels the
+// quad entry already takes), a wave multiplies one row tile x two 32-position units (two independent chains, one A fragment).
+// ------------------------------------------------------------------------------------------------
+template <int CIN, int COUT, int PLANE, bool EPI>
+__global__ __launch_bounds__(64 * ((PLANE + 63) / 64) * (COUT / 8), 1) void convt4s2_rows_kernel(const QuadProblem pa, const QuadProblem pb) {
+  constexpr int UP = PLANE / 64, CTS = COUT / 8, NW = UP * CTS, NT = 64 * NW;   // unit pairs x row tiles = waves
+  constexpr int OCT = CIN / 8, GPT = CIN / 16, KB = 9 * GPT;
+  constexpr int NITEM = (PLANE / 4) * (CIN / 4) / NT;             // (4 positions x 4 channels) items per thread
+  static_assert(NITEM * NT == (PLANE / 4) * (CIN / 4) && NITEM >= 1 && UP >= 1 && CTS >= 1, "whole items");
+  const bool second = blockIdx.x >= (unsigned)pa.nx;  // workgroup-uniform
+  // (every field is selected by itself: a reference to "second ? pb : pa" made the compiler copy both structs to scratch here)
+#define MTRSSM_PICK(f) (second ? pb.f : pa.f)
+  struct {
+    const float* src;
+    const float* bias;
+    const float* actgrad;
+    float* out;
+  } P{MTRSSM_PICK(src), MTRSSM_PICK(bias), MTRSSM_PICK(actgrad), MTRSSM_PICK(out)};
+  const int wg = second ? (int)blockIdx.x - pa.nx : (int)blockIdx.x, nwg = MTRSSM_PICK(nx);
+  const int Ws = MTRSSM_PICK(g[0].Ws), Hs = MTRSSM_PICK(g[0].Hs);   // host: Hs * Ws == PLANE, Ws a power of two
+  const int wsh = 31 - __builtin_clz(Ws);
+  const int ntiles = MTRSSM_PICK(g[0].N);
+  const int g_act = MTRSSM_PICK(g[0].act), g_pre = MTRSSM_PICK(g[0].pre_act);
+  const int PW = Ws + 2;
+  const int NPOS = (Hs + 2) * PW + 1;
+  const int OSZ = NPOS * 16, IMG = OCT * OSZ;               // one octet plane / one piece
+  const int Wo = 2 * Ws;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, il = lane & 31, kl = lane >> 5;
+  if (wg >= ntiles) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char band_lds[];  // [2 pieces][OCT][NPOS] x 16 B
+  const int up = wave % UP, ct = wave / UP;
+
+  // A operands: row il of tile ct = (output channel co, class q); k-block kb = (neighbour t = kb / GPT, channel group kb % GPT);
+  // class q reads neighbour (dy, dx) with tap (ty, tx) = (OFFY_q - dy, OFFX_q - dx) of its packed 2 x 2 sub-kernel
+  bf16x8 a[KB][2];
+  {
+    const int R = 32 * ct + il, co = R >> 2, q = R & 3;
+    const unsigned short* wq = q == 0 ? MTRSSM_PICK(wq[0]) : (q == 1 ? MTRSSM_PICK(wq[1]) : (q == 2 ? MTRSSM_PICK(wq[2]) : MTRSSM_PICK(wq[3])));
+    const int offy = q == 0 ? MTRSSM_PICK(g[0].OFFY) : (q == 1 ? MTRSSM_PICK(g[1].OFFY) : (q == 2 ? MTRSSM_PICK(g[2].OFFY) : MTRSSM_PICK(g[3].OFFY)));
+    const int offx = q == 0 ? MTRSSM_PICK(g[0].OFFX) : (q == 1 ? MTRSSM_PICK(g[1].OFFX) : (q == 2 ? MTRSSM_PICK(g[2].OFFX) : MTRSSM_PICK(g[3].OFFX)));
+#undef MTRSSM_PICK
+    const size_t piece = (size_t)32 * 4 * CIN;  // host: CoutPad == 32, Cpad == CIN
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const int t = kb / GPT, dy = t / 3 - 1, dx = t % 3 - 1;
+      const int ty = offy - dy, tx = offx - dx;
+      const bool live = ty >= 0 && ty < 2 && tx >= 0 && tx < 2;
+      const size_t wofs = ((size_t)co * 4 + (live ? ty * 2 + tx : 0)) * CIN + 16 * (kb % GPT) + 8 * kl;  // unconditional requests, selected afterwards
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(wq + s * piece + wofs);
+        a[kb][s] = __builtin_bit_cast(bf16x8, live ? v : u32x4{0u, 0u, 0u, 0u});
+      }
+    }
+  }
+  for (int o = tid * 16; o < 2 * IMG; o += NT * 16) *reinterpret_cast<u32x4*>(band_lds + o) = u32x4{0u, 0u, 0u, 0u};
+
+  band_f4 pv[NITEM][4];
+  auto request = [&](int tile) {
+    const __amdgpu_buffer_rsrc_t rsf =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.src + (size_t)tile * CIN * PLANE), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < NITEM; ++k) {
+      const int it = tid + NT * k, pg = it % (PLANE / 4), cq = it / (PLANE / 4);
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        pv[k][c] = __builtin_bit_cast(band_f4, __builtin_amdgcn_raw_buffer_load_b128(rsf, ((4 * cq + c) * PLANE + 4 * pg) * 4, 0, 0));
+    }
+  };
+  const int act = g_act;
+  const int mode = g_pre == 0 ? 0 : (act == MTRSSM_ACT_ELU ? 1 : 2);
+  auto stage_as = [&](auto mode_tag) {
+    constexpr int MODE = decltype(mode_tag)::value;
+    auto activate = [&](float v) {
+      if (MODE == 1) v = elu_fast(v);
+      if (MODE == 2) v = act_fwd(v, act);
+      return v;
+    };
+#pragma unroll
+    for (int k = 0; k < NITEM; ++k) {
+      const int it = tid + NT * k, pg = it % (PLANE / 4), cq = it / (PLANE / 4);
+      const int p = pg * 4, r = p >> wsh, x = p & (Ws - 1);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        unsigned short h[4][2];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) split_bf16<2>(activate(pv[k][c][e]), h[c]);
+        unsigned char* d = band_lds + (cq >> 1) * OSZ + ((r + 1) * PW + x + e + 1) * 16 + (cq & 1) * 8;
+        *reinterpret_cast<uint2*>(d) = make_uint2((unsigned)h[0][0] | ((unsigned)h[1][0] << 16), (unsigned)h[2][0] | ((unsigned)h[3][0] << 16));
+        *reinterpret_cast<uint2*>(d + IMG) = make_uint2((unsigned)h[0][1] | ((unsigned)h[1][1] << 16), (unsigned)h[2][1] | ((unsigned)h[3][1] << 16));
+      }
+    }
+  };
+  auto stage = [&]() {
+    if (mode == 0) stage_as(std::integral_constant<int, 0>{});
+    else if (mode == 1) stage_as(std::integral_constant<int, 1>{});
+    else stage_as(std::integral_constant<int, 2>{});
+  };
+
+  // this wave's two units: input position j = 64 up + 32 u + il -> (iy, ix); the lane's accumulator rows 4 i + q are the classes
+  // of output channel 8 ct + kl + 2 i
+  unsigned bb[2];
+  int opx[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int j = 64 * up + 32 * u + il, iy = j >> wsh, ix = j & (Ws - 1);
+    bb[u] = (unsigned)(kl * OSZ + ((iy + 1) * PW + ix + 1) * 16);
+    opx[u] = (2 * iy) * Wo + 2 * ix;
+  }
+  const float* __restrict__ actgrad = P.actgrad;  // host: non-null exactly in the EPI instantiation
+  const float* __restrict__ bias = P.bias;
+  const bool act_elu = act == MTRSSM_ACT_ELU, act_relu = act == MTRSSM_ACT_RELU;
+  float bv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) bv[i] = bias ? bias[8 * ct + kl + 2 * i] : 0.f;
+  auto frag_off = [&](int kb) {
+    const int t = kb / GPT;
+    return ((t / 3 - 1) * PW + (t % 3 - 1)) * 16 + (2 * (kb % GPT)) * OSZ;
+  };
+  auto compute = [&](int tile) {
+    const size_t obase = ((size_t)tile * COUT + 8 * ct + kl) * (size_t)(4 * PLANE);
+    float2 gv[EPI ? 2 : 1][EPI ? 8 : 1];
+    if constexpr (EPI) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float* gp = actgrad + obase + (size_t)(2 * i) * (4 * PLANE) + opx[u];
+          gv[u][2 * i] = *reinterpret_cast<const float2*>(gp);
+          gv[u][2 * i + 1] = *reinterpret_cast<const float2*>(gp + Wo);
+        }
+    }
+    f32x16 acc[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[u][r] = bv[r >> 2];
+    bf16x8 q0[2][2], q1[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      q0[0][u] = *reinterpret_cast<const bf16x8*>(band_lds + (int)bb[u] + frag_off(0));
+      q1[0][u] = *reinterpret_cast<const bf16x8*>(band_lds + (int)bb[u] + frag_off(0) + IMG);
+    }
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const int st = kb & 1;
+      if (kb + 1 < KB) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          q0[st ^ 1][u] = *reinterpret_cast<const bf16x8*>(band_lds + (int)bb[u] + frag_off(kb + 1));
+          q1[st ^ 1][u] = *reinterpret_cast<const bf16x8*>(band_lds + (int)bb[u] + frag_off(kb + 1) + IMG);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kb][0], q1[st][u], acc[u], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kb][1], q0[st][u], acc[u], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kb][0], q0[st][u], acc[u], 0, 0, 0);
+    }
+    auto egrad = [&](float x) {
+      const float e = __expf(x);
+      const float neg = act_elu ? e : (act_relu ? 0.f : 1.f);
+      return x > 0.f ? 1.f : neg;
+    };
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float2 top = make_float2(acc[u][4 * i], acc[u][4 * i + 1]), bot = make_float2(acc[u][4 * i + 2], acc[u][4 * i + 3]);
+        if constexpr (EPI) {
+          top.x *= egrad(gv[u][2 * i].x);
+          top.y *= egrad(gv[u][2 * i].y);
+          bot.x *= egrad(gv[u][2 * i + 1].x);
+          bot.y *= egrad(gv[u][2 * i + 1].y);
+        }
+        float* op = P.out + obase + (size_t)(2 * i) * (4 * PLANE) + opx[u];
+        *reinterpret_cast<float2*>(op) = top;
+        *reinterpret_cast<float2*>(op + Wo) = bot;
+      }
+  };
+  const int last = wg + ((ntiles - 1 - wg) / nwg) * nwg;
+  request(wg);
+  __syncthreads();  // the zero fill
+  for (int tile = wg; tile < ntiles; tile += nwg) {
+    stage();
+    const int nx = tile + nwg;
+    request(nx < last ? nx : last);
+    lds_barrier();
+    compute(tile);
+    lds_barrier();
+  }
+}
+
+template <int CIN, int PLANE>
+__host__ __device__ constexpr size_t convt_rows_lds_bytes() {
+  // haloed positions: the widest plane of the shape (PLANE = 64: 18 x 6, 256: 34 x 10, 1024: 66 x 18) + 1
+  return (size_t)2 * (CIN / 8) * ((PLANE == 64 ? 108 : (PLANE == 256 ? 340 : 1188)) + 1) * 16;
+}
+
 }  // namespace mtrssm
