@@ -850,6 +850,95 @@ __global__ __launch_bounds__(kConvThreads) void conv_gather_thin_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// Conv2d(k = 4, s = 2, p = 1) gather from ONE input channel to 16 output channels: the backward-data of the decoders' last
+// ConvTranspose layer (default.yaml:70-74; out *= act'(layer input)).  conv_gather_thin_kernel<16> spends 48 memory
+// instructions and 64 LDS weight reads on a pixel's 256 FMAs (3.6 TB/s).  Here a thread owns TWO horizontally adjacent output
+// pixels: their 4 x 6 source window is 16 loads (aligned pairs + the two edge columns), a tap's 16 weights are read once for
+// both pixels, the act' operand and the output go as 8-byte pairs: 24 memory instructions and 32 LDS reads per pixel.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void conv4s2_c1_thin16_kernel(const MtrssmConvGeom g, const float* __restrict__ src, const float* __restrict__ wp,
+                                                                const float* __restrict__ bias, const float* __restrict__ actgrad_in,
+                                                                float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float w_lds[16 * 16];  // [tap][output channel]
+  const int tid = threadIdx.x;
+  w_lds[tid] = wp[((size_t)(tid & 15) * 16 + (tid >> 4)) * g.Cpad];  // host: 256 threads; wp [CoutPad][16 taps][Cpad], channel 0
+  __syncthreads();
+  const int Wq = g.Wq, Hq = g.Hq, Ws = g.Ws, Hs = g.Hs;  // host: Ws == 2 Wq, Hs == 2 Hq, Wq even
+  const int hw = Wq >> 1, ppf = Hq * hw;
+  const long pair = (long)blockIdx.x * 256 + tid;
+  const int n = (int)(pair / ppf);
+  if (n >= g.N) return;
+  const int rem = (int)(pair - (long)n * ppf), oy = rem / hw, ox = 2 * (rem - oy * hw);
+  const float* __restrict__ s = src + (size_t)n * Hs * Ws;
+  // source rows 2 oy - 1 .. 2 oy + 2, columns 2 ox - 1 .. 2 ox + 4: unconditional loads from clamped addresses, selected afterwards
+  float v[4][6];
+  const bool lv = ox > 0, rv = 2 * ox + 4 < Ws;
+#pragma unroll
+  for (int ky = 0; ky < 4; ++ky) {
+    const int sy = 2 * oy - 1 + ky;
+    const bool ok = sy >= 0 && sy < Hs;
+    const float* row = s + (size_t)(ok ? sy : 0) * Ws + 2 * ox;
+    const float l = row[lv ? -1 : 0], r = row[rv ? 4 : 3];
+    const float2 m0 = *reinterpret_cast<const float2*>(row), m1 = *reinterpret_cast<const float2*>(row + 2);
+    v[ky][0] = ok && lv ? l : 0.f;
+    v[ky][1] = ok ? m0.x : 0.f;
+    v[ky][2] = ok ? m0.y : 0.f;
+    v[ky][3] = ok ? m1.x : 0.f;
+    v[ky][4] = ok ? m1.y : 0.f;
+    v[ky][5] = ok && rv ? r : 0.f;
+  }
+  const size_t plane_o = (size_t)Hq * Wq;
+  const size_t base = (size_t)n * 16 * plane_o + (size_t)oy * Wq + ox;
+  float2 gv[16];
+  {
+    const float* gsafe = actgrad_in ? actgrad_in : out;  // any readable address of the same shape: the value is dropped
+#pragma unroll
+    for (int j = 0; j < 16; ++j) gv[j] = *reinterpret_cast<const float2*>(gsafe + base + (size_t)j * plane_o);
+  }
+  float a0[16], a1[16];
+  {
+    const float* bsafe = bias ? bias : w_lds;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float b = bsafe[j];
+      a0[j] = a1[j] = bias ? b : 0.f;
+    }
+  }
+#pragma unroll
+  for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx) {
+      asm volatile("" ::: "memory");  // keeps a tap's four weight reads at the tap (hoisted to the top they are 256 registers)
+      const float4* w4 = reinterpret_cast<const float4*>(w_lds + (ky * 4 + kx) * 16);
+      const float p0 = v[ky][kx], p1 = v[ky][kx + 2];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 w = w4[q];
+        a0[4 * q] = fmaf(p0, w.x, a0[4 * q]);
+        a0[4 * q + 1] = fmaf(p0, w.y, a0[4 * q + 1]);
+        a0[4 * q + 2] = fmaf(p0, w.z, a0[4 * q + 2]);
+        a0[4 * q + 3] = fmaf(p0, w.w, a0[4 * q + 3]);
+        a1[4 * q] = fmaf(p1, w.x, a1[4 * q]);
+        a1[4 * q + 1] = fmaf(p1, w.y, a1[4 * q + 1]);
+        a1[4 * q + 2] = fmaf(p1, w.z, a1[4 * q + 2]);
+        a1[4 * q + 3] = fmaf(p1, w.w, a1[4 * q + 3]);
+      }
+    }
+  // act' as lane-uniform selects (host: no Tanh): a branch per element splits the epilogue into hundreds of blocks
+  const bool elu = g.act == MTRSSM_ACT_ELU, relu = g.act == MTRSSM_ACT_RELU, has_g = actgrad_in != nullptr;
+  auto egrad = [&](float x) {
+    float e = __expf(x);
+    asm volatile("" : "+v"(e));
+    const float neg = elu ? e : (relu ? 0.f : 1.f);
+    const float m = x > 0.f ? 1.f : neg;
+    return has_g ? m : 1.f;
+  };
+#pragma unroll
+  for (int j = 0; j < 16; ++j)
+    *reinterpret_cast<float2*>(out + base + (size_t)j * plane_o) = make_float2(a0[j] * egrad(gv[j].x), a1[j] * egrad(gv[j].y));
+}
+
+// ------------------------------------------------------------------------------------------------
 // Last decoder layer: ConvTranspose2d(k = 4, s = 2, p = 1) to <= 2 output channels with the preceding activation
 // fused.  The generic thin kernel runs one launch per output parity class and re-activates every source value once
 // per tap (expm1f dominates its instruction stream).  Here a workgroup stages act(x) for an 8 x 32 tile of INPUT
@@ -1610,6 +1699,17 @@ int conv_gather_gemm_launch(const MtrssmConvGeom* g, const float* src, const flo
     GatherProblem p{};
     p.g = *g; p.src = src; p.wq = wq; p.bias = bias; p.actgrad_in = actgrad_in; p.out = out;
     return launch_s2k4_band(p, nullptr, stream);
+  }
+  // MTRSSM_THIN16_PAIRS=0: conv_gather_thin_kernel<16> for the one-channel k = 4 stride-2 gather too (A/B runs)
+  static const bool thin16_pairs = [] { const char* e = getenv("MTRSSM_THIN16_PAIRS"); return !(e && e[0] == '0'); }();
+  if (thin16_pairs && g->C == 1 && g->C2 == 0 && g->Cout == 16 && g->KH == 4 && g->KW == 4 && g->SS == 2 && g->TS == 1 && g->OFFY == -1 && g->OFFX == -1 &&
+      g->OS == 1 && g->QY == 0 && g->QX == 0 && g->pre_act == 0 && !add_in && g->Hs == 2 * g->Hq && g->Ws == 2 * g->Wq && g->Ho == g->Hq &&
+      g->Wo == g->Wq && g->Wq % 2 == 0 && g->Ws % 2 == 0 && g->act != MTRSSM_ACT_TANH && !((uintptr_t)src & 7) && !((uintptr_t)out & 7) && !((uintptr_t)actgrad_in & 7) &&
+      kConvThreads == 256) {
+    const long pairs = (long)g->N * g->Hq * (g->Wq / 2);
+    set_last_kernel("mtrssm::conv4s2_c1_thin16_kernel");
+    hipLaunchKernelGGL(conv4s2_c1_thin16_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, stream, *g, src, wp, bias, actgrad_in, out);
+    return launched("conv_gather_gemm(thin16 pairs)");
   }
   if ((g->Cout <= 8 || g->C + g->C2 <= 2) && g->Cout <= 16 && g->KH * g->KW * (g->C + g->C2) <= kThinMaxK) {  // thin layer: VALU kernel
     const dim3 grid((unsigned)((ptot + kConvThreads - 1) / kConvThreads));
