@@ -2508,7 +2508,7 @@ int conv_convt_quad_launch(const MtrssmConvGeom* ga4, const float* srca, const u
   }
   const dim3 grid((unsigned)(qa.nx + qb.nx));
   // The classes as tile rows (convt4s2_rows_kernel) where that form is faster: 32 -> 16 on 256-position frames (198 -> 158 us
-  // paired) and 16 -> 8 with the act' operand (144 -> 100 us); the 64-position frames stay on one wave per class (the rows form
+  // paired) and 16 -> 8 with the act' operand (144 -> 88 us); the 64-position frames stay on one wave per class (the rows form
   // multiplies 2.25 x as much: 124 -> 189 us, 80 -> 103 us).  MTRSSM_CONVT_ROWS=<digits>: the keys (1..4) that use it ("0": none).
   static const unsigned rows_mask = [] {
     const char* e = getenv("MTRSSM_CONVT_ROWS");
@@ -2522,6 +2522,16 @@ int conv_convt_quad_launch(const MtrssmConvGeom* ga4, const float* srca, const u
   {                                                                                                                   \
     static bool attr_done_dev[64] = {}; bool& attr_done = attr_done_dev[device_slot()];                               \
     const size_t ql = convt_rows_lds_bytes<CIN_, PLANE_>();                                                           \
+    const int slots = ncu * convt_rows_wgs(CIN_, COUT_, PLANE_);   /* persistent workgroups: this kernel's share of a CU */ \
+    if (tb == 0) {                                                                                                    \
+      qa.nx = (int)(ta < slots ? ta : slots);                                                                         \
+    } else {                                                                                                          \
+      long na = (slots * ta + (ta + tb) / 2) / (ta + tb);                                                             \
+      na = na < 1 ? 1 : (na > slots - 1 ? slots - 1 : na);                                                            \
+      qa.nx = (int)(na < ta ? na : ta);                                                                               \
+      qb.nx = (int)(slots - na < tb ? slots - na : tb);                                                               \
+    }                                                                                                                 \
+    const dim3 grid((unsigned)(qa.nx + qb.nx));                                                                       \
     if (!attr_done) {                                                                                                 \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convt4s2_rows_kernel<CIN_, COUT_, PLANE_, EPI_>),       \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)ql);                                 \

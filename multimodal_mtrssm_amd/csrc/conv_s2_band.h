@@ -567,8 +567,16 @@ __global__ __launch_bounds__(64 * (PLANE / 128) * (COUT / 32), 1) void conv4s2_b
 // launch), the weights are A operands in registers for the whole launch (gathered from the four packed 2 x 2 sub-kernels the
 // quad entry already takes), a wave multiplies one row tile x two 32-position units (two independent chains, one A fragment).
 // ------------------------------------------------------------------------------------------------
+// Workgroups per CU: a workgroup's waves stage (VALU) and multiply (MFMA) in lockstep around its one image buffer; where the
+// registers allow it, several workgroups per CU run those phases against each other (16 -> 8 with act': 100 -> 88 us; the
+// 32 -> 16 shape as four waves x two jobs, which would fit twice, spills 100+ registers).
+__host__ __device__ constexpr int convt_rows_wgs(int cin, int cout, int plane) {
+  const int waves = (plane / 64) * (cout / 8), a_regs = 9 * (cin / 16) * 8;
+  return a_regs > 160 ? 1 : (waves <= 2 ? 4 : (waves <= 4 ? 2 : 1));
+}
 template <int CIN, int COUT, int PLANE, bool EPI>
-__global__ __launch_bounds__(64 * ((PLANE + 63) / 64) * (COUT / 8), 1) void convt4s2_rows_kernel(const QuadProblem pa, const QuadProblem pb) {
+__global__ __launch_bounds__(64 * (PLANE / 64) * (COUT / 8), (convt_rows_wgs(CIN, COUT, PLANE) * (PLANE / 64) * (COUT / 8) + 3) / 4)  // (threads, waves per SIMD)
+void convt4s2_rows_kernel(const QuadProblem pa, const QuadProblem pb) {
   constexpr int UP = PLANE / 64, CTS = COUT / 8, NW = UP * CTS, NT = 64 * NW;   // unit pairs x row tiles = waves
   constexpr int OCT = CIN / 8, GPT = CIN / 16, KB = 9 * GPT;
   constexpr int NITEM = (PLANE / 4) * (CIN / 4) / NT;             // (4 positions x 4 channels) items per thread
