@@ -2552,6 +2552,16 @@ int conv_convt_quad_launch(const MtrssmConvGeom* ga4, const float* srca, const u
   {                                                                                                                   \
     static bool attr_done_dev[64] = {}; bool& attr_done = attr_done_dev[device_slot()];                                                                                    \
     const size_t ql = quad_lds_bytes<CIN_, PLANE_>();                                                                 \
+    const int slots = ncu * quad_wgs(CIN_, PLANE_);                                                                         \
+    if (tb == 0) {                                                                                                    \
+      qa.nx = (int)(ta < slots ? ta : slots);                                                                         \
+    } else {                                                                                                          \
+      long na = (slots * ta + (ta + tb) / 2) / (ta + tb);                                                             \
+      na = na < 1 ? 1 : (na > slots - 1 ? slots - 1 : na);                                                            \
+      qa.nx = (int)(na < ta ? na : ta);                                                                               \
+      qb.nx = (int)(slots - na < tb ? slots - na : tb);                                                               \
+    }                                                                                                                 \
+    const dim3 grid((unsigned)(qa.nx + qb.nx));                                                                       \
     if (!attr_done) {                                                                                                 \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convt_quad_resident_kernel<CIN_, COUT_, PLANE_, EPI_>), \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)ql);                                 \

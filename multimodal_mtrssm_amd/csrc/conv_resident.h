@@ -548,8 +548,11 @@ __host__ __device__ constexpr size_t quad_lds_bytes() {
   return (size_t)4 * (PLANE == 64 ? 108 : 340) * res_row_bytes(CIN);  // haloed positions: 10x10 / 18x6, 18x18 / 34x10
 }
 
+// 32 -> 16 on 64-position frames: two workgroups per CU (registers and images fit twice: 80 -> 75 us; the 64 -> 32 instance
+// at half its registers spills and runs 118 -> 123 us)
+__host__ __device__ constexpr int quad_wgs(int cin, int plane) { return plane == 64 && cin <= 32 ? 2 : 1; }
 template <int CIN, int COUT, int PLANE, bool EPI>
-__global__ __launch_bounds__(kResThreads, 1) void convt_quad_resident_kernel(const QuadProblem qa, const QuadProblem qb) {
+__global__ __launch_bounds__(kResThreads, quad_wgs(CIN, PLANE)) void convt_quad_resident_kernel(const QuadProblem qa, const QuadProblem qb) {
   constexpr int CB = CIN / 16, KB = 4 * CB;
   constexpr int RB = res_row_bytes(CIN);
   constexpr int NPOS = PLANE == 64 ? 108 : 340;
